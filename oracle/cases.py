@@ -1,0 +1,119 @@
+"""TEST INFRASTRUCTURE ONLY -- seeded parity cases shared by make_golden.py (reference side),
+the CPU oracle tests and the GPU parity tests.
+
+Inputs and weights are regenerated from seeds with a CPU torch.Generator (bit-identical in
+the build container and on the GPU box: same image, same torch build); the committed
+fixtures hold the *reference outputs* plus checksums of the regenerated inputs/weights so a
+generator drift fails loudly instead of silently comparing different problems.
+"""
+import math
+from typing import Dict
+
+import torch
+
+from . import dit as O
+from . import vae as OV
+
+Tensor = torch.Tensor
+
+
+def checksum(tensors: Dict[str, Tensor]) -> Tensor:
+    """Order-independent fingerprint: per-tensor (sum, abs-sum) in fp64, keyed by sorted name."""
+    vals = []
+    for k in sorted(tensors):
+        t = tensors[k].to(torch.float64)
+        vals += [t.sum().item(), t.abs().sum().item()]
+    return torch.tensor(vals, dtype=torch.float64)
+
+
+def randn(gen, *shape):
+    return torch.randn(*shape, generator=gen, dtype=torch.float32)
+
+
+# ----------------------------------------------------------------------------- DiT cases
+def dit_case(cfg: dict, seed: int, frames: int = 3, h: int = 16, w: int = 16, batch: int = 2, per_token_t: bool = True,
+             t_value: float = 731.5, text_lens=(5, 11)) -> dict:
+    """Synthetic FlexAM DiT call (all FlexAM inputs: y, additional_control, full_ref, density).
+    latent [B,48,frames,h,w]; tokens = frames*(h/2)*(w/2) (+ (h/2)*(w/2) ref tokens)."""
+    g = torch.Generator().manual_seed(seed)
+    c = cfg["out_dim"]
+    x = randn(g, batch, c, frames, h, w)
+    y = randn(g, batch, cfg["in_dim"] - c, frames, h, w)
+    add = randn(g, batch, cfg["in_dim_cnn_block"] - c, frames, h, w)
+    ref = randn(g, batch, cfg["in_dim_ref_conv"], h, w)
+    ctx = [randn(g, text_lens[i % len(text_lens)], cfg["text_dim"]) for i in range(batch)]
+    seq_len = frames * (h // 2) * (w // 2)
+    if per_token_t:
+        t = torch.full((batch, seq_len), t_value)
+        t[:, : (h // 2) * (w // 2)] = 0.0            # frame-0 tokens pinned (PIPE.py:891-898)
+    else:
+        t = torch.tensor([500.0, 24.4, 1000.0, 0.0][:batch])
+    dens = torch.full((batch,), 0.1)
+    return dict(x=x, t=t, context=ctx, seq_len=seq_len, y=y, full_ref=ref, additional_control=add, density=dens)
+
+
+def dit_weights(cfg: dict, seed: int) -> Dict[str, Tensor]:
+    return O.seeded_state_dict(O.dit_param_shapes(cfg), seed)
+
+
+def block_case(dim: int = 256, ffn: int = 512, heads: int = 2, grid=(4, 8, 8), text: int = 16, seed: int = 11) -> dict:
+    """One WanAttentionBlock (G3): L = prod(grid), per-token e0 with two distinct rows."""
+    g = torch.Generator().manual_seed(seed)
+    l = grid[0] * grid[1] * grid[2]
+    x = randn(g, 2, l, dim)
+    rows = randn(g, 2, 2, 6, dim) * 0.5                 # [B, 2 distinct, 6, C]
+    sel = torch.zeros(l, dtype=torch.long)
+    sel[grid[1] * grid[2]:] = 1
+    e0 = rows[:, sel]                                   # [B, L, 6, C]
+    dens0 = randn(g, 2, 2, dim) * 0.5
+    ctx = randn(g, 2, text, dim)
+    return dict(x=x, e0=e0, e_rows=rows, sel=sel, dens0=dens0, context=ctx, grid=grid, heads=heads, dim=dim, ffn=ffn)
+
+
+def block_weights(dim: int, ffn: int, seed: int = 12) -> Dict[str, Tensor]:
+    cfg = dict(O.DIT_TINY, dim=dim, ffn_dim=ffn, num_layers=1)
+    shapes = {k[len("blocks.0."):]: v for k, v in O.dit_param_shapes(cfg).items() if k.startswith("blocks.0.")}
+    return O.seeded_state_dict(shapes, seed)
+
+
+# ----------------------------------------------------------------------------- sampler case (BASELINE config 1)
+def sampler_case(cfg: dict, seed: int = 21, frames: int = 3, h: int = 16, w: int = 16) -> dict:
+    """9x256x256 -> latent [1,48,3,16,16]; motion_transfer mask (frame 0 known)."""
+    g = torch.Generator().manual_seed(seed)
+    c = cfg["out_dim"]
+    latents = randn(g, 1, c, frames, h, w)
+    control = randn(g, 1, c, frames, h, w)
+    add = randn(g, 1, cfg["in_dim_cnn_block"] - c, frames, h, w)
+    masked = randn(g, 1, c, frames, h, w)
+    ref = randn(g, 1, cfg["in_dim_ref_conv"], h, w)
+    ctx_u = [randn(g, 4, cfg["text_dim"]) * 0.1]
+    ctx_c = [randn(g, 9, cfg["text_dim"]) * 0.1]
+    fpix = 1 + 4 * (frames - 1)
+    mask_pix = torch.ones(1, 1, fpix, h * 16, w * 16)
+    mask_pix[:, :, 0] = 0                                # frame 0 kept (demo.py:88,107-111)
+    return dict(latents=latents, control_latents=control, additional_control=add, masked_video_latents=masked,
+                ref_latents=ref, context_uncond=ctx_u, context_cond=ctx_c, mask_pixels=mask_pix, density=0.1,
+                guidance_scale=6.0, num_steps=4)
+
+
+# ----------------------------------------------------------------------------- VAE cases
+VAE_SMALL = dict(z_dim=48, dec_dim=16, dim_mult=(1, 2, 4, 4), temporal_up=(True, True, False))
+
+
+def vae_weights(vcfg: dict, seed: int = 31, prefix: str = "model.") -> Dict[str, Tensor]:
+    shp = OV.vae_decoder_param_shapes(vcfg["z_dim"], vcfg["dec_dim"], vcfg["dim_mult"], vcfg["temporal_up"], prefix)
+    return O.seeded_state_dict(shp, seed)
+
+
+def vae_case(seed: int = 32, frames: int = 3, h: int = 4, w: int = 4, z_dim: int = 48) -> Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return randn(g, 1, z_dim, frames, h, w)
+
+
+def psnr(a: Tensor, b: Tensor, peak: float = None) -> float:
+    """PSNR of a vs reference b; peak defaults to the reference's max-abs range."""
+    a, b = a.double(), b.double()
+    mse = (a - b).pow(2).mean().item()
+    if peak is None:
+        peak = (b.max() - b.min()).item()
+    return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)
