@@ -1,0 +1,40 @@
+// flexam_amd/csrc/api.hip -- version / error plumbing of libflexam_hip.so.
+// Convention (include/flexam_hip.h): every entry point returns 0 or a negative FLEXAM_E_* code
+// and leaves a human-readable message for flexam_last_error(); nothing allocates, frees,
+// synchronises or keeps a pointer past the call; all work is ordered on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+#include "flexam_hip.h"
+
+static thread_local char g_err[512] = "";
+
+int flexam_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int flexam_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return flexam_fail(FLEXAM_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return FLEXAM_OK;
+}
+
+extern "C" const char* flexam_last_error(void) { return g_err; }
+extern "C" int flexam_version(void) { return FLEXAM_HIP_VERSION; }
+extern "C" const char* flexam_arch(void) { return "gfx950"; }
+
+extern "C" int flexam_device_check(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return flexam_fail(FLEXAM_E_ARCH, "no HIP device");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return flexam_fail(FLEXAM_E_ARCH, "cannot query device %d", dev);
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return flexam_fail(FLEXAM_E_ARCH, "device %d is %s; libflexam_hip.so is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+  return FLEXAM_OK;
+}

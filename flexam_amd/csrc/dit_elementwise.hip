@@ -1,0 +1,470 @@
+// flexam_amd/csrc/dit_elementwise.hip -- the HBM-bound kernels of the FlexAM DiT block and the
+// sampler step.  All are one-pass, 16-byte vectorised, fp32 math with one rounding to bf16.
+//
+// Row kernels use one 128-thread workgroup (2 waves) per token row: a 3072-wide row is exactly
+// 3 x 128 vectors of 8 elements, kept in registers between the reduction and the write.
+#include "common.h"
+#include "flexam_hip.h"
+
+namespace {
+
+constexpr int RT = 128;   // threads per row
+
+__device__ __forceinline__ float row_sum(float v, float* red) { return block_sum<RT>(v, red); }
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm (no affine, or affine for norm3) * scale + shift  ->  bf16
+//   scale/shift rows come from a small fp32 table; row = row_index[m] or m / rows_per_batch.
+//   The table already holds (1 + scale) and (shift + density shift): see mod_table_kernel.
+// ------------------------------------------------------------------------------------------
+template <int VPT>
+__global__ __launch_bounds__(RT) void ln_modulate_kernel(const float* __restrict__ x, int64_t ldx, int C, float eps,
+                                                         const float* __restrict__ shift, const float* __restrict__ scale,
+                                                         int64_t tab_ld, const int32_t* __restrict__ row_index,
+                                                         int64_t rows_per_batch, const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, bf16* __restrict__ out, int64_t ldo) {
+  __shared__ float red[8];
+  const int64_t m = blockIdx.x;
+  const float* xr = x + m * ldx;
+  const int nvec = C >> 3;
+  f32x4 v[VPT][2];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vec = threadIdx.x + i * RT;
+    if (vec < nvec) {
+      v[i][0] = *(const f32x4*)(xr + vec * 8);
+      v[i][1] = *(const f32x4*)(xr + vec * 8 + 4);
+    } else {
+      v[i][0] = v[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += v[i][0][j] + v[i][1][j];
+  }
+  const float mean = row_sum(s, red) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vec = threadIdx.x + i * RT;
+    if (vec < nvec) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = v[i][0][j] - mean, b = v[i][1][j] - mean;
+        q += a * a + b * b;
+      }
+    }
+  }
+  const float rstd = __builtin_amdgcn_rsqf(row_sum(q, red) / (float)C + eps);
+  const float* sh = nullptr;
+  const float* sc = nullptr;
+  if (shift) {
+    const int64_t r = row_index ? (int64_t)row_index[m] : m / rows_per_batch;
+    sh = shift + r * tab_ld;
+    sc = scale + r * tab_ld;
+  }
+  bf16* orow = out + m * ldo;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vec = threadIdx.x + i * RT;
+    if (vec >= nvec) continue;
+    bf16x8 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = vec * 8 + h * 4;
+      f32x4 y = (v[i][h] - mean) * rstd;
+      if (ln_w) y = y * *(const f32x4*)(ln_w + c) + *(const f32x4*)(ln_b + c);
+      if (sh) y = y * *(const f32x4*)(sc + c) + *(const f32x4*)(sh + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[h * 4 + j] = f2bf(y[j]);
+    }
+    *(bf16x8*)(orow + vec * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// x[m, :] += y_bf16[m, :] * gate[row(m), :]        (fp32 residual stream, in place)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_residual_kernel(float* __restrict__ x, int64_t ldx, const bf16* __restrict__ y,
+                                                            int64_t ldy, const float* __restrict__ gate, int64_t gate_ld,
+                                                            const int32_t* __restrict__ row_index, int64_t rows_per_batch,
+                                                            int64_t M, int C) {
+  const int nvec = C >> 3;
+  const int64_t total = M * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / nvec;
+    const int c = (int)(i - m * nvec) * 8;
+    const bf16x8 yv = *(const bf16x8*)(y + m * ldy + c);
+    float* xp = x + m * ldx + c;
+    f32x4 a = *(const f32x4*)xp, b = *(const f32x4*)(xp + 4);
+    f32x4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0;
+    if (gate) {
+      const int64_t r = row_index ? (int64_t)row_index[m] : m / rows_per_batch;
+      g0 = *(const f32x4*)(gate + r * gate_ld + c);
+      g1 = *(const f32x4*)(gate + r * gate_ld + c + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] += bf2f(yv[j]) * g0[j];
+      b[j] += bf2f(yv[4 + j]) * g1[j];
+    }
+    *(f32x4*)xp = a;
+    *(f32x4*)(xp + 4) = b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// WanRMSNorm over the whole row (all heads) + 3-axis RoPE on interleaved pairs, bf16 in/out.
+//   blockIdx.y selects the tensor (0: q, 1: k).  cos/sin: [tokens_per_batch, head_dim/2] fp32,
+//   identity rows for pass-through tokens; null -> no rotation (cross-attention q).
+// ------------------------------------------------------------------------------------------
+struct RmsRopeArgs {
+  const bf16* in[2];
+  bf16* out[2];
+  const float* w[2];
+  int64_t ld_in[2], ld_out[2];
+};
+
+template <int VPT>
+__global__ __launch_bounds__(RT) void rmsnorm_rope_kernel(RmsRopeArgs a, int C, float eps, const float* __restrict__ cs,
+                                                          const float* __restrict__ sn, int64_t tokens_per_batch,
+                                                          int64_t token_offset, int head_dim) {
+  __shared__ float red[8];
+  const int which = blockIdx.y;
+  const int64_t m = blockIdx.x;
+  const bf16* xr = a.in[which] + m * a.ld_in[which];
+  const int nvec = C >> 3;
+  bf16x8 v[VPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vec = threadIdx.x + i * RT;
+    if (vec < nvec) {
+      v[i] = *(const bf16x8*)(xr + vec * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = bf2f(v[i][j]);
+        s += f * f;
+      }
+    }
+  }
+  const float r = __builtin_amdgcn_rsqf(row_sum(s, red) / (float)C + eps);
+  const float* w = a.w[which];
+  bf16* orow = a.out[which] + m * a.ld_out[which];
+  const int half = head_dim >> 1;
+  const int64_t tok = token_offset + (m % tokens_per_batch);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int vec = threadIdx.x + i * RT;
+    if (vec >= nvec) continue;
+    const int c = vec * 8;
+    const f32x4 w0 = *(const f32x4*)(w + c), w1 = *(const f32x4*)(w + c + 4);
+    float y[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      y[j] = bf2f(v[i][j]) * r * w0[j];
+      y[4 + j] = bf2f(v[i][4 + j]) * r * w1[j];
+    }
+    if (cs) {
+      const int pair0 = (c % head_dim) >> 1;          // 4 consecutive pairs
+      const f32x4 co = *(const f32x4*)(cs + tok * half + pair0);
+      const f32x4 si = *(const f32x4*)(sn + tok * half + pair0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float re = y[2 * j], im = y[2 * j + 1];
+        y[2 * j] = re * co[j] - im * si[j];
+        y[2 * j + 1] = re * si[j] + im * co[j];
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(y[j]);
+    *(bf16x8*)(orow + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Modulation table:  out[blk][r][j][:] = mod[blk][j][:] + e[r][j][:] + (scale_mask>>j & 1)
+//                                        + (dens_slot[j] >= 0 ? mdens[blk][slot][:] + dens[r / rows_per_batch][slot][:] : 0)
+// (FX.py:444-449, 452, 464, 500-506: `modulation + e0`, `1 + e[1]`, `+ density_emb[k]`)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mod_table_kernel(const float* __restrict__ mod, const float* __restrict__ e,
+                                                        const float* __restrict__ mdens, const float* __restrict__ dens,
+                                                        float* __restrict__ out, int nblk, int R, int nj, int nslot, int C,
+                                                        int rows_per_batch, int scale_mask, int dens_slots /*4 bits per j, 0xF = none*/) {
+  const int64_t total = (int64_t)nblk * R * nj * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int j = (int)(t % nj);
+    t /= nj;
+    const int r = (int)(t % R);
+    const int blk = (int)(t / R);
+    float v = mod[((int64_t)blk * nj + j) * C + c] + e[((int64_t)r * nj + j) * C + c];
+    if ((scale_mask >> j) & 1) v += 1.0f;
+    const int slot = (dens_slots >> (4 * j)) & 0xF;
+    if (slot != 0xF) v += mdens[((int64_t)blk * nslot + slot) * C + c] + dens[((int64_t)(r / rows_per_batch) * nslot + slot) * C + c];
+    out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Small-M fp32 linear: y[M,N] = act_in(x[M,K]) . W[N,K]^T + b   (M <= 8; W bf16 or fp32)
+// The time / density embedding MLPs run in fp32 in the reference (FX.py:928-955).
+// One wave per output column n; lanes stride K.
+// ------------------------------------------------------------------------------------------
+template <typename WT, int MAXM>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int64_t ldx, const WT* __restrict__ W,
+                                                           int64_t ldw, const float* __restrict__ b, float* __restrict__ y,
+                                                           int64_t ldy, int M, int N, int K, int silu_in) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float acc[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
+  const WT* wr = W + (int64_t)n * ldw;
+  for (int k = lane * 4; k < K; k += 256) {
+    float w[4];
+    if constexpr (sizeof(WT) == 2) {
+      const bf16x4 t = *(const bf16x4*)(wr + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = bf2f(t[j]);
+    } else {
+      const f32x4 t = *(const f32x4*)(wr + k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = t[j];
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        f32x4 xv = *(const f32x4*)(x + (int64_t)m * ldx + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float t = xv[j];
+          if (silu_in) t = t / (1.0f + __expf(-t));
+          acc[m] += t * w[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) {
+    const float t = wave_sum(acc[m]);
+    if (lane == 0 && m < M) y[(int64_t)m * ldy + n] = t + (b ? b[n] : 0.f);
+  }
+}
+
+// sinusoidal_embedding_1d (FX.py:31-41): out[r][:half] = cos(t_r * f_i), out[r][half:] = sin(...), fp64 math
+__global__ void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int R, int dim) {
+  const int half = dim >> 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * half) return;
+  const int r = i / half, k = i - r * half;
+  const double f = pow(10000.0, -(double)k / (double)half);
+  const double a = (double)t[r] * f;
+  out[(int64_t)r * dim + k] = (float)cos(a);
+  out[(int64_t)r * dim + half + k] = (float)sin(a);
+}
+
+// ------------------------------------------------------------------------------------------
+// patchify: src[C, F, H, W] (fp32 or bf16) -> dst[(f, h/2, w/2), col0 + c*4 + ph*2 + pw] bf16
+// = the im2col of a kernel=stride=(1,2,2) conv (FX.py:624-625, 676) in weight.flatten(1) order.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ src, int C, int F, int H, int W,
+                                                       bf16* __restrict__ dst, int64_t ldd, int col0, int64_t row0) {
+  const int hw2 = (H / 2) * (W / 2);
+  const int64_t total = (int64_t)F * hw2 * C * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (C * 4));
+    const int64_t tok = i / (C * 4);
+    const int c = col >> 2, ph = (col >> 1) & 1, pw = col & 1;
+    const int f = (int)(tok / hw2);
+    const int rem = (int)(tok - (int64_t)f * hw2);
+    const int h2 = rem / (W / 2), w2 = rem - h2 * (W / 2);
+    const T v = src[(((int64_t)c * F + f) * H + (h2 * 2 + ph)) * W + (w2 * 2 + pw)];
+    dst[(row0 + tok) * ldd + col0 + col] = f2bf((float)v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// unpatchify (FX.py:1126-1149): tokens [L, 4*C] (col = (ph*2+pw)*C + c) -> [C, F, H, W]
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ tok, int64_t ldt, int64_t tok0, int C,
+                                                         int F, int H, int W, TO* __restrict__ dst) {
+  const int64_t total = (int64_t)C * F * H * W;
+  const int hw2 = (H / 2) * (W / 2);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    int64_t t = i / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int f = (int)(t % F);
+    const int c = (int)(t / F);
+    const int64_t token = tok0 + (int64_t)f * hw2 + (h >> 1) * (W / 2) + (w >> 1);
+    const int col = (((h & 1) << 1) | (w & 1)) * C + c;
+    dst[i] = (TO)tok[token * ldt + col];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused sampler step (PIPE.py:926-934): unpatchify both CFG rows, v = u + g (c - u),
+// x += (sigma_next - sigma) v, x = (1 - mask) x_known + mask x.   Latents fp32 [C, F, H, W].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_euler_blend_kernel(const float* __restrict__ tok_u, const float* __restrict__ tok_c,
+                                                              int64_t ldt, int64_t tok0, float guidance, float dt,
+                                                              float* __restrict__ latents, const float* __restrict__ known,
+                                                              const float* __restrict__ mask, int C, int F, int H, int W) {
+  const int64_t total = (int64_t)C * F * H * W;
+  const int hw2 = (H / 2) * (W / 2);
+  const int64_t fhw = (int64_t)F * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    int64_t t = i / W;
+    const int h = (int)(t % H);
+    t /= H;
+    const int f = (int)(t % F);
+    const int c = (int)(t / F);
+    const int64_t token = tok0 + (int64_t)f * hw2 + (h >> 1) * (W / 2) + (w >> 1);
+    const int col = (((h & 1) << 1) | (w & 1)) * C + c;
+    float v = tok_u[token * ldt + col];
+    if (tok_c) v = v + guidance * (tok_c[token * ldt + col] - v);
+    float x = latents[i] + dt * v;
+    if (mask) {
+      const float mk = mask[i % fhw];
+      x = (1.0f - mk) * known[i] + mk * x;
+    }
+    latents[i] = x;
+  }
+}
+
+inline int grid_for(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+#define DISPATCH_VPT(C, ...)                                                          \
+  do {                                                                                \
+    const int vpt_ = ((C) / 8 + RT - 1) / RT;                                         \
+    switch (vpt_) {                                                                   \
+      case 1: { constexpr int VPT = 1; __VA_ARGS__; } break;                          \
+      case 2: { constexpr int VPT = 2; __VA_ARGS__; } break;                          \
+      case 3: { constexpr int VPT = 3; __VA_ARGS__; } break;                          \
+      case 4: { constexpr int VPT = 4; __VA_ARGS__; } break;                          \
+      case 5: case 6: case 7: case 8: { constexpr int VPT = 8; __VA_ARGS__; } break;  \
+      default: return flexam_fail(FLEXAM_E_SHAPE, "row width %d unsupported (max 8192)", (int)(C)); \
+    }                                                                                 \
+  } while (0)
+
+extern "C" int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C, float eps, const float* shift,
+                                  const float* scale, int64_t tab_ld, const int32_t* row_index, int64_t rows_per_batch,
+                                  const float* ln_w, const float* ln_b, void* out, int64_t ldo, void* stream) {
+  FX_REQUIRE(x && out && M > 0, FLEXAM_E_ARG, "ln_modulate: null pointer or empty");
+  FX_REQUIRE(C % 8 == 0 && ldx % 4 == 0 && ldo % 8 == 0, FLEXAM_E_SHAPE, "ln_modulate: C%%8, ldx%%4, ldo%%8 required (C=%d)", C);
+  FX_REQUIRE((shift == nullptr) == (scale == nullptr), FLEXAM_E_ARG, "ln_modulate: shift and scale go together");
+  FX_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), FLEXAM_E_ARG, "ln_modulate: ln_w and ln_b go together");
+  FX_REQUIRE(!shift || row_index || rows_per_batch > 0, FLEXAM_E_ARG, "ln_modulate: need row_index or rows_per_batch");
+  if (rows_per_batch <= 0) rows_per_batch = 1;
+  DISPATCH_VPT(C, hipLaunchKernelGGL(ln_modulate_kernel<VPT>, dim3((unsigned)M), dim3(RT), 0, (hipStream_t)stream, x, ldx, C, eps,
+                                     shift, scale, tab_ld, row_index, rows_per_batch, ln_w, ln_b, (bf16*)out, ldo));
+  return flexam_check_launch("flexam_ln_modulate");
+}
+
+extern "C" int flexam_gate_residual(float* x, int64_t ldx, const void* y, int64_t ldy, const float* gate, int64_t gate_ld,
+                                    const int32_t* row_index, int64_t rows_per_batch, int64_t M, int C, void* stream) {
+  FX_REQUIRE(x && y && M > 0, FLEXAM_E_ARG, "gate_residual: null pointer or empty");
+  FX_REQUIRE(C % 8 == 0 && ldx % 4 == 0 && ldy % 8 == 0, FLEXAM_E_SHAPE, "gate_residual: C%%8, ldx%%4, ldy%%8 required");
+  FX_REQUIRE(!gate || row_index || rows_per_batch > 0, FLEXAM_E_ARG, "gate_residual: need row_index or rows_per_batch");
+  if (rows_per_batch <= 0) rows_per_batch = 1;
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(grid_for(M * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (const bf16*)y, ldy, gate, gate_ld, row_index, rows_per_batch, M, C);
+  return flexam_check_launch("flexam_gate_residual");
+}
+
+extern "C" int flexam_rmsnorm_rope(const void* q_in, int64_t ldq_in, void* q_out, int64_t ldq_out, const float* wq,
+                                   const void* k_in, int64_t ldk_in, void* k_out, int64_t ldk_out, const float* wk,
+                                   int64_t M, int C, float eps, const float* rope_cos, const float* rope_sin,
+                                   int64_t tokens_per_batch, int64_t token_offset, int head_dim, void* stream) {
+  FX_REQUIRE(q_in && q_out && wq && M > 0, FLEXAM_E_ARG, "rmsnorm_rope: null pointer or empty");
+  FX_REQUIRE(C % 8 == 0 && ldq_in % 8 == 0 && ldq_out % 8 == 0, FLEXAM_E_SHAPE, "rmsnorm_rope: widths must be multiples of 8");
+  FX_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), FLEXAM_E_ARG, "rmsnorm_rope: cos and sin go together");
+  FX_REQUIRE(!rope_cos || (head_dim % 8 == 0 && C % head_dim == 0 && tokens_per_batch > 0), FLEXAM_E_SHAPE,
+             "rmsnorm_rope: head_dim %d must divide C %d and be a multiple of 8", head_dim, C);
+  if (k_in) FX_REQUIRE(k_out && wk && ldk_in % 8 == 0 && ldk_out % 8 == 0, FLEXAM_E_ARG, "rmsnorm_rope: bad k arguments");
+  RmsRopeArgs a;
+  a.in[0] = (const bf16*)q_in; a.out[0] = (bf16*)q_out; a.w[0] = wq; a.ld_in[0] = ldq_in; a.ld_out[0] = ldq_out;
+  a.in[1] = (const bf16*)k_in; a.out[1] = (bf16*)k_out; a.w[1] = wk; a.ld_in[1] = ldk_in; a.ld_out[1] = ldk_out;
+  if (tokens_per_batch <= 0) tokens_per_batch = M;
+  if (head_dim <= 0) head_dim = 8;
+  DISPATCH_VPT(C, hipLaunchKernelGGL(rmsnorm_rope_kernel<VPT>, dim3((unsigned)M, k_in ? 2 : 1), dim3(RT), 0, (hipStream_t)stream, a,
+                                     C, eps, rope_cos, rope_sin, tokens_per_batch, token_offset, head_dim));
+  return flexam_check_launch("flexam_rmsnorm_rope");
+}
+
+extern "C" int flexam_mod_table(const float* mod, const float* e, const float* mdens, const float* dens, float* out, int nblk,
+                                int R, int nj, int nslot, int C, int rows_per_batch, int scale_mask, int dens_slots, void* stream) {
+  FX_REQUIRE(mod && e && out, FLEXAM_E_ARG, "mod_table: null pointer");
+  FX_REQUIRE(nblk > 0 && R > 0 && nj > 0 && nj <= 8 && C > 0 && rows_per_batch > 0, FLEXAM_E_SHAPE, "mod_table: bad sizes");
+  FX_REQUIRE(dens_slots == -1 || (mdens && dens && nslot > 0), FLEXAM_E_ARG, "mod_table: density terms need mdens/dens");
+  hipLaunchKernelGGL(mod_table_kernel, dim3(grid_for((int64_t)nblk * R * nj * C, 256)), dim3(256), 0, (hipStream_t)stream, mod, e,
+                     mdens, dens, out, nblk, R, nj, nslot, C, rows_per_batch, scale_mask, dens_slots);
+  return flexam_check_launch("flexam_mod_table");
+}
+
+extern "C" int flexam_small_linear_f32(const float* x, int64_t ldx, const void* W, int w_is_bf16, int64_t ldw, const float* b,
+                                       float* y, int64_t ldy, int M, int N, int K, int silu_in, void* stream) {
+  FX_REQUIRE(x && W && y, FLEXAM_E_ARG, "small_linear: null pointer");
+  FX_REQUIRE(M >= 1 && M <= 8, FLEXAM_E_SHAPE, "small_linear: M=%d must be in 1..8", M);
+  FX_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, FLEXAM_E_SHAPE, "small_linear: K, ldx, ldw must be multiples of 4");
+  dim3 grid((N + 3) / 4), block(256);
+  if (w_is_bf16)
+    hipLaunchKernelGGL((small_linear_kernel<bf16, 8>), grid, block, 0, (hipStream_t)stream, x, ldx, (const bf16*)W, ldw, b, y, ldy, M, N, K, silu_in);
+  else
+    hipLaunchKernelGGL((small_linear_kernel<float, 8>), grid, block, 0, (hipStream_t)stream, x, ldx, (const float*)W, ldw, b, y, ldy, M, N, K, silu_in);
+  return flexam_check_launch("flexam_small_linear_f32");
+}
+
+extern "C" int flexam_sinusoid_embed(const float* t, float* out, int R, int dim, void* stream) {
+  FX_REQUIRE(t && out && R > 0 && dim > 0 && dim % 2 == 0, FLEXAM_E_ARG, "sinusoid_embed: bad arguments");
+  const int total = R * (dim / 2);
+  hipLaunchKernelGGL(sinusoid_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out, R, dim);
+  return flexam_check_launch("flexam_sinusoid_embed");
+}
+
+extern "C" int flexam_patchify(const void* src, int src_is_bf16, int C, int F, int H, int W, void* dst, int64_t ldd, int col0,
+                               int64_t row0, void* stream) {
+  FX_REQUIRE(src && dst, FLEXAM_E_ARG, "patchify: null pointer");
+  FX_REQUIRE(C > 0 && F > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "patchify: H, W must be even");
+  const int64_t total = (int64_t)F * (H / 2) * (W / 2) * C * 4;
+  if (src_is_bf16)
+    hipLaunchKernelGGL(patchify_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, C, F, H, W, (bf16*)dst, ldd, col0, row0);
+  else
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, C, F, H, W, (bf16*)dst, ldd, col0, row0);
+  return flexam_check_launch("flexam_patchify");
+}
+
+extern "C" int flexam_unpatchify(const float* tok, int64_t ldt, int64_t tok0, int C, int F, int H, int W, void* dst,
+                                 int dst_is_bf16, void* stream) {
+  FX_REQUIRE(tok && dst, FLEXAM_E_ARG, "unpatchify: null pointer");
+  FX_REQUIRE(H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "unpatchify: H, W must be even");
+  const int64_t total = (int64_t)C * F * H * W;
+  if (dst_is_bf16)
+    hipLaunchKernelGGL(unpatchify_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, tok, ldt, tok0, C, F, H, W, (bf16*)dst);
+  else
+    hipLaunchKernelGGL(unpatchify_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, tok, ldt, tok0, C, F, H, W, (float*)dst);
+  return flexam_check_launch("flexam_unpatchify");
+}
+
+extern "C" int flexam_cfg_euler_blend(const float* tok_uncond, const float* tok_cond, int64_t ldt, int64_t tok0, float guidance,
+                                      float dt, float* latents, const float* known, const float* mask, int C, int F, int H, int W,
+                                      void* stream) {
+  FX_REQUIRE(tok_uncond && latents, FLEXAM_E_ARG, "cfg_euler_blend: null pointer");
+  FX_REQUIRE((mask == nullptr) == (known == nullptr), FLEXAM_E_ARG, "cfg_euler_blend: mask and known go together");
+  FX_REQUIRE(H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "cfg_euler_blend: H, W must be even");
+  hipLaunchKernelGGL(cfg_euler_blend_kernel, dim3(grid_for((int64_t)C * F * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     tok_uncond, tok_cond, ldt, tok0, guidance, dt, latents, known, mask, C, F, H, W);
+  return flexam_check_launch("flexam_cfg_euler_blend");
+}

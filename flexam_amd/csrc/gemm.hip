@@ -1,0 +1,247 @@
+// flexam_amd/csrc/gemm.hip -- bf16 MFMA GEMM for the DiT projections / FFN and (through the
+// per-K-block A offset table) the VAE's implicit-GEMM causal convolutions.
+//
+//   C[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] )        A, W bf16 row-major (K contiguous)
+//
+// Replaces the cuBLAS/hipBLASLt calls behind nn.Linear in the reference
+// (FlexAM/models/wan_transformer3d_FlexAM.py:242-244,261,363-365,370,415-416) and cuDNN
+// Conv3d/Conv2d (FlexAM/models/wan_vae3_8.py:39-47,94,99).
+//
+// MI355X mapping (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
+//  * 256x256x64 tile per 512-thread workgroup (8 waves = 2(M) x 4(N), 128x64 outputs per wave),
+//    one workgroup per CU, accumulators in 128 VGPRs/AGPRs per lane.
+//  * both operands staged HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round trip), two
+//    LDS buffers (2 x 64 KiB); tile rows are 128 B so the 16-B chunk index is XOR-swizzled with
+//    (row>>1)&7 on the *source* address (the LDS image must stay lane-linear for LDS-DMA) and
+//    again on the ds_read_b128 fragment reads: conflict-free per tools/lds_sim.py.
+//  * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment in the A slot) so each lane
+//    ends up with 4 consecutive N columns of one output row -> 8-byte bf16 / 16-byte f32 stores.
+//  * workgroup -> tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
+//    chunks of the tile list, walked in groups of 8 tile-rows so concurrently resident tiles
+//    share A row-panels and W column-panels in L2.
+#include "common.h"
+#include "flexam_hip.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int NT = 512;
+constexpr int TILE_BYTES = BM * BK * 2;   // 32 KiB per operand tile
+
+struct GemmParams {
+  const bf16* A;
+  const bf16* W;
+  void* C;
+  const float* bias;
+  int64_t lda, ldw, ldc;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  // fused residual epilogue (EPI_GATE_RESIDUAL): X[m, n] += bf16round(acc + bias) * gate[row(m), n]
+  float* X;
+  int64_t ldx;
+  const float* gate;       // [rows, gate_ld] or null (gate = 1)
+  int64_t gate_ld;
+  const int32_t* gate_row; // [M] row index per output row, or null
+  int64_t rows_per_batch;  // used when gate_row is null: row = m / rows_per_batch
+};
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
+
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, const int64_t (&row_off)[4], int64_t kcol,
+                                           char* lds_tile, int wave) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16* src = base + row_off[i] + kcol;
+    char* dst = lds_tile + i * 8192 + wave * 1024;   // wave-uniform; hardware adds lane*16
+    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
+  }
+}
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
+  // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- XCD-aware, grouped tile order
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = bid - group * per_group;
+  const int tm = first_m + in_group % gsz;
+  const int tn = in_group / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging addresses: thread -> (row = i*64 + tid/8, LDS slot = tid%8), source chunk = slot ^ swz(row)
+  int64_t a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 64 + (tid >> 3);
+    const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+    const int gm = min(m0 + row, p.M - 1);
+    const int gn = min(n0 + row, p.N - 1);
+    a_off[i] = (int64_t)gm * p.lda + chunk * 8;
+    w_off[i] = (int64_t)gn * p.ldw + chunk * 8;
+  }
+
+  // ---- fragment read offsets (bytes inside a tile): row = base16 + (lane&15), chunk = (lane>>4) + 4*ks
+  const int sw = (lane & 15) >> 1;
+  const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
+  const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
+
+  stage_tile(p.A, a_off, kcol_a(0), smem, wave);
+  stage_tile(p.W, w_off, 0, smem + TILE_BYTES, wave);
+  int64_t kcol_next = kcol_a(1);          // offset of tile kb+1, fetched one iteration ahead
+  __syncthreads();
+
+  for (int kb = 0; kb < nk; ++kb) {
+    char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
+    if (kb + 1 < nk) {
+      char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
+      stage_tile(p.A, a_off, kcol_next, nxt, wave);
+      stage_tile(p.W, w_off, (int64_t)(kb + 1) * BK, nxt + TILE_BYTES, wave);
+    }
+    kcol_next = kcol_a(kb + 2);
+    const char* at = cur + wm * (128 * 128);
+    const char* wt = cur + TILE_BYTES + wn * (64 * 128);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int fo = ks ? frag_off1 : frag_off0;
+      bf16x8 wf[4], af[8];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(wt + nt * 2048 + fo);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) af[mt] = *(const bf16x8*)(at + mt * 2048 + fo);
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
+  const int mrow = m0 + wm * 128 + (lane & 15);
+  const int ncol = n0 + wn * 64 + (lane >> 4) * 4;
+  f32x4 bias[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int n = ncol + nt * 16;
+    bias[nt] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = mrow + mt * 16;
+    if (m >= p.M) continue;
+    const float* grow = nullptr;
+    if constexpr (EPI == EPI_GATE_RESIDUAL) {
+      if (p.gate) {
+        const int64_t r = p.gate_row ? (int64_t)p.gate_row[m] : (int64_t)m / p.rows_per_batch;
+        grow = p.gate + r * p.gate_ld;
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = ncol + nt * 16;
+      if (n >= p.N) continue;
+      f32x4 v = acc[mt][nt] + bias[nt];
+      if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
+      }
+      if constexpr (EPI == EPI_GATE_RESIDUAL) {
+        // y is rounded to bf16 first, like the reference's bf16 Linear output (FX.py:456,461,468)
+        float* xp = p.X + (int64_t)m * p.ldx + n;
+        f32x4 x = *(const f32x4*)xp;
+        f32x4 g = grow ? *(const f32x4*)(grow + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(v[j])) * g[j];
+        *(f32x4*)xp = x;
+      } else if constexpr (sizeof(OutT) == 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+        *(bf16x4*)((bf16*)p.C + (int64_t)m * p.ldc + n) = o;
+      } else {
+        *(f32x4*)((float*)p.C + (int64_t)m * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
+template <int EPI, typename OutT>
+int launch(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
+  auto kern = gemm_bf16_kernel<EPI, OutT>;
+  static bool attr_set = false;
+  const int smem = 4 * TILE_BYTES;   // 128 KiB
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NT), smem, s, p, a_koff);
+  return flexam_check_launch("flexam_gemm_bf16");
+}
+
+}  // namespace
+
+extern "C" int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
+                                int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, int out_f32,
+                                const int64_t* a_koff, void* stream) {
+  FX_REQUIRE(A && W && C, FLEXAM_E_ARG, "gemm: null pointer");
+  FX_REQUIRE(M > 0 && N > 0 && K > 0, FLEXAM_E_SHAPE, "gemm: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  FX_REQUIRE(K % BK == 0, FLEXAM_E_SHAPE, "gemm: K=%ld must be a multiple of %d (pad on the host)", (long)K, BK);
+  FX_REQUIRE(N % 4 == 0 && ldc % 4 == 0, FLEXAM_E_SHAPE, "gemm: N=%ld and ldc=%ld must be multiples of 4", (long)N, (long)ldc);
+  FX_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, FLEXAM_E_SHAPE, "gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
+  FX_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0, FLEXAM_E_ARG, "gemm: pointers must be 16-byte aligned");
+  FX_REQUIRE(epilogue == EPI_NONE || epilogue == EPI_GELU, FLEXAM_E_ARG, "gemm: unknown epilogue %d", epilogue);
+  GemmParams p{};
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_f32) {
+    FX_REQUIRE(epilogue == EPI_NONE, FLEXAM_E_ARG, "gemm: f32 output supports no activation epilogue");
+    return launch<EPI_NONE, float>(p, a_koff, s);
+  }
+  return epilogue == EPI_GELU ? launch<EPI_GELU, bf16>(p, a_koff, s) : launch<EPI_NONE, bf16>(p, a_koff, s);
+}
+
+extern "C" int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                              float* X, int64_t ldx, const float* gate, int64_t gate_ld,
+                                              const int32_t* gate_row, int64_t rows_per_batch, int64_t M, int64_t N,
+                                              int64_t K, void* stream) {
+  FX_REQUIRE(A && W && X, FLEXAM_E_ARG, "gemm_gate_residual: null pointer");
+  FX_REQUIRE(M > 0 && N > 0 && K > 0, FLEXAM_E_SHAPE, "gemm_gate_residual: empty problem");
+  FX_REQUIRE(K % BK == 0 && N % 4 == 0 && ldx % 4 == 0, FLEXAM_E_SHAPE, "gemm_gate_residual: K%%64, N%%4, ldx%%4 required");
+  FX_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, FLEXAM_E_SHAPE, "gemm_gate_residual: lda/ldw must be multiples of 8");
+  FX_REQUIRE(!gate || gate_row || rows_per_batch > 0, FLEXAM_E_ARG, "gemm_gate_residual: gate needs gate_row or rows_per_batch");
+  GemmParams p{};
+  p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = nullptr; p.bias = bias;
+  p.lda = lda; p.ldw = ldw; p.ldc = 0; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+  p.X = X; p.ldx = ldx; p.gate = gate; p.gate_ld = gate_ld; p.gate_row = gate_row;
+  p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
+  return launch<EPI_GATE_RESIDUAL, bf16>(p, nullptr, (hipStream_t)stream);
+}

@@ -1,0 +1,366 @@
+"""HIP execution engine of the FlexAM DiT (Wan2.2-Fun-5B-FLEXAM) on one MI355X, optionally one
+shard of a sequence-parallel group.
+
+What the reference does per denoise step in wan_transformer3d_FlexAM.py:817-1123 is split here by
+how often it changes:
+
+  per clip   (`set_conditioning`)  cnn-block over the control/depth/cos latents (:869-881), the
+             100 step-invariant input channels of the patch embedding (:883-885), ref_conv tokens
+             (:895-899), text embedding (:958-964) and every block's cross-attention K/V
+             (:364-365), density embedding (:950-955), RoPE rows (:137-164)
+  per step   (`run`)  48-channel patchify + patch GEMM, the time-embedding MLP on the DISTINCT
+             timesteps only (two rows in the sampler: frame-0 tokens have t = 0, PIPE.py:891-898),
+             one AdaLN table for all blocks, 30 blocks, head
+
+Data layout in HBM (per rank): residual stream x fp32 [B*Lc, C] (token-major, rows of 12 KiB);
+GEMM operands bf16 row-major with K contiguous; q|k|v of a block in one [B*Lc, 3C] buffer (heads
+packed along the row, so attention addresses head h at column h*128); AdaLN rows are looked up per
+token through an int32 row index instead of the reference's materialised [B, L, 6, C] fp32 tensor.
+All arithmetic runs in libflexam_hip.so (flexam_amd/hip.py); torch only allocates and slices.
+"""
+import math
+from typing import List, Optional
+
+import torch
+
+from . import hip
+from .rope import rope_angle_table, rope_tables
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class _ConvCL:
+    """A (1,kh,kw) convolution as an implicit GEMM over a padded channels-last image."""
+
+    def __init__(self, weight: torch.Tensor, bias: torch.Tensor, cp_in: int, device):
+        co, ci = weight.shape[0], weight.shape[1]
+        kh, kw = weight.shape[-2], weight.shape[-1]
+        w = weight.detach().to(device, F32).reshape(co, ci, kh, kw).permute(0, 2, 3, 1)        # [co, kh, kw, ci]
+        wp = torch.zeros(co, kh, kw, cp_in, device=device, dtype=F32)
+        wp[..., :ci] = w
+        self.weight = wp.reshape(co, kh * kw * cp_in).to(BF16).contiguous()
+        self.bias = bias.detach().to(device, F32).contiguous()
+        self.kh, self.kw, self.cp_in, self.cout = kh, kw, cp_in, co
+        self._koff = {}
+
+    def koff(self, wp_img: int, device) -> torch.Tensor:
+        if wp_img not in self._koff:
+            offs = []
+            for dh in range(self.kh):
+                for dw in range(self.kw):
+                    base = ((dh - self.kh // 2) * wp_img + (dw - self.kw // 2)) * self.cp_in
+                    offs += [base + cb * 64 for cb in range(self.cp_in // 64)]
+            self._koff[wp_img] = torch.tensor(offs, dtype=I64, device=device)
+        return self._koff[wp_img]
+
+
+class _Image:
+    """Zero-padded channels-last bf16 image [F, H+2, W+2, Cp] with guard rows on both sides so that
+    every 3x3 tap offset of every padded position stays inside the allocation."""
+
+    def __init__(self, f, h, w, cp, device):
+        self.f, self.h, self.w, self.cp = f, h, w, cp
+        self.rows = f * (h + 2) * (w + 2)
+        guard = (w + 2) + 1
+        self.buf = torch.zeros((self.rows + 2 * guard) * cp, device=device, dtype=BF16)
+        self.img = self.buf[guard * cp:(guard + self.rows) * cp].view(f, h + 2, w + 2, cp)
+        self.mat = self.img.view(self.rows, cp)
+
+
+class DiTEngine:
+    def __init__(self, model):
+        self.model = model
+        c = model.config
+        self.dim, self.ffn, self.nh, self.nl = c["dim"], c["ffn_dim"], c["num_heads"], c["num_layers"]
+        self.hd = self.dim // self.nh
+        self.eps = c["eps"]
+        self.patch = tuple(c["patch_size"])
+        self.out_dim, self.in_dim = c["out_dim"], c["in_dim"]
+        self.text_len, self.freq_dim = c["text_len"], c["freq_dim"]
+        if self.hd != 128:
+            raise RuntimeError(f"flexam_amd: head_dim {self.hd} unsupported by the HIP attention kernel (128 only)")
+        if self.patch != (1, 2, 2):
+            raise RuntimeError("flexam_amd: only patch_size (1,2,2) is implemented")
+        self.device = model.patch_embedding.weight.device
+        if self.device.type != "cuda":
+            raise RuntimeError("flexam_amd: the DiT runs only on a GPU through libflexam_hip.so "
+                               "(no CPU or eager fallback); move the model to cuda first")
+        hip.device_check()
+        self.sp_group = None
+        self.sp_rank, self.sp_size = 0, 1
+        self._ws = {}
+        self._angles = None
+        self.cond = None
+        self._pack()
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self):
+        m, dev, d = self.model, self.device, self.dim
+        bf = lambda t: t.detach().to(dev, BF16).contiguous()
+        f32 = lambda t: t.detach().to(dev, F32).contiguous()
+        small = lambda t: t.detach().to(dev).contiguous() if t.dtype in (BF16, F32) else f32(t)
+
+        def pad_k(w2d):
+            n, k = w2d.shape
+            out = torch.zeros(n, _round_up(k, 64), device=dev, dtype=BF16)
+            out[:, :k] = w2d.detach().to(dev, BF16)
+            return out
+        self.pe_w, self.pe_b = pad_k(m.patch_embedding.weight.flatten(1)), f32(m.patch_embedding.bias)
+        self.ref_w = self.ref_b = None
+        if m.ref_conv is not None:
+            self.ref_w, self.ref_b = pad_k(m.ref_conv.weight.flatten(1)), f32(m.ref_conv.bias)
+        self.head_w, self.head_b = bf(m.head.head.weight), f32(m.head.head.bias)
+        self.txt = [(pad_k(m.text_embedding[0].weight), f32(m.text_embedding[0].bias)),
+                    (bf(m.text_embedding[2].weight), f32(m.text_embedding[2].bias))]
+        self.time = [(small(l.weight), f32(l.bias)) for l in (m.time_embedding[0], m.time_embedding[2], m.time_projection[1])]
+        self.dens = [(small(l.weight), f32(l.bias)) for l in (m.density_embedding[0], m.density_embedding[2], m.density_projection[1])]
+        self.blocks = []
+        for blk in m.blocks:
+            sa, ca = blk.self_attn, blk.cross_attn
+            self.blocks.append(dict(
+                wqkv=torch.cat([bf(sa.q.weight), bf(sa.k.weight), bf(sa.v.weight)]),
+                bqkv=torch.cat([f32(sa.q.bias), f32(sa.k.bias), f32(sa.v.bias)]),
+                wo=bf(sa.o.weight), bo=f32(sa.o.bias), nq=f32(sa.norm_q.weight), nk=f32(sa.norm_k.weight),
+                cwq=bf(ca.q.weight), cbq=f32(ca.q.bias),
+                cwkv=torch.cat([bf(ca.k.weight), bf(ca.v.weight)]), cbkv=torch.cat([f32(ca.k.bias), f32(ca.v.bias)]),
+                cwo=bf(ca.o.weight), cbo=f32(ca.o.bias), cnq=f32(ca.norm_q.weight), cnk=f32(ca.norm_k.weight),
+                n3w=f32(blk.norm3.weight), n3b=f32(blk.norm3.bias),
+                w1=bf(blk.ffn[0].weight), b1=f32(blk.ffn[0].bias), w2=bf(blk.ffn[2].weight), b2=f32(blk.ffn[2].bias)))
+        self.mod = torch.stack([f32(b.modulation)[0] for b in m.blocks])                       # [nl, 6, d]
+        self.mdens = torch.stack([f32(b.modulation_density)[0] for b in m.blocks])            # [nl, 2, d]
+        self.hmod, self.hmdens = f32(m.head.modulation), f32(m.head.modulation_density)       # [1,2,d], [1,1,d]
+        self.cnn = None
+        if m.cnn_conv1 is not None:
+            cin = [_round_up(m.cnn_conv1[0].weight.shape[1], 64), 192, 192, 128]
+            self.cnn = dict(
+                convs=[_ConvCL(getattr(m, f"cnn_conv{i}")[0].weight, getattr(m, f"cnn_conv{i}")[0].bias, cin[i - 1], dev) for i in range(1, 5)],
+                gn=[(f32(getattr(m, f"cnn_conv{i}")[1].weight), f32(getattr(m, f"cnn_conv{i}")[1].bias)) for i in range(1, 5)],
+                conv5=_ConvCL(m.cnn_conv5.weight, m.cnn_conv5.bias, 128, dev), groups=[24, 24, 12, 12], cp=cin)
+
+    def set_sequence_parallel(self, group, rank: int, size: int):
+        self.sp_group, self.sp_rank, self.sp_size = group, rank, size
+        self._ws.clear()
+
+    # ------------------------------------------------------------------ per-clip state
+    def _cnn_block(self, control: torch.Tensor, additional: torch.Tensor) -> torch.Tensor:
+        """control [Cc,F,H,W], additional [Ca,F,H,W] -> cnn output [Co,F,H,W] fp32 (FX.py:869-880)."""
+        dev = self.device
+        _, f, h, w = control.shape
+        cn = self.cnn
+        rows = f * (h + 2) * (w + 2)
+        img = _Image(f, h, w, cn["cp"][0], dev)
+        hip.pack_cl(control.contiguous(), img.img, 0)
+        hip.pack_cl(additional.contiguous(), img.img, control.shape[0])
+        prev = None
+        for i, conv in enumerate(cn["convs"]):
+            y = hip.gemm(img.mat, conv.weight, conv.bias, a_koff=conv.koff(w + 2, dev), m=rows, k=conv.weight.shape[1], out_dtype=F32)
+            cp_out = cn["cp"][i + 1] if i + 1 < 4 else 128
+            nxt = _Image(f, h, w, cp_out, dev)
+            gamma, beta = cn["gn"][i]
+            residual = img.img if i in (1, 3) else None                   # x2 = conv2(x1) + x1, x4 = conv4(x3) + x3
+            hip.groupnorm_silu_cl(y, conv.cout, f, h, w, cn["groups"][i], gamma, beta, nxt.img, residual=residual)
+            prev, img = img, nxt
+        c5 = cn["conv5"]
+        y = hip.gemm(img.mat, c5.weight, c5.bias, a_koff=c5.koff(w + 2, dev), m=rows, k=c5.weight.shape[1], out_dtype=F32)
+        return hip.unpack_cl(y, c5.cout, f, h, w)
+
+    def set_conditioning(self, context: List[torch.Tensor], y: Optional[torch.Tensor], full_ref: Optional[torch.Tensor],
+                         additional_control: Optional[torch.Tensor], density: Optional[torch.Tensor], latent_shape,
+                         shared: bool = False):
+        """Computes everything that does not depend on the noisy latent or the timestep.
+        context: list of B tensors [len_i, text_dim]; y [By, 100, F, H, W]; full_ref [By, 48, H, W];
+        additional_control [By, 240, F, H, W]; density [B].  shared=True: conditioning tensors have
+        batch 1 and are shared by all B rows (the sampler's CFG pair differs only in `context`)."""
+        dev, d = self.device, self.dim
+        B = len(context)
+        cx, f, h, w = latent_shape
+        lvid = f * (h // 2) * (w // 2)
+        ref_len = (h // 2) * (w // 2) if (full_ref is not None and self.ref_w is not None) else 0
+        L = lvid + ref_len
+        nb = 1 if shared else B
+        kpe = self.pe_w.shape[1]
+        patch_a = torch.zeros(nb, lvid, kpe, device=dev, dtype=BF16)
+        ref_tok = torch.empty(nb, ref_len, d, device=dev, dtype=F32) if ref_len else None
+        if y is not None:
+            for b in range(nb):
+                yb = y[b].to(dev)
+                if self.cnn is not None and additional_control is not None:
+                    cnn_out = self._cnn_block(yb[:cx].float(), additional_control[b].to(dev).float())
+                    hip.patchify(cnn_out, patch_a[b], col0=cx * 4)
+                    rest = yb[cx:].float().contiguous()
+                    hip.patchify(rest, patch_a[b], col0=(cx + cnn_out.shape[0]) * 4)
+                else:
+                    hip.patchify(yb.float().contiguous(), patch_a[b], col0=cx * 4)
+        if ref_len:
+            kr = self.ref_w.shape[1]
+            for b in range(nb):
+                ra = torch.zeros(ref_len, kr, device=dev, dtype=BF16)
+                hip.patchify(full_ref[b].to(dev).float().unsqueeze(1).contiguous(), ra)
+                # the reference's conv output is bf16 (autocast); keep that rounding for the tokens
+                hip.gemm(ra, self.ref_w, self.ref_b, out=ref_tok[b], out_dtype=F32)
+        # text -> context embedding -> per-block cross K (normalised) and V
+        tdim = self.txt[0][0].shape[1]
+        ctx_in = torch.zeros(B * self.text_len, tdim, device=dev, dtype=BF16)
+        for b, u in enumerate(context):
+            n = min(u.shape[0], self.text_len)
+            ctx_in[b * self.text_len:b * self.text_len + n, :u.shape[1]] = u[:n].to(dev, BF16)
+        hmid = hip.gemm(ctx_in, self.txt[0][0], self.txt[0][1], epilogue=hip.EPI_GELU_TANH)
+        ctx = hip.gemm(hmid, self.txt[1][0], self.txt[1][1])
+        cross_kv = []
+        for p in self.blocks:
+            kv = hip.gemm(ctx, p["cwkv"], p["cbkv"])
+            hip.rmsnorm_rope(kv[:, :d], p["cnk"], eps=self.eps)
+            cross_kv.append(kv.view(B, self.text_len, 2 * d))
+        # density embedding
+        dens_emb = dens0 = None
+        if density is not None:
+            s = hip.sinusoid_embed(density.to(dev, F32).reshape(-1), self.freq_dim)
+            e1 = hip.small_linear(s, *self.dens[0])
+            dens_emb = hip.small_linear(e1, *self.dens[1], silu_in=True)
+            dens0 = hip.small_linear(dens_emb, *self.dens[2], silu_in=True).view(B, 2, d)
+        grid = (f + (1 if ref_len else 0), h // 2, w // 2)
+        if self._angles is None:
+            self._angles = self.model._rope_angles()
+        cos, sin = rope_tables(grid, L, self.hd, self._angles)
+        self.cond = dict(B=B, nb=nb, L=L, lvid=lvid, ref_len=ref_len, latent_shape=(cx, f, h, w), patch_a=patch_a, ref_tok=ref_tok,
+                         cross_kv=cross_kv, dens_emb=dens_emb, dens0=dens0, cos=cos.to(dev), sin=sin.to(dev))
+        return self.cond
+
+    # ------------------------------------------------------------------ workspace
+    def _workspace(self, B, lc):
+        key = (B, lc)
+        if key not in self._ws:
+            dev, d, m = self.device, self.dim, B * lc
+            self._ws = {key: dict(
+                x=torch.empty(m, d, device=dev, dtype=F32), h=torch.empty(m, d, device=dev, dtype=BF16),
+                qkv=torch.empty(m, 3 * d, device=dev, dtype=BF16), ao=torch.empty(m, d, device=dev, dtype=BF16),
+                ffn=torch.empty(m, self.ffn, device=dev, dtype=BF16),
+                head=torch.empty(m, self.head_w.shape[0], device=dev, dtype=F32))}
+        return self._ws[key]
+
+    # ------------------------------------------------------------------ per-step
+    def embed_time(self, t_rows: torch.Tensor):
+        """t_rows [R] fp32 distinct timesteps -> e [R, d], e0 [R, 6, d] (fp32, FX.py:928-944)."""
+        R, d = t_rows.numel(), self.dim
+        s = hip.sinusoid_embed(t_rows.to(self.device, F32), self.freq_dim)
+        e = torch.empty(R, d, device=self.device, dtype=F32)
+        e0 = torch.empty(R, 6 * d, device=self.device, dtype=F32)
+        for i in range(0, R, 8):
+            sl = slice(i, min(i + 8, R))
+            e1 = hip.small_linear(s[sl], *self.time[0])
+            hip.small_linear(e1, *self.time[1], silu_in=True, out=e[sl])
+            hip.small_linear(e[sl], *self.time[2], silu_in=True, out=e0[sl])
+        return e, e0.view(R, 6, d)
+
+    def run(self, x: torch.Tensor, t_rows: torch.Tensor, row_index: Optional[torch.Tensor], rows_per_batch: int) -> torch.Tensor:
+        """x [Bx, 48, F, H, W] (Bx = B, or 1 when all rows share the latent); t_rows [R] distinct
+        timesteps with R = B * rows_per_batch table rows (rows of batch b are b*rows_per_batch ..);
+        row_index int32 [B * L] global table row per token, or None (then token (b, l) uses row b).
+        Returns the head output tokens fp32 [B, Lc, 4*out_dim] of this rank's token chunk."""
+        cd, dev, d = self.cond, self.device, self.dim
+        B, L, lvid, ref_len = cd["B"], cd["L"], cd["lvid"], cd["ref_len"]
+        cx, f, h, w = cd["latent_shape"]
+        sp, rank = self.sp_size, self.sp_rank
+        if L % sp:
+            raise RuntimeError(f"sequence length {L} is not divisible by the sequence-parallel size {sp}")
+        lc = L // sp
+        tok0 = rank * lc
+        ws = self._workspace(B, lc)
+        xres, hbuf, qkv, ao, ffn, head = ws["x"], ws["h"], ws["qkv"], ws["ao"], ws["ffn"], ws["head"]
+        xr = xres.view(B, lc, d)
+
+        # ---- stem: patch embedding of the noisy latent (+ cached static channels), ref tokens
+        bx = x.shape[0]
+        full = torch.empty(L, d, device=dev, dtype=F32) if sp > 1 else None
+        for b in range(bx):
+            pa = cd["patch_a"][b if cd["nb"] > 1 else 0]
+            hip.patchify(x[b].to(dev).contiguous(), pa, col0=0)
+            dst = full if sp > 1 else xr[b]
+            hip.gemm(pa, self.pe_w, self.pe_b, out=dst[ref_len:], out_dtype=F32)
+            if ref_len:
+                dst[:ref_len].copy_(cd["ref_tok"][b if cd["nb"] > 1 else 0])
+            if sp > 1:
+                xr[b].copy_(full[tok0:tok0 + lc])
+        for b in range(bx, B):
+            xr[b].copy_(xr[0])
+
+        # ---- timestep embedding on the distinct rows + AdaLN tables of all blocks and the head
+        R = t_rows.numel()
+        e, e0 = self.embed_time(t_rows)
+        tab = torch.empty(self.nl, R, 6, d, device=dev, dtype=F32)
+        hip.mod_table(self.mod, e0, tab, rows_per_batch, 0b010010, self.mdens, cd["dens0"], 0xFF1FF0 if cd["dens0"] is not None else -1)
+        htab = torch.empty(1, R, 2, d, device=dev, dtype=F32)
+        e2 = e.unsqueeze(1).expand(R, 2, d).contiguous()
+        hd_dens = cd["dens_emb"].view(B, 1, d) if cd["dens_emb"] is not None else None
+        hip.mod_table(self.hmod, e2, htab, rows_per_batch, 0b10, self.hmdens if hd_dens is not None else None, hd_dens,
+                      0xF0 if hd_dens is not None else -1)
+        if row_index is not None and sp > 1:
+            row_index = row_index.view(B, L)[:, tok0:tok0 + lc].contiguous().view(-1)
+        rpb = lc                                   # used only when row_index is None: row = m // lc = b
+
+        nh, hdim = self.nh, self.hd
+        q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hdim))
+        k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hdim))
+        v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hdim))
+        ao4 = ao.view(B, lc, nh, hdim)
+        for i, p in enumerate(self.blocks):
+            T = tab[i]
+            hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
+            hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
+            hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                             tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
+            if sp > 1:
+                kf, vf = self._gather_kv(qkv, B, lc)
+                hip.attn_fwd(q4, kf, vf, out=ao4)
+            else:
+                hip.attn_fwd(q4, k4, v4, out=ao4)
+            hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
+            # cross-attention on the text context (K/V precomputed per clip)
+            hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
+            qc = qkv[:, 0:d]
+            hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
+            hip.rmsnorm_rope(qc, p["cnq"], eps=self.eps)
+            kv = cd["cross_kv"][i]
+            hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4)
+            hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
+            # FFN
+            hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
+            hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
+            hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
+        # ---- head
+        H = htab[0]
+        hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=H[:, 0], scale=H[:, 1], row_index=row_index, rows_per_batch=rpb)
+        hip.gemm(hbuf, self.head_w, self.head_b, out=head)
+        return head.view(B, lc, -1)
+
+    # ------------------------------------------------------------------ sequence parallel
+    def _gather_kv(self, qkv, B, lc):
+        """All-gather of this block's post-norm, post-RoPE K and V over the sequence-parallel group
+        (RCCL over xGMI).  Returns K, V views [B, L, H, 128]."""
+        import torch.distributed as dist
+        d, sp = self.dim, self.sp_size
+        ws = self._ws[(B, lc)]
+        if "kv_send" not in ws:
+            ws["kv_send"] = torch.empty(B, lc, 2 * d, device=self.device, dtype=BF16)
+            ws["kv_full"] = torch.empty(sp, B, lc, 2 * d, device=self.device, dtype=BF16)
+            ws["kv_cat"] = torch.empty(B, sp * lc, 2 * d, device=self.device, dtype=BF16)
+        ws["kv_send"].copy_(qkv.view(B, lc, 3 * d)[:, :, d:])
+        dist.all_gather_into_tensor(ws["kv_full"], ws["kv_send"], group=self.sp_group)
+        ws["kv_cat"].view(B, sp, lc, 2 * d).copy_(ws["kv_full"].transpose(0, 1))
+        kv = ws["kv_cat"]
+        return kv[:, :, 0:d].unflatten(2, (self.nh, self.hd)), kv[:, :, d:].unflatten(2, (self.nh, self.hd))
+
+    def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
+        """All-gather of the head output [B, Lc, 192] -> [B, L, 192] (the reference's one collective,
+        wan_transformer3d_FlexAM.py:1103-1104)."""
+        if self.sp_size == 1:
+            return head_local
+        import torch.distributed as dist
+        B, lc, n = head_local.shape
+        out = torch.empty(self.sp_size, B, lc, n, device=head_local.device, dtype=head_local.dtype)
+        dist.all_gather_into_tensor(out, head_local.contiguous(), group=self.sp_group)
+        return out.transpose(0, 1).reshape(B, self.sp_size * lc, n)

@@ -1,0 +1,280 @@
+"""ctypes binding of libflexam_hip.so (C ABI in include/flexam_hip.h) + thin tensor wrappers.
+
+PyTorch is plumbing here: it owns device memory and the stream; every function below passes raw
+device pointers, sizes and strides to the HIP library and raises RuntimeError on a non-zero
+return code.  There is NO fallback: if the shared library is missing, or a tensor is not on a
+GPU, the call fails loudly (a silent CPU/eager path would void every parity claim).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflexam_hip.so")
+
+EPI_NONE, EPI_GELU_TANH = 0, 1
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+_SIGNATURES = {
+    "flexam_version": ([], c_int),
+    "flexam_arch": ([], c_char_p),
+    "flexam_last_error": ([], c_char_p),
+    "flexam_device_check": ([], c_int),
+    "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P], c_int),
+    "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P], c_int),
+    "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
+    "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
+    "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
+    "flexam_rmsnorm_rope": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
+    "flexam_mod_table": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
+    "flexam_small_linear_f32": ([_P, _L, _P, _I, _L, _P, _P, _L, _I, _I, _I, _I, _P], c_int),
+    "flexam_sinusoid_embed": ([_P, _P, _I, _I, _P], c_int),
+    "flexam_patchify": ([_P, _I, _I, _I, _I, _I, _P, _L, _I, _L, _P], c_int),
+    "flexam_unpatchify": ([_P, _L, _L, _I, _I, _I, _I, _P, _I, _P], c_int),
+    "flexam_cfg_euler_blend": ([_P, _P, _L, _L, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P], c_int),
+    "flexam_pack_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
+    "flexam_unpack_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _P], c_int),
+    "flexam_groupnorm_silu_cl": ([_P, _L, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _I, _P], c_int),
+}
+
+_lib = None
+
+
+def load_library(path: str = None) -> ctypes.CDLL:
+    """Loads libflexam_hip.so and declares every entry point.  No compute call is made, so this
+    also works on a host without a GPU (used by the CPU test that checks the exported symbols)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m flexam_amd.build` "
+                           "(flexam_amd has no CPU or eager fallback)")
+    lib = ctypes.CDLL(path)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def lib() -> ctypes.CDLL:
+    return _lib if _lib is not None else load_library()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().flexam_last_error().decode()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("flexam_amd.hip: tensor is not on a GPU (there is no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"flexam_amd.hip: expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _rows(t):
+    """2-D view requirements: last dim contiguous; returns (rows, cols, row_stride)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"flexam_amd.hip: expected a 2-D row-major view, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+
+
+def device_check():
+    _check(lib().flexam_device_check(), "flexam_device_check")
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=None, m=None, k=None):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  a, w bf16 2-D views (row stride free).
+    With a_koff (int64 [K/64]) `a` is only a base view: rows are `m`, K = `k` (implicit conv)."""
+    am, ak, lda = _rows(a)
+    wn, wk, ldw = _rows(w)
+    M = am if m is None else m
+    K = wk if k is None else k
+    if a_koff is None and ak != K:
+        raise RuntimeError(f"gemm: K mismatch a {ak} vs w {K}")
+    if out is None:
+        out = torch.empty(M, wn, device=a.device, dtype=out_dtype)
+    om, on, ldc = _rows(out)
+    if (om, on) != (M, wn):
+        raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != ({M}, {wn})")
+    _check(lib().flexam_gemm_bf16(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(out), ldc, M, wn, K, epilogue,
+                                  1 if out.dtype == F32 else 0, _ptr(a_koff, I64), _stream()), "flexam_gemm_bf16")
+    return out
+
+
+def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0):
+    """x[M,N] (fp32, in place) += bf16(a @ w^T + bias) * gate[row]."""
+    M, K, lda = _rows(a)
+    N, wk, ldw = _rows(w)
+    xm, xn, ldx = _rows(x)
+    if wk != K or (xm, xn) != (M, N):
+        raise RuntimeError("gemm_gate_residual: shape mismatch")
+    gate_ld = gate.stride(0) if gate is not None else 0
+    _check(lib().flexam_gemm_bf16_gate_residual(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(x, F32), ldx,
+                                                _ptr(gate, F32), gate_ld, _ptr(gate_row, I32), rows_per_batch, M, N, K,
+                                                _stream()), "flexam_gemm_bf16_gate_residual")
+    return x
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, out=None, softmax_scale=None):
+    """q [B,Lq,H,128], k/v [B,Lk,H,128] bf16 (arbitrary batch/row strides, head dim contiguous and
+    heads packed: stride(2) == 128) -> out [B,Lq,H,128] bf16."""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != D:
+            raise RuntimeError("attn_fwd: heads must be packed along the row (stride(2) == head_dim, stride(3) == 1)")
+    if out is None:
+        out = torch.empty(B, Lq, H, D, device=q.device, dtype=BF16)
+    scale = softmax_scale if softmax_scale is not None else D ** -0.5
+    _check(lib().flexam_attn_fwd(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1),
+                                 _ptr(v, BF16), v.stride(0), v.stride(1), _ptr(out, BF16), out.stride(0), out.stride(1),
+                                 B, H, Lq, Lk, D, scale, _stream()), "flexam_attn_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- DiT row kernels
+def ln_modulate(x, out=None, eps=1e-6, shift=None, scale=None, row_index=None, rows_per_batch=0, ln_w=None, ln_b=None):
+    M, C, ldx = _rows(x)
+    if out is None:
+        out = torch.empty(M, C, device=x.device, dtype=BF16)
+    tab_ld = shift.stride(0) if shift is not None else 0
+    if shift is not None and (shift.stride(-1) != 1 or scale.stride(-1) != 1 or scale.stride(0) != tab_ld):
+        raise RuntimeError("ln_modulate: shift/scale must be row views of one table")
+    _check(lib().flexam_ln_modulate(_ptr(x, F32), ldx, M, C, eps, _ptr(shift, F32), _ptr(scale, F32), tab_ld,
+                                    _ptr(row_index, I32), rows_per_batch, _ptr(ln_w, F32), _ptr(ln_b, F32), _ptr(out, BF16),
+                                    out.stride(0), _stream()), "flexam_ln_modulate")
+    return out
+
+
+def gate_residual(x, y, gate=None, row_index=None, rows_per_batch=0):
+    M, C, ldx = _rows(x)
+    gate_ld = gate.stride(0) if gate is not None else 0
+    _check(lib().flexam_gate_residual(_ptr(x, F32), ldx, _ptr(y, BF16), y.stride(0), _ptr(gate, F32), gate_ld,
+                                      _ptr(row_index, I32), rows_per_batch, M, C, _stream()), "flexam_gate_residual")
+    return x
+
+
+def rmsnorm_rope(q, wq, k=None, wk=None, eps=1e-6, rope_cos=None, rope_sin=None, tokens_per_batch=0, token_offset=0,
+                 head_dim=128, q_out=None, k_out=None):
+    """In place by default.  q/k: 2-D bf16 views [M, C]."""
+    M, C, ldq = _rows(q)
+    q_out = q if q_out is None else q_out
+    k_out = k if k_out is None else k_out
+    _check(lib().flexam_rmsnorm_rope(_ptr(q, BF16), ldq, _ptr(q_out, BF16), q_out.stride(0), _ptr(wq, F32),
+                                     _ptr(k, BF16), k.stride(0) if k is not None else 0,
+                                     _ptr(k_out, BF16), k_out.stride(0) if k_out is not None else 0, _ptr(wk, F32),
+                                     M, C, eps, _ptr(rope_cos, F32), _ptr(rope_sin, F32), tokens_per_batch, token_offset,
+                                     head_dim, _stream()), "flexam_rmsnorm_rope")
+    return q_out, k_out
+
+
+def mod_table(mod, e, out, rows_per_batch, scale_mask, mdens=None, dens=None, dens_slots=-1):
+    """mod [nblk,nj,C], e [R,nj,C], mdens [nblk,nslot,C], dens [B,nslot,C] -> out [nblk,R,nj,C] fp32."""
+    nblk, nj, C = mod.shape
+    R = e.shape[0]
+    nslot = mdens.shape[1] if mdens is not None else 0
+    for t in (mod, e, out, mdens, dens):
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("mod_table: tensors must be contiguous")
+    _check(lib().flexam_mod_table(_ptr(mod, F32), _ptr(e, F32), _ptr(mdens, F32), _ptr(dens, F32), _ptr(out, F32), nblk, R, nj,
+                                  nslot, C, rows_per_batch, scale_mask, dens_slots, _stream()), "flexam_mod_table")
+    return out
+
+
+def small_linear(x, w, b=None, silu_in=False, out=None):
+    """fp32 y[M,N] = silu?(x[M,K]) @ w[N,K]^T + b, M <= 8; w bf16 or fp32."""
+    M, K, ldx = _rows(x)
+    N, wk, ldw = _rows(w)
+    if wk != K:
+        raise RuntimeError("small_linear: K mismatch")
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=F32)
+    if w.dtype not in (BF16, F32):
+        raise RuntimeError("small_linear: weight must be bf16 or fp32")
+    _check(lib().flexam_small_linear_f32(_ptr(x, F32), ldx, _ptr(w), 1 if w.dtype == BF16 else 0, ldw, _ptr(b, F32),
+                                         _ptr(out, F32), out.stride(0), M, N, K, 1 if silu_in else 0, _stream()),
+           "flexam_small_linear_f32")
+    return out
+
+
+def sinusoid_embed(t, dim, out=None):
+    R = t.numel()
+    if out is None:
+        out = torch.empty(R, dim, device=t.device, dtype=F32)
+    _check(lib().flexam_sinusoid_embed(_ptr(t.contiguous(), F32), _ptr(out, F32), R, dim, _stream()), "flexam_sinusoid_embed")
+    return out
+
+
+def patchify(src, dst, col0=0, row0=0):
+    """src [C,F,H,W] (fp32/bf16, contiguous) -> dst[row0 + token, col0 + c*4+ph*2+pw] (bf16 2-D)."""
+    C, F, H, W = src.shape
+    if not src.is_contiguous():
+        raise RuntimeError("patchify: src must be contiguous")
+    _check(lib().flexam_patchify(_ptr(src), 1 if src.dtype == BF16 else 0, C, F, H, W, _ptr(dst, BF16), dst.stride(0), col0, row0,
+                                 _stream()), "flexam_patchify")
+    return dst
+
+
+def unpatchify(tok, tok0, C, F, H, W, out=None, dtype=F32):
+    if out is None:
+        out = torch.empty(C, F, H, W, device=tok.device, dtype=dtype)
+    _check(lib().flexam_unpatchify(_ptr(tok, F32), tok.stride(0), tok0, C, F, H, W, _ptr(out), 1 if out.dtype == BF16 else 0,
+                                   _stream()), "flexam_unpatchify")
+    return out
+
+
+def cfg_euler_blend(tok_uncond, tok_cond, tok0, guidance, dt, latents, known=None, mask=None):
+    C, F, H, W = latents.shape
+    _check(lib().flexam_cfg_euler_blend(_ptr(tok_uncond, F32), _ptr(tok_cond, F32), tok_uncond.stride(0), tok0, guidance, dt,
+                                        _ptr(latents, F32), _ptr(known, F32), _ptr(mask, F32), C, F, H, W, _stream()),
+           "flexam_cfg_euler_blend")
+    return latents
+
+
+# ----------------------------------------------------------------------------- channels-last conv helpers
+def pack_cl(src, dst, c0=0):
+    """src [C,F,H,W] -> interior of dst [F,H+2,W+2,Cp] (bf16) at channel offset c0."""
+    C, F, H, W = src.shape
+    if not src.is_contiguous() or dst.shape[:3] != (F, H + 2, W + 2) or not dst.is_contiguous():
+        raise RuntimeError("pack_cl: bad layout")
+    _check(lib().flexam_pack_cl(_ptr(src), 1 if src.dtype == BF16 else 0, C, F, H, W, _ptr(dst, BF16), dst.shape[3], c0, _stream()),
+           "flexam_pack_cl")
+    return dst
+
+
+def unpack_cl(src, C, F, H, W, out=None):
+    """src [F*(H+2)*(W+2), ld] (fp32/bf16 rows) -> [C,F,H,W] fp32."""
+    if out is None:
+        out = torch.empty(C, F, H, W, device=src.device, dtype=F32)
+    _check(lib().flexam_unpack_cl(_ptr(src), 1 if src.dtype == BF16 else 0, src.stride(0), C, F, H, W, _ptr(out, F32), _stream()),
+           "flexam_unpack_cl")
+    return out
+
+
+def groupnorm_silu_cl(x, C, F, H, W, groups, gamma, beta, dst, residual=None, eps=1e-5, stats=None):
+    """x [F*(H+2)*(W+2), ld] fp32 -> dst [F,H+2,W+2,Cp] bf16 interior; residual: bf16 padded image."""
+    if stats is None:
+        stats = torch.empty(2 * groups, device=x.device, dtype=F32)
+    _check(lib().flexam_groupnorm_silu_cl(_ptr(x, F32), x.stride(0), C, F, H, W, groups, eps, _ptr(gamma, F32), _ptr(beta, F32),
+                                          _ptr(stats, F32), _ptr(residual, BF16), residual.shape[-1] if residual is not None else 0,
+                                          _ptr(dst, BF16), dst.shape[-1], _stream()), "flexam_groupnorm_silu_cl")
+    return dst

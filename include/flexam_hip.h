@@ -1,0 +1,139 @@
+/* include/flexam_hip.h -- C ABI of libflexam_hip.so: the MI355X (gfx950) kernels behind the
+ * FlexAM denoising hot path (Wan2.2-Fun-5B-FLEXAM DiT forward, sampler step, Wan2.2 3D-VAE
+ * decode).  This is the drop-in boundary: plain pointers and sizes, no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 (FLEXAM_OK) or a negative FLEXAM_E_* code; flexam_last_error()
+ *     returns the message of the last failure on the calling thread;
+ *   - all pointers are DEVICE pointers unless a comment says host; the caller (PyTorch-ROCm in
+ *     flexam_amd/hip.py) owns every buffer, the library never allocates, frees or retains one;
+ *   - `stream` is a hipStream_t; calls are asynchronous and ordered on it, no hidden syncs,
+ *     safe to capture into a hipGraph;
+ *   - bf16 = IEEE bfloat16 (torch.bfloat16); "f32 table row" arguments are row pointers of
+ *     small fp32 tables selected per token through an int32 row index ("two-row
+ *     modulation").
+ * Each entry point cites the reference code it replaces (paths relative to the FlexAM repo).
+ */
+#ifndef FLEXAM_HIP_H
+#define FLEXAM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLEXAM_HIP_VERSION 1
+#define FLEXAM_OK 0
+#define FLEXAM_E_ARG (-1)
+#define FLEXAM_E_SHAPE (-2)
+#define FLEXAM_E_ARCH (-3)
+#define FLEXAM_E_LAUNCH (-4)
+
+#define FLEXAM_EPI_NONE 0
+#define FLEXAM_EPI_GELU_TANH 1
+
+int flexam_version(void);
+const char* flexam_arch(void);          /* "gfx950" */
+const char* flexam_last_error(void);
+int flexam_device_check(void);          /* FLEXAM_E_ARCH unless the current device is gfx950 */
+
+/* C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]); A, W bf16 row-major with K contiguous (nn.Linear
+ * weight layout), fp32 accumulate on MFMA; C bf16 (out_f32 = 0) or fp32 (out_f32 = 1).
+ * K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0 (pad on the host).  a_koff (optional, [K/64] int64,
+ * device): element offset added to every A row base for K block kb instead of kb*64 -- the
+ * implicit-GEMM form of the VAE's causal convolutions (one entry per (tap, 64-channel slice)).
+ * Replaces nn.Linear -> cuBLAS: FlexAM/models/wan_transformer3d_FlexAM.py:242-244,261,363-365,
+ * 370,415-416,487,626-636 and Conv3d/Conv2d -> cuDNN: FlexAM/models/wan_vae3_8.py:39-47,94,99. */
+int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int epilogue, int out_f32, const int64_t* a_koff, void* stream);
+
+/* X[m,n] += bf16(A.W^T + bias)[m,n] * gate[row(m), n]   (fp32 residual stream updated in place)
+ * row(m) = gate_row[m] if gate_row else m / rows_per_batch; gate == NULL means gate = 1.
+ * Replaces Linear + `x = x + y * e[2]` / `x + cross_attn(...)` / `x + y * e[5]`:
+ * FlexAM/models/wan_transformer3d_FlexAM.py:261+456, 370+461, 416+468. */
+int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* X,
+                                   int64_t ldx, const float* gate, int64_t gate_ld, const int32_t* gate_row,
+                                   int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* Flash attention forward, head_dim 128, non-causal, keys [0, Lk): o = softmax(q k^T * scale) v.
+ * q/k/v/o are [B, L, H, 128] views given by batch stride `*_bs` and row stride `*_rs` (elements);
+ * head h starts at column h*128 of a row.  bf16 in/out, fp32 softmax/accumulate.
+ * Replaces attention() -> flash_attn / sageattn / SDPA: FlexAM/models/attention_utils.py:43-233
+ * (call sites wan_transformer3d_FlexAM.py:251-256 self, :367 cross). */
+int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
+                    int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk,
+                    int head_dim, float softmax_scale, void* stream);
+
+/* out_bf16[m,:] = LN(x_f32[m,:]; eps) [* ln_w + ln_b] [* scale[row(m),:] + shift[row(m),:]]
+ * row(m) = row_index[m] if row_index else m / rows_per_batch; scale rows already hold (1+scale),
+ * shift rows already hold shift + density shift (flexam_mod_table).  Replaces WanLayerNorm +
+ * modulate: FlexAM/models/wan_transformer3d_FlexAM.py:192-202,452-453,461(norm3),464-465,506. */
+int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C, float eps, const float* shift, const float* scale,
+                       int64_t tab_ld, const int32_t* row_index, int64_t rows_per_batch, const float* ln_w,
+                       const float* ln_b, void* out, int64_t ldo, void* stream);
+
+/* x_f32[m,:] += y_bf16[m,:] * gate[row(m),:] (gate NULL = 1).  wan_transformer3d_FlexAM.py:456,461,468. */
+int flexam_gate_residual(float* x, int64_t ldx, const void* y, int64_t ldy, const float* gate, int64_t gate_ld,
+                         const int32_t* row_index, int64_t rows_per_batch, int64_t M, int C, void* stream);
+
+/* WanRMSNorm over the full row (all heads) followed by the 3-axis interleaved-pair RoPE, for q and
+ * (optionally) k in one launch; bf16 in/out (in place allowed), fp32 math, one rounding.
+ * rope_cos/rope_sin: [tokens, head_dim/2] fp32 per-token tables (identity rows = pass-through);
+ * NULL = no rotation (cross-attention q).  token(m) = token_offset + m % tokens_per_batch.
+ * Replaces WanRMSNorm.forward + rope_apply_qk: wan_transformer3d_FlexAM.py:137-170,173-189,242-249. */
+int flexam_rmsnorm_rope(const void* q_in, int64_t ldq_in, void* q_out, int64_t ldq_out, const float* wq, const void* k_in,
+                        int64_t ldk_in, void* k_out, int64_t ldk_out, const float* wk, int64_t M, int C, float eps,
+                        const float* rope_cos, const float* rope_sin, int64_t tokens_per_batch, int64_t token_offset,
+                        int head_dim, void* stream);
+
+/* out[blk][r][j][:] = mod[blk][j][:] + e[r][j][:] + ((scale_mask>>j)&1) + density terms, where slot
+ * s = (dens_slots >> 4j) & 0xF (0xF = none) adds mdens[blk][s][:] + dens[r / rows_per_batch][s][:].
+ * One launch per denoise step builds the AdaLN tables of all blocks (wan_transformer3d_FlexAM.py:
+ * 444-449,452,464; head :500-506). */
+int flexam_mod_table(const float* mod, const float* e, const float* mdens, const float* dens, float* out, int nblk, int R,
+                     int nj, int nslot, int C, int rows_per_batch, int scale_mask, int dens_slots, void* stream);
+
+/* y[M,N] = silu_in?(x[M,K]) . W[N,K]^T + b, fp32 math, 1 <= M <= 8, W bf16 or fp32.  The time /
+ * density embedding MLPs (forced fp32 in the reference: wan_transformer3d_FlexAM.py:928-955). */
+int flexam_small_linear_f32(const float* x, int64_t ldx, const void* W, int w_is_bf16, int64_t ldw, const float* b, float* y,
+                            int64_t ldy, int M, int N, int K, int silu_in, void* stream);
+
+/* out[r][:dim/2] = cos(t[r] f_i), out[r][dim/2:] = sin(t[r] f_i), f_i = 10000^(-i/(dim/2)), fp64 math
+ * (sinusoidal_embedding_1d, wan_transformer3d_FlexAM.py:31-41). */
+int flexam_sinusoid_embed(const float* t, float* out, int R, int dim, void* stream);
+
+/* im2col of a kernel = stride = (1,2,2) conv: src [C,F,H,W] (fp32 or bf16) ->
+ * dst[row0 + (f,h/2,w/2)][col0 + c*4 + ph*2 + pw] bf16 (weight.flatten(1) column order).
+ * patch_embedding / ref_conv inputs: wan_transformer3d_FlexAM.py:624-625,676,885,896. */
+int flexam_patchify(const void* src, int src_is_bf16, int C, int F, int H, int W, void* dst, int64_t ldd, int col0,
+                    int64_t row0, void* stream);
+
+/* Head output tokens [L, 4C] fp32 (col = (ph*2+pw)*C + c), starting at token tok0 -> [C,F,H,W].
+ * unpatchify, wan_transformer3d_FlexAM.py:1126-1149 (tok0 skips the reference-image tokens, :1106-1109). */
+int flexam_unpatchify(const float* tok, int64_t ldt, int64_t tok0, int C, int F, int H, int W, void* dst, int dst_is_bf16,
+                      void* stream);
+
+/* One fused sampler step on fp32 latents [C,F,H,W]: v = u + guidance (c - u) (tok_cond NULL: v = u),
+ * x += dt v, x = (1 - mask) known + mask x (mask [F,H,W], NULL: no blend).
+ * FlexAM/pipeline/pipeline_wan2_2_fun_control_FlexAM.py:926-934 (+ unpatchify of both CFG rows). */
+int flexam_cfg_euler_blend(const float* tok_uncond, const float* tok_cond, int64_t ldt, int64_t tok0, float guidance, float dt,
+                           float* latents, const float* known, const float* mask, int C, int F, int H, int W, void* stream);
+
+/* Channels-last helpers around the implicit-GEMM convolutions (cnn-block: wan_transformer3d_FlexAM.py:
+ * 680-705,869-881; VAE decoder: wan_vae3_8.py).  A conv input is a spatially zero-padded bf16 image
+ * img[f][H+2][W+2][Cp]; tap (dh,dw) of a 3x3 kernel is then the constant A offset
+ * ((dh-1)*(W+2)+(dw-1))*Cp handed to flexam_gemm_bf16 through a_koff.
+ * pack_cl:   src [C,F,H,W] (fp32|bf16) -> interior of img at channel offset c0.
+ * unpack_cl: rows [(f,hp,wp)][ld] (fp32|bf16), interior positions -> dst [C,F,H,W] fp32.
+ * groupnorm_silu_cl: GroupNorm(groups, eps) over all interior positions of x [(f,hp,wp)][ld] fp32
+ *   (stats: scratch [2*groups] fp32), * gamma + beta, SiLU, optional + residual (bf16 padded image,
+ *   channel stride res_cp) -> interior of the bf16 padded image dst (channel stride Cp). */
+int flexam_pack_cl(const void* src, int src_is_bf16, int C, int F, int H, int W, void* dst, int Cp, int c0, void* stream);
+int flexam_unpack_cl(const void* src, int src_is_bf16, int64_t ld, int C, int F, int H, int W, float* dst, void* stream);
+int flexam_groupnorm_silu_cl(const float* x, int64_t ld, int C, int F, int H, int W, int groups, float eps, const float* gamma,
+                             const float* beta, float* stats, const void* residual, int res_cp, void* dst, int Cp, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEXAM_HIP_H */

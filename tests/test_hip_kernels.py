@@ -1,0 +1,301 @@
+"""GPU parity tests of each HIP kernel, called through the C ABI (flexam_amd.hip -> libflexam_hip.so),
+against the fp32 oracle (oracle/dit.py) on the same seeded inputs.
+
+Tolerances (stated per op, "HIP bf16 path vs fp32 restatement"):
+  * GEMM / attention: inputs are bf16-representable, products accumulate in fp32 on MFMA, the
+    output is rounded once to bf16  ->  |err| <= 2^-8 |out| + small absolute slack;
+  * elementwise / norm kernels: fp32 math, one bf16 rounding of the output -> 1 bf16 ulp;
+  * fp32-output kernels (residual, sampler step, small linear): 1e-5 relative.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf(x):
+    return x.to(BF)
+
+
+def assert_bf16_close(got, want, ulps=1.0, atol=0.0, msg=""):
+    got, want = got.float().cpu(), want.float().cpu()
+    tol = ulps * (2.0 ** -8) * want.abs() + atol
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{msg} {int(bad.sum())}/{bad.numel()} off; max err {(got - want).abs().max():.4g}"
+
+
+@pytest.fixture(scope="module")
+def H():
+    from flexam_amd import hip
+    hip.device_check()
+    return hip
+
+
+# ----------------------------------------------------------------------------- GEMM
+def test_gemm_identity_asymmetric(H):
+    """A = I with an asymmetric W catches transposed / permuted fragment maps exactly."""
+    n, k = 512, 256
+    a = torch.zeros(256, k, dtype=BF, device=dev())
+    a[torch.arange(256), torch.arange(256)] = 1
+    w = bf(torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 251 - 125).to(dev())
+    out = H.gemm(a, w, out_dtype=torch.float32)
+    torch.testing.assert_close(out.cpu(), w.float().cpu().t()[:256].contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (300, 200, 128), (1000, 772, 192), (2048, 1536, 3072), (77, 3072, 640)])
+def test_gemm_exact_integers(H, m, n, k):
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    w = torch.randint(-3, 4, (n, k), generator=g).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    out = H.gemm(bf(a).to(dev()), bf(w).to(dev()), b.to(dev()), out_dtype=torch.float32)
+    torch.testing.assert_close(out.cpu(), a @ w.t() + b, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("epi", ["none", "gelu"])
+def test_gemm_random_bf16_out_strided(H, epi):
+    g = torch.Generator().manual_seed(5)
+    m, n, k = 700, 1024, 512
+    big = bf(torch.randn(m, 3 * k, generator=g))
+    a = big[:, k:2 * k]                                  # row stride 3k: a slice of a fused buffer
+    w = bf(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b = torch.randn(n, generator=g) * 0.1
+    outbuf = torch.zeros(m, 2 * n, dtype=BF, device=dev())
+    H.gemm(big.to(dev())[:, k:2 * k], w.to(dev()), b.to(dev()), out=outbuf[:, n:],
+           epilogue=H.EPI_GELU_TANH if epi == "gelu" else H.EPI_NONE)
+    want = a.float() @ w.float().t() + b
+    if epi == "gelu":
+        want = F.gelu(want, approximate="tanh")
+    assert_bf16_close(outbuf[:, n:], want, ulps=1.0, atol=2e-3, msg="gemm")
+    assert float(outbuf[:, :n].abs().max()) == 0.0     # nothing written outside the view
+
+
+def test_gemm_koff_implicit_conv(H):
+    """Per-K-block A offsets: a 3-tap 1-D 'convolution' over rows of a [R, 64] buffer."""
+    g = torch.Generator().manual_seed(9)
+    rows, cin, cout, m = 400, 64, 128, 300
+    x = bf(torch.randn(rows, cin, generator=g))
+    w = bf(torch.randn(cout, 3 * cin, generator=g) / math.sqrt(3 * cin))
+    koff = torch.tensor([0 * cin, 1 * cin, 2 * cin], dtype=torch.int64)        # tap t reads row m + t
+    out = H.gemm(x.to(dev()), w.to(dev()), None, a_koff=koff.to(dev()), m=m, k=3 * cin, out_dtype=torch.float32)
+    xa = torch.cat([x[0:m], x[1:m + 1], x[2:m + 2]], dim=1).float()
+    torch.testing.assert_close(out.cpu(), xa @ w.float().t(), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_gate_residual(H):
+    g = torch.Generator().manual_seed(10)
+    m, n, k = 520, 512, 256
+    a = bf(torch.randn(m, k, generator=g))
+    w = bf(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b = torch.randn(n, generator=g) * 0.1
+    x = torch.randn(m, n, generator=g)
+    gate = torch.randn(4, n, generator=g)
+    rows = torch.randint(0, 4, (m,), generator=g, dtype=torch.int32)
+    xd = x.clone().to(dev())
+    H.gemm_gate_residual(a.to(dev()), w.to(dev()), b.to(dev()), xd, gate.to(dev()), rows.to(dev()))
+    y = bf(a.float() @ w.float().t() + b).float()
+    want = x + y * gate[rows.long()]
+    # y is rounded to bf16 inside the kernel exactly as here, up to fp32 accumulation order
+    torch.testing.assert_close(xd.cpu(), want, rtol=0, atol=2.0 ** -7 * 4)
+    xd2 = x.clone().to(dev())
+    H.gemm_gate_residual(a.to(dev()), w.to(dev()), b.to(dev()), xd2)           # gate = 1 (cross-attention form)
+    torch.testing.assert_close(xd2.cpu(), x + y, rtol=0, atol=2.0 ** -7 * 4)
+
+
+# ----------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v):
+    from oracle import dit as O
+    return O.attention(q.float(), k.float(), v.float())
+
+
+@pytest.mark.parametrize("b,h,lq,lk", [(1, 2, 256, 256), (2, 3, 300, 77), (1, 1, 64, 1000), (1, 2, 1111, 1111)])
+def test_attention_matches_oracle(H, b, h, lq, lk):
+    g = torch.Generator().manual_seed(lq + lk)
+    q = bf(torch.randn(b, lq, h, 128, generator=g))
+    k = bf(torch.randn(b, lk, h, 128, generator=g))
+    v = bf(torch.randn(b, lk, h, 128, generator=g))
+    out = H.attn_fwd(q.to(dev()), k.to(dev()), v.to(dev()))
+    assert_bf16_close(out, _attn_ref(q, k, v), ulps=2.0, atol=6e-3, msg="attention")
+
+
+def test_attention_strided_qkv_and_scale(H):
+    """q, k, v as column slices of one fused [B, L, 3*H*128] projection buffer (the DiT layout)."""
+    g = torch.Generator().manual_seed(3)
+    b, l, h = 2, 320, 2
+    qkv = bf(torch.randn(b, l, 3 * h * 128, generator=g) * 2.0)
+    d = qkv.to(dev())
+    views = [d[:, :, i * h * 128:(i + 1) * h * 128].unflatten(2, (h, 128)) for i in range(3)]
+    out = H.attn_fwd(*views)
+    q, k, v = (qkv[:, :, i * h * 128:(i + 1) * h * 128].unflatten(2, (h, 128)) for i in range(3))
+    assert_bf16_close(out, _attn_ref(q, k, v), ulps=2.0, atol=6e-3, msg="attention strided")
+
+
+def test_attention_online_softmax_rescale_spike(H):
+    """Force the running max to jump at a late key tile (cdna guide rule 26): one key aligned with
+    one query and scaled up, placed in the 5th tile; rows that see it must still be exact."""
+    g = torch.Generator().manual_seed(4)
+    l = 512
+    q = torch.randn(1, l, 1, 128, generator=g)
+    k = torch.randn(1, l, 1, 128, generator=g)
+    v = torch.randn(1, l, 1, 128, generator=g)
+    k[0, 300, 0] = q[0, 17, 0] * 3.0
+    k[0, 450, 0] = q[0, 200, 0] * 5.0
+    q, k, v = bf(q), bf(k), bf(v)
+    out = H.attn_fwd(q.to(dev()), k.to(dev()), v.to(dev()))
+    assert_bf16_close(out, _attn_ref(q, k, v), ulps=2.0, atol=6e-3, msg="attention spike")
+
+
+def test_attention_linearity_in_v_full_size(H):
+    """Size-independent property at the BASELINE shape (L = 11648, one head pair): attention is
+    linear in V, and a constant V gives that constant back."""
+    g = torch.Generator().manual_seed(6)
+    l, h = 11648, 2
+    q = bf(torch.randn(1, l, h, 128, generator=g)).to(dev())
+    k = bf(torch.randn(1, l, h, 128, generator=g)).to(dev())
+    ones = torch.ones(1, l, h, 128, dtype=BF, device=dev())
+    out = H.attn_fwd(q, k, ones)
+    torch.testing.assert_close(out.float(), torch.ones_like(out).float(), rtol=0, atol=2.0 ** -7)
+    v1 = bf(torch.randn(1, l, h, 128, generator=g)).to(dev())
+    o1 = H.attn_fwd(q, k, v1).float()
+    o2 = H.attn_fwd(q, k, (v1.float() * 2).to(BF)).float()
+    torch.testing.assert_close(o2, 2 * o1, rtol=2.0 ** -6, atol=1e-3)
+    # spot-check 64 query rows against the oracle
+    rows = torch.arange(0, l, l // 64)[:64]
+    ref = _attn_ref(q[:, rows].cpu(), k.cpu(), v1.cpu())
+    assert_bf16_close(o1[:, rows], ref, ulps=2.0, atol=4e-3, msg="attention full size rows")
+
+
+# ----------------------------------------------------------------------------- row kernels
+def test_ln_modulate_two_row_table(H):
+    from oracle import dit as O
+    g = torch.Generator().manual_seed(20)
+    m, c = 333, 3072
+    x = torch.randn(m, c, generator=g) * 2 + 0.5
+    table = torch.randn(4, 2, c, generator=g) * 0.5           # [rows][shift|scale]
+    rows = torch.randint(0, 4, (m,), generator=g, dtype=torch.int32)
+    out = H.ln_modulate(x.to(dev()), shift=table.to(dev())[:, 0], scale=table.to(dev())[:, 1], row_index=rows.to(dev()))
+    want = O.layer_norm(x, 1e-6) * table[rows.long(), 1] + table[rows.long(), 0]
+    assert_bf16_close(out, want, ulps=1.0, atol=1e-6, msg="ln_modulate")
+    # affine form (norm3) on a narrower row, batch-indexed table form
+    x2 = torch.randn(64, 256, generator=g)
+    w, b = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    out2 = H.ln_modulate(x2.to(dev()), ln_w=w.to(dev()), ln_b=b.to(dev()))
+    assert_bf16_close(out2, O.layer_norm(x2, 1e-6, w, b), ulps=1.0, atol=1e-6, msg="ln affine")
+    t2 = torch.randn(2, 2, 256, generator=g)
+    out3 = H.ln_modulate(x2.to(dev()), shift=t2.to(dev())[:, 0], scale=t2.to(dev())[:, 1], rows_per_batch=32)
+    idx = torch.arange(64) // 32
+    assert_bf16_close(out3, O.layer_norm(x2, 1e-6) * t2[idx, 1] + t2[idx, 0], ulps=1.0, atol=1e-6, msg="ln batch rows")
+
+
+def test_gate_residual(H):
+    g = torch.Generator().manual_seed(21)
+    m, c = 257, 3072
+    x = torch.randn(m, c, generator=g)
+    y = bf(torch.randn(m, c, generator=g))
+    gate = torch.randn(3, c, generator=g)
+    rows = torch.randint(0, 3, (m,), generator=g, dtype=torch.int32)
+    xd = x.clone().to(dev())
+    H.gate_residual(xd, y.to(dev()), gate.to(dev()), rows.to(dev()))
+    torch.testing.assert_close(xd.cpu(), x + y.float() * gate[rows.long()], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("c,heads", [(256, 2), (3072, 24)])
+def test_rmsnorm_rope_matches_oracle(H, c, heads):
+    from oracle import dit as O
+    from flexam_amd.rope import rope_tables
+    g = torch.Generator().manual_seed(22)
+    grid = (3, 4, 6)
+    l = grid[0] * grid[1] * grid[2] + 5                      # 5 pass-through tokens
+    b = 2
+    q = bf(torch.randn(b, l, c, generator=g) * 1.5)
+    k = bf(torch.randn(b, l, c, generator=g))
+    wq, wk = 1 + 0.1 * torch.randn(c, generator=g), 1 + 0.1 * torch.randn(c, generator=g)
+    cos, sin = rope_tables(grid, l, 128)
+    qd, kd = q.clone().to(dev()).view(b * l, c), k.clone().to(dev()).view(b * l, c)
+    H.rmsnorm_rope(qd, wq.to(dev()), kd, wk.to(dev()), rope_cos=cos.to(dev()), rope_sin=sin.to(dev()), tokens_per_batch=l)
+    ang = O.rope_angles(1024, 128)
+    for got, x, w in ((qd, q, wq), (kd, k, wk)):
+        want = O.rope_apply(O.rms_norm(x.float(), w, 1e-6).view(b, l, heads, 128), grid, ang).reshape(b * l, c)
+        assert_bf16_close(got, want, ulps=1.0, atol=1e-6, msg="rmsnorm_rope")
+    # no-rope, q only (cross-attention form)
+    q2 = q.clone().to(dev()).view(b * l, c)
+    H.rmsnorm_rope(q2, wq.to(dev()))
+    assert_bf16_close(q2, O.rms_norm(q.float(), wq, 1e-6).view(b * l, c), ulps=1.0, atol=1e-6, msg="rmsnorm")
+
+
+def test_mod_table_small_linear_sinusoid(H):
+    from oracle import dit as O
+    g = torch.Generator().manual_seed(23)
+    nblk, R, C, B = 3, 4, 256, 2
+    mod, e = torch.randn(nblk, 6, C, generator=g), torch.randn(R, 6, C, generator=g)
+    mdens, dens = torch.randn(nblk, 2, C, generator=g), torch.randn(B, 2, C, generator=g)
+    out = torch.empty(nblk, R, 6, C, device=dev())
+    H.mod_table(mod.to(dev()), e.to(dev()), out, rows_per_batch=R // B, scale_mask=0b010010, mdens=mdens.to(dev()),
+                dens=dens.to(dev()), dens_slots=0xFF1FF0)
+    want = mod[:, None] + e[None]
+    want[:, :, 1] += 1
+    want[:, :, 4] += 1
+    bidx = torch.arange(R) // (R // B)
+    want[:, :, 0] += mdens[:, None, 0] + dens[bidx, 0][None]
+    want[:, :, 3] += mdens[:, None, 1] + dens[bidx, 1][None]
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-6, atol=1e-6)
+
+    t = torch.tensor([0.0, 24.4, 500.0, 1000.0])
+    torch.testing.assert_close(H.sinusoid_embed(t.to(dev()), 256).cpu(), O.sinusoidal_embedding_1d(256, t).float(), rtol=0, atol=1e-6)
+
+    x = torch.randn(4, 256, generator=g)
+    for wdt in (torch.float32, BF):
+        w = (torch.randn(768, 256, generator=g) / 16).to(wdt)
+        b = torch.randn(768, generator=g)
+        y = H.small_linear(x.to(dev()), w.to(dev()), b.to(dev()), silu_in=True)
+        torch.testing.assert_close(y.cpu(), F.linear(F.silu(x), w.float(), b), rtol=1e-5, atol=1e-5)
+
+
+def test_patchify_gemm_equals_conv3d_and_unpatchify(H):
+    from oracle import dit as O
+    g = torch.Generator().manual_seed(24)
+    c, f, h, w, d = 20, 3, 8, 12, 256
+    x = bf(torch.randn(c, f, h, w, generator=g))
+    wt = bf(torch.randn(d, c, 1, 2, 2, generator=g) / math.sqrt(c * 4))
+    bias = torch.randn(d, generator=g)
+    kpad = 128                                                  # c*4 = 80 -> padded K
+    a = torch.zeros(f * (h // 2) * (w // 2), kpad, dtype=BF, device=dev())
+    H.patchify(x.float().to(dev()), a)
+    wpad = torch.zeros(d, kpad, dtype=BF)
+    wpad[:, : c * 4] = wt.flatten(1)
+    out = H.gemm(a, wpad.to(dev()), bias.to(dev()), out_dtype=torch.float32)
+    want = F.conv3d(x.float()[None], wt.float(), bias, stride=(1, 2, 2))[0].flatten(1).t()
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-4, atol=1e-4)
+
+    cc = 48
+    tok = torch.randn(5 + f * (h // 2) * (w // 2), 4 * cc, generator=g)
+    got = H.unpatchify(tok.to(dev()), 5, cc, f, h, w)
+    torch.testing.assert_close(got.cpu(), O.unpatchify(tok[5:], (f, h // 2, w // 2), (1, 2, 2), cc), rtol=0, atol=0)
+
+
+def test_cfg_euler_blend(H):
+    from oracle import dit as O
+    g = torch.Generator().manual_seed(25)
+    c, f, h, w = 48, 3, 8, 12
+    n = f * (h // 2) * (w // 2)
+    tu, tc = torch.randn(7 + n, 4 * c, generator=g), torch.randn(7 + n, 4 * c, generator=g)
+    lat, known = torch.randn(c, f, h, w, generator=g), torch.randn(c, f, h, w, generator=g)
+    mask = torch.ones(f, h, w)
+    mask[0] = 0
+    mask[1, :2] = 0.25
+    ld = lat.clone().to(dev())
+    H.cfg_euler_blend(tu.to(dev()), tc.to(dev()), 7, 6.0, -0.0371, ld, known.to(dev()), mask.to(dev()))
+    vu = O.unpatchify(tu[7:], (f, h // 2, w // 2), (1, 2, 2), c)
+    vc = O.unpatchify(tc[7:], (f, h // 2, w // 2), (1, 2, 2), c)
+    x = lat + (-0.0371) * (vu + 6.0 * (vc - vu))
+    want = (1 - mask) * known + mask * x
+    torch.testing.assert_close(ld.cpu(), want, rtol=1e-5, atol=1e-5)
