@@ -1,0 +1,31 @@
+"""flexam_amd -- MI355X-native implementation of FlexAM's denoising hot path.
+
+Exports the reference's names (FlexAM/models/__init__.py, FlexAM/pipeline/__init__.py) so
+`pipelines.py` / ComfyUI nodes can import them unchanged:
+    Wan2_2Transformer3DModel_FlexAM, WanTransformer3DModel_FlexAM, AutoencoderKLWan3_8,
+    Wan2_2FunControlPipeline_FlexAM, attention
+Arithmetic runs in libflexam_hip.so (hand-written gfx950 HIP kernels, C ABI in
+include/flexam_hip.h); this package is the host-side mirror of the reference interface.
+"""
+__all__ = ["Wan2_2Transformer3DModel_FlexAM", "WanTransformer3DModel_FlexAM", "AutoencoderKLWan3_8",
+           "Wan2_2FunControlPipeline_FlexAM", "FlowMatchEulerDiscreteScheduler", "attention"]
+
+
+def __getattr__(name):
+    # lazy: importing the package must not need torch.cuda or the built library
+    if name in ("Wan2_2Transformer3DModel_FlexAM", "WanTransformer3DModel_FlexAM"):
+        from . import wan_transformer3d_FlexAM as m
+        return getattr(m, name)
+    if name == "AutoencoderKLWan3_8":
+        from .wan_vae3_8 import AutoencoderKLWan3_8
+        return AutoencoderKLWan3_8
+    if name in ("Wan2_2FunControlPipeline_FlexAM", "WanPipelineOutput"):
+        from . import pipeline_wan2_2_fun_control_FlexAM as m
+        return getattr(m, name)
+    if name == "FlowMatchEulerDiscreteScheduler":
+        from .scheduler import FlowMatchEulerDiscreteScheduler
+        return FlowMatchEulerDiscreteScheduler
+    if name == "attention":
+        from .attention_utils import attention
+        return attention
+    raise AttributeError(name)
