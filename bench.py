@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- denoise-steps/sec of the FlexAM hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE config 2): Wan2.2-Fun-5B-FLEXAM DiT (dim 3072, 24 heads x 128, ffn 14336,
+30 layers, 5.03 B parameters, random-init bf16), 97x512x896 -> latent [1,48,25,32,56], L = 11648 tokens
+(448 reference-image tokens + 11200 video tokens), CFG pair (B = 2), flow-match Euler, 50-step schedule,
+synthetic seeded conditioning.  One *step* = one iteration of the reference loop
+(pipeline_wan2_2_fun_control_FlexAM.py:844-949): two DiT sample-forwards + CFG + Euler + masked blend.
+N > 1: one process per GPU, the token sequence is split into N contiguous chunks, K/V are all-gathered
+per block over RCCL/xGMI (strong scaling of ONE clip).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the self-attention flash kernel, timed
+live with events on the launch stream) and `cpu_baseline` (the fp32 oracle on the host cores, one of the
+60 block-forwards of a step, extrapolated -- a baseline, not a target).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def block_flops(L, d, f, T):
+    """Algorithmic FLOPs of one WanAttentionBlock on one sample."""
+    return 8 * L * d * d + 4 * L * L * d + 4 * L * d * d + 4 * T * d * d + 4 * L * T * d + 4 * L * d * f
+
+
+def synthetic_inputs(frames, height, width, text_dim):
+    """Seeded synthetic conditioning of SURVEY 8(d) (CPU generators -> identical on every rank)."""
+    f, h, w = (frames - 1) // 4 + 1, height // 16, width // 16
+    g0 = torch.Generator().manual_seed(1245644)          # demo.py seed
+    latents = torch.randn(1, 48, f, h, w, generator=g0)
+    g1 = torch.Generator().manual_seed(1)
+    control = torch.randn(1, 48, f, h, w, generator=g1)
+    additional = torch.randn(1, 240, f, h, w, generator=g1)
+    masked = torch.randn(1, 48, f, h, w, generator=g1)
+    ref = torch.randn(1, 48, h, w, generator=g1)
+    g2 = torch.Generator().manual_seed(2)
+    ctx_u = [torch.randn(77, text_dim, generator=g2) * 0.1]
+    ctx_c = [torch.randn(126, text_dim, generator=g2) * 0.1]
+    mask = torch.ones(1, 1, f, h, w)
+    mask[:, :, 0] = 0                                     # motion_transfer: frame 0 known
+    mask_latents = torch.zeros(1, 4, f, h, w)
+    mask_latents[:, :, 0] = 1                             # resize_mask(1 - mask_condition) for that mask
+    return dict(latents=latents, control=control, additional=additional, masked=masked, ref=ref, ctx_u=ctx_u, ctx_c=ctx_c,
+                mask=mask, mask_latents=mask_latents)
+
+
+def build_model(cfg, device):
+    from flexam_amd import Wan2_2Transformer3DModel_FlexAM
+    kw = dict(cfg)
+    kw.pop("eps", None)
+    torch.manual_seed(0)
+    with torch.device(device):
+        model = Wan2_2Transformer3DModel_FlexAM(**kw)
+    model.randomize_zero_init(seed=0)
+    return model.to(torch.bfloat16)
+
+
+def time_kernel(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    s.record()                 # recorded on torch's current stream = the stream every flexam_* call launches on
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / iters
+
+
+def kernel_rooflines(eng, B, L, lc):
+    """Live per-launch timing of the hot kernels at this run's shapes, on the engine's own buffers."""
+    from flexam_amd import hip
+    d, f, nh, hd = eng.dim, eng.ffn, eng.nh, eng.hd
+    ws = eng._ws[(B, lc)]
+    p = eng.blocks[0]
+    qkv, ao, hbuf, ffn = ws["qkv"], ws["ao"], ws["h"], ws["ffn"]
+    M = B * lc
+    q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hd))
+    out = {}
+    if eng.sp_size == 1:
+        k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hd))
+        v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hd))
+    else:
+        kv = ws["kv_cat"]
+        k4, v4 = kv[:, :, 0:d].unflatten(2, (nh, hd)), kv[:, :, d:].unflatten(2, (nh, hd))
+    t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd)), iters=8)
+    out["attn_self"] = dict(flops=4.0 * B * lc * L * d, sec=t)
+    t = time_kernel(lambda: hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv))
+    out["gemm_qkv"] = dict(flops=2.0 * M * 3 * d * d, sec=t)
+    t = time_kernel(lambda: hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH))
+    out["gemm_ffn1_gelu"] = dict(flops=2.0 * M * f * d, sec=t)
+    xs = torch.zeros(M, d, device=qkv.device, dtype=torch.float32)
+    t = time_kernel(lambda: hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xs))
+    out["gemm_ffn2_residual"] = dict(flops=2.0 * M * d * f, sec=t)
+    t = time_kernel(lambda: hip.gemm_gate_residual(ao, p["wo"], p["bo"], xs))
+    out["gemm_oproj_residual"] = dict(flops=2.0 * M * d * d, sec=t)
+    for v in out.values():
+        v["tflops"] = v["flops"] / v["sec"] / 1e12
+    return out
+
+
+def cpu_baseline(L, cfg):
+    """fp32 oracle (oracle/dit.py: the restatement pinned to the reference by golden vectors) on the
+    host cores: ONE WanAttentionBlock forward on ONE sample at the full token count = 1/60 of a step."""
+    from oracle import cases as C
+    from oracle import dit as O
+    d, f, nh, T = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"], cfg["text_len"]
+    one = dict(cfg, num_layers=1)
+    shapes = {k: v for k, v in O.dit_param_shapes(one).items() if k.startswith("blocks.0.")}
+    sd = O.seeded_state_dict(shapes, 3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, L, d, generator=g)
+    e0 = torch.randn(1, 6, d, generator=g) * 0.1
+    dens0 = torch.randn(1, 2, d, generator=g) * 0.1
+    ctx = torch.randn(1, T, d, generator=g)
+    grid = (26, 16, 28) if L == 11648 else (1, 1, L)
+    ang = O.rope_angles(1024, d // nh)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.block_forward(sd, "blocks.0", x, e0, dens0, grid, ang, ctx, nh)
+    sec = time.perf_counter() - t0
+    steps_per_sec = 1.0 / (sec * 60.0)
+    return dict(value=steps_per_sec, unit="denoise-steps/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 of the 60 block-forwards of one step (oracle/dit.py block_forward, fp32, L={L}, d={d}) "
+                       f"took {sec:.1f} s; value = 1/(60 x that), extrapolated", block_seconds=sec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=97)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=896)
+    ap.add_argument("--layers", type=int, default=30, help="debug only: fewer layers makes the number INVALID")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from flexam_amd import Wan2_2FunControlPipeline_FlexAM
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    from flexam_amd.configs import WAN22_FUN_5B_FLEXAM
+    cfg = dict(WAN22_FUN_5B_FLEXAM, num_layers=args.layers)
+    model = build_model(cfg, device)
+    if world > 1:
+        model.enable_multi_gpus_inference()
+    pipe = Wan2_2FunControlPipeline_FlexAM(transformer=model)
+    inp = synthetic_inputs(args.frames, args.height, args.width, cfg["text_dim"])
+    cond = LatentConditioning(control_latents=inp["control"], additional_control=inp["additional"], masked_video_latents=inp["masked"],
+                              ref_latents=inp["ref"], mask_latents=inp["mask_latents"], mask=inp["mask"])
+    total_steps = 50
+    pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+    eng = model.engine()
+    L = eng.cond["L"]
+    B = 2
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        pipe.denoise_step(i % total_steps)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pipe.denoise_step((args.warmup + i) % total_steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    finite = bool(torch.isfinite(pipe._state["latents"]).all())
+
+    lc = L // world
+    kern = None if args.no_kernel_timing else kernel_rooflines(eng, B, L, lc)
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base = cpu_baseline(L, cfg)
+
+    if rank == 0:
+        steps_per_sec = args.steps / elapsed
+        blk = block_flops(L, cfg["dim"], cfg["ffn_dim"], cfg["text_len"])
+        step_block_flops = blk * B * cfg["num_layers"]
+        result = {
+            "metric": "denoise-steps/sec", "value": steps_per_sec, "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Wan2.2-Fun-5B-FLEXAM DiT denoise step, {args.frames}x{args.height}x{args.width}, "
+                                   f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
+                                   f"random-init bf16 weights, synthetic conditioning (BASELINE configs[1])",
+                       "parallelism": f"sp{world} (token-chunk sequence parallel, RCCL K/V all-gather per block)" if world > 1 else "single GPU",
+                       "layers": cfg["num_layers"]},
+            "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
+            "dit_block_tflops": step_block_flops * steps_per_sec / 1e12,
+            "dit_block_mfma_frac": step_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "finite": finite,
+        }
+        if kern is not None:
+            a = kern["attn_self"]
+            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel (self-attention, head_dim 128)", "achieved": a["tflops"],
+                                  "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                                  "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"]}
+            result["kernels"] = {k: {"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1),
+                                     "frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} for k, v in kern.items()}
+        if base is not None:
+            result["cpu_baseline"] = base
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

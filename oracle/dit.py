@@ -86,6 +86,9 @@ def layer_norm(x: Tensor, eps: float, weight: Optional[Tensor] = None, bias: Opt
 def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
     """ATT.py:174-233 semantics on the path: plain softmax(q k^T / sqrt(D)) v, non-causal, no
     mask (k_lens == L in self-attention, None in cross-attention).  Layout [B, L, N, D]."""
+    if q.shape[2] > 1 and q.shape[0] * q.shape[1] * k.shape[1] * q.shape[2] > (1 << 28):
+        # same arithmetic one head at a time: bounds the score matrix (13 GB at L = 11648, 24 heads)
+        return torch.cat([attention(q[:, :, i:i + 1], k[:, :, i:i + 1], v[:, :, i:i + 1]) for i in range(q.shape[2])], dim=2)
     q, k, v = (u.transpose(1, 2) for u in (q, k, v))
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
     return torch.matmul(s.softmax(dim=-1), v).transpose(1, 2)
