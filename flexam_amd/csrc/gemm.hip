@@ -231,7 +231,7 @@ extern "C" int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64
 extern "C" int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                               float* X, int64_t ldx, const float* gate, int64_t gate_ld,
                                               const int32_t* gate_row, int64_t rows_per_batch, int64_t M, int64_t N,
-                                              int64_t K, void* stream) {
+                                              int64_t K, const int64_t* a_koff, void* stream) {
   FX_REQUIRE(A && W && X, FLEXAM_E_ARG, "gemm_gate_residual: null pointer");
   FX_REQUIRE(M > 0 && N > 0 && K > 0, FLEXAM_E_SHAPE, "gemm_gate_residual: empty problem");
   FX_REQUIRE(K % BK == 0 && N % 4 == 0 && ldx % 4 == 0, FLEXAM_E_SHAPE, "gemm_gate_residual: K%%64, N%%4, ldx%%4 required");
@@ -243,5 +243,5 @@ extern "C" int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const 
   p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
   p.X = X; p.ldx = ldx; p.gate = gate; p.gate_ld = gate_ld; p.gate_row = gate_row;
   p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-  return launch<EPI_GATE_RESIDUAL, bf16>(p, nullptr, (hipStream_t)stream);
+  return launch<EPI_GATE_RESIDUAL, bf16>(p, a_koff, (hipStream_t)stream);
 }

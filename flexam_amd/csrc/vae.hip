@@ -1,0 +1,254 @@
+// flexam_amd/csrc/vae.hip -- HBM-bound kernels of the Wan2.2 3D-VAE decoder
+// (FlexAM/models/wan_vae3_8.py: RMS_norm :50-64, Resample :76-160, AttentionBlock :243-282,
+// DupUp3D :375-417, unpatchify :304-318).  The convolutions themselves are flexam_gemm_bf16 over
+// padded channels-last images (conv_cl.hip header); these kernels move activations between
+//   "rows"   : matrices [(t, hp, wp), ld] indexed by PADDED position (GEMM outputs; border rows
+//              hold garbage and are never read), fp32 or bf16, and
+//   "images" : zero-bordered bf16 [frames, H+2, W+2, Cp] conv inputs (with 2 leading history
+//              frames for the causal 3x3x3 convs),
+// one pass each, channel-contiguous so a wave reads/writes whole 128-byte lines.
+#include "common.h"
+#include "flexam_hip.h"
+
+namespace {
+
+inline int grid_for(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+template <typename T>
+__device__ __forceinline__ float ld(const T* p) { return (float)*p; }
+
+// ------------------------------------------------------------------------------------------
+// prep: rows -> image / matrix, one wave per interior position.
+//   mode 0: cast;  mode 1: F.normalize(x, channel) * sqrt(C) * gamma;  mode 2: mode 1 + SiLU.
+//   dst position: compact (t*H + h)*W + w  if dst_compact else padded ((t + t0)*Hp + h+1)*Wp + w+1
+// ------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void vae_prep_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
+                                                       const float* __restrict__ gamma, int mode, bf16* __restrict__ dst, int Cp,
+                                                       int t0, int dst_compact) {
+  const int lane = threadIdx.x & 63;
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t npos = (int64_t)T * H * W;
+  for (int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pos < npos; pos += (int64_t)gridDim.x * 4) {
+    const int w = (int)(pos % W);
+    int64_t r = pos / W;
+    const int h = (int)(r % H);
+    const int t = (int)(r / H);
+    const TI* s = src + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * lds_;
+    bf16* d = dst + (dst_compact ? pos : (((int64_t)(t + t0) * Hp + h + 1) * Wp + w + 1)) * Cp;
+    float scale = 1.f;
+    if (mode != 0) {
+      float q = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float v = ld(s + c);
+        q += v * v;
+      }
+      q = wave_sum(q);
+      scale = sqrtf((float)C) / fmaxf(sqrtf(q), 1e-12f);
+    }
+    for (int c = lane; c < C; c += 64) {
+      float v = ld(s + c);
+      if (mode != 0) v = v * scale * gamma[c];
+      if (mode == 2) v = silu(v);
+      d[c] = f2bf(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// nearest-exact 2x spatial upsample of rows -> padded image; optional temporal de-interleave:
+// dst frame t' = 2t + s takes channels [s*C, (s+1)*C) of src frame t (Resample upsample3d,
+// wan_vae3_8.py:153-156).
+// ------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
+                                                         int interleave, bf16* __restrict__ dst, int Cp) {
+  const int To = interleave ? 2 * T : T, Ho = 2 * H, Wo = 2 * W;
+  const int Hp = H + 2, Wp = W + 2, Hop = Ho + 2, Wop = Wo + 2;
+  const int cvec = C >> 2;
+  const int64_t total = (int64_t)To * Ho * Wo * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cvec) * 4;
+    int64_t r = i / cvec;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int to = (int)(r / Ho);
+    const int t = interleave ? (to >> 1) : to;
+    const int coff = interleave ? (to & 1) * C : 0;
+    const TI* s = src + (((int64_t)t * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * lds_ + coff + c;
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(ld(s + j));
+    *(bf16x4*)(dst + (((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * Cp + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// x_main[(t', h', w'), co] += x_in[(t, h, w), (co*ft*4 + st*4 + sh*2 + sw) / repeats]     (DupUp3D)
+//   t' = t*ft + st - drop  (drop = ft-1 on the first chunk: wan_vae3_8.py:415-416)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dupup_add_kernel(float* __restrict__ xm, int64_t ldm, int Co, int To, int Ho, int Wo,
+                                                        const float* __restrict__ xin, int64_t ldi, int Ci, int ft, int drop) {
+  const int H = Ho / 2, W = Wo / 2;
+  const int Hp = H + 2, Wp = W + 2, Hop = Ho + 2, Wop = Wo + 2;
+  const int repeats = Co * ft * 4 / Ci;
+  const int64_t total = (int64_t)To * Ho * Wo * Co;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Co);
+    int64_t r = i / Co;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int to = (int)(r / Ho);
+    const int tt = to + drop;
+    const int t = tt / ft, st = tt - t * ft;
+    const int ci = ((co * ft + st) * 4 + (ho & 1) * 2 + (wo & 1)) / repeats;
+    const float v = xin[(((int64_t)t * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldi + ci];
+    xm[(((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + co] += v;
+  }
+}
+
+// row softmax(scale * s) fp32 -> bf16 (zero padded to ldo columns); one 256-thread block per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds_, int N, float scale,
+                                                           bf16* __restrict__ out, int64_t ldo, int Npad) {
+  __shared__ float red[8];
+  const float* row = s + (int64_t)blockIdx.x * lds_;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) mx = fmaxf(mx, row[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) sum += __expf((row[i] - mx) * scale);
+  sum = block_sum<256>(sum, red);
+  const float inv = 1.f / sum;
+  bf16* orow = out + (int64_t)blockIdx.x * ldo;
+  for (int i = threadIdx.x; i < Npad; i += 256) orow[i] = f2bf(i < N ? __expf((row[i] - mx) * scale) * inv : 0.f);
+}
+
+// x[padded (t,h,w), c] += y[compact (t,h,w), c]
+__global__ __launch_bounds__(256) void scatter_add_kernel(float* __restrict__ x, int64_t ldx, const bf16* __restrict__ y, int64_t ldy,
+                                                          int C, int T, int H, int W) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t total = (int64_t)T * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t pos = i / C;
+    const int w = (int)(pos % W);
+    int64_t r = pos / W;
+    const int h = (int)(r % H);
+    const int t = (int)(r / H);
+    x[(((int64_t)t * Hp + h + 1) * Wp + w + 1) * ldx + c] += bf2f(y[pos * ldy + c]);
+  }
+}
+
+// rows [(t,hp,wp), ld] (12 channels = (c r q), wan_vae3_8.py:304-318) -> video[c][f0 + t][2h + q][2w + r], clamped
+__global__ __launch_bounds__(256) void vae_unpatchify_kernel(const float* __restrict__ src, int64_t lds_, int T, int H, int W,
+                                                             float* __restrict__ video, int Ftot, int f0, float lo, float hi) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t total = (int64_t)3 * T * (2 * H) * (2 * W);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % (2 * W));
+    int64_t r = i / (2 * W);
+    const int y = (int)(r % (2 * H));
+    r /= (2 * H);
+    const int t = (int)(r % T);
+    const int c = (int)(r / T);
+    const int ch = c * 4 + (x & 1) * 2 + (y & 1);
+    const float v = src[(((int64_t)t * Hp + (y >> 1) + 1) * Wp + (x >> 1) + 1) * lds_ + ch];
+    video[(((int64_t)c * Ftot + f0 + t) * (2 * H) + y) * (2 * W) + x] = fminf(fmaxf(v, lo), hi);
+  }
+}
+
+// z[c][t][h][w] * std[c] + mean[c] -> padded image interior (wan_vae3_8.py:823-828)
+__global__ __launch_bounds__(256) void pack_affine_kernel(const float* __restrict__ src, int C, int T, int H, int W,
+                                                          const float* __restrict__ mul, const float* __restrict__ add,
+                                                          bf16* __restrict__ dst, int Cp) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t total = (int64_t)T * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int t = (int)(r / H);
+    const float v = src[(((int64_t)c * T + t) * H + h) * W + w] * mul[c] + add[c];
+    dst[(((int64_t)t * Hp + h + 1) * Wp + w + 1) * Cp + c] = f2bf(v);
+  }
+}
+
+}  // namespace
+
+extern "C" int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, const float* gamma,
+                                  int mode, void* dst, int Cp, int t0, int dst_compact, void* stream) {
+  FX_REQUIRE(src && dst, FLEXAM_E_ARG, "vae_prep_cl: null pointer");
+  FX_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || gamma), FLEXAM_E_ARG, "vae_prep_cl: mode %d needs gamma", mode);
+  FX_REQUIRE(C > 0 && C <= Cp && C <= ld_src && T > 0 && H > 0 && W > 0, FLEXAM_E_SHAPE, "vae_prep_cl: bad shape");
+  const int64_t npos = (int64_t)T * H * W;
+  dim3 grid(grid_for(npos, 4)), block(256);
+  if (src_is_bf16)
+    hipLaunchKernelGGL(vae_prep_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact);
+  else
+    hipLaunchKernelGGL(vae_prep_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact);
+  return flexam_check_launch("flexam_vae_prep_cl");
+}
+
+extern "C" int flexam_upsample2x_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, int interleave,
+                                    void* dst, int Cp, void* stream) {
+  FX_REQUIRE(src && dst, FLEXAM_E_ARG, "upsample2x_cl: null pointer");
+  FX_REQUIRE(C % 4 == 0 && C <= Cp && Cp % 4 == 0, FLEXAM_E_SHAPE, "upsample2x_cl: C=%d must be a multiple of 4", C);
+  const int64_t total = (int64_t)(interleave ? 2 * T : T) * 4 * H * W * (C / 4);
+  if (src_is_bf16)
+    hipLaunchKernelGGL(upsample2x_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, interleave, (bf16*)dst, Cp);
+  else
+    hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, interleave, (bf16*)dst, Cp);
+  return flexam_check_launch("flexam_upsample2x_cl");
+}
+
+extern "C" int flexam_dupup_add_cl(float* x_main, int64_t ld_main, int Co, int To, int Ho, int Wo, const float* x_in, int64_t ld_in,
+                                   int Ci, int ft, int drop, void* stream) {
+  FX_REQUIRE(x_main && x_in, FLEXAM_E_ARG, "dupup_add_cl: null pointer");
+  FX_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0 && (ft == 1 || ft == 2) && (Co * ft * 4) % Ci == 0, FLEXAM_E_SHAPE, "dupup_add_cl: bad shape");
+  hipLaunchKernelGGL(dupup_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * Co, 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
+                     Co, To, Ho, Wo, x_in, ld_in, Ci, ft, drop);
+  return flexam_check_launch("flexam_dupup_add_cl");
+}
+
+extern "C" int flexam_softmax_rows(const float* s, int64_t ld_s, int64_t M, int N, float scale, void* out, int64_t ld_out, int Npad,
+                                   void* stream) {
+  FX_REQUIRE(s && out && M > 0 && N > 0 && Npad >= N && Npad <= ld_out, FLEXAM_E_ARG, "softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream, s, ld_s, N, scale, (bf16*)out, ld_out, Npad);
+  return flexam_check_launch("flexam_softmax_rows");
+}
+
+extern "C" int flexam_scatter_add_cl(float* x, int64_t ldx, const void* y, int64_t ldy, int C, int T, int H, int W, void* stream) {
+  FX_REQUIRE(x && y, FLEXAM_E_ARG, "scatter_add_cl: null pointer");
+  hipLaunchKernelGGL(scatter_add_kernel, dim3(grid_for((int64_t)T * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (const bf16*)y, ldy, C, T, H, W);
+  return flexam_check_launch("flexam_scatter_add_cl");
+}
+
+extern "C" int flexam_vae_unpatchify_clamp(const float* src, int64_t ld_src, int T, int H, int W, float* video, int Ftot, int f0,
+                                           float lo, float hi, void* stream) {
+  FX_REQUIRE(src && video && ld_src >= 12, FLEXAM_E_ARG, "vae_unpatchify_clamp: bad arguments");
+  FX_REQUIRE(f0 >= 0 && f0 + T <= Ftot, FLEXAM_E_SHAPE, "vae_unpatchify_clamp: frames %d+%d exceed %d", f0, T, Ftot);
+  hipLaunchKernelGGL(vae_unpatchify_kernel, dim3(grid_for((int64_t)12 * T * H * W, 256)), dim3(256), 0, (hipStream_t)stream, src, ld_src,
+                     T, H, W, video, Ftot, f0, lo, hi);
+  return flexam_check_launch("flexam_vae_unpatchify_clamp");
+}
+
+extern "C" int flexam_pack_affine_cl(const float* src, int C, int T, int H, int W, const float* mul, const float* add, void* dst, int Cp,
+                                     void* stream) {
+  FX_REQUIRE(src && mul && add && dst && C <= Cp, FLEXAM_E_ARG, "pack_affine_cl: bad arguments");
+  hipLaunchKernelGGL(pack_affine_kernel, dim3(grid_for((int64_t)T * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, src, C, T, H, W,
+                     mul, add, (bf16*)dst, Cp);
+  return flexam_check_launch("flexam_pack_affine_cl");
+}

@@ -1,0 +1,52 @@
+"""Sequence-parallel plumbing for the FlexAM DiT: the part of the reference that is *missing*
+(`FlexAM/dist` was swallowed by the reference's .gitignore; only its call sites exist:
+wan_transformer3d_FlexAM.py:22-24, 801-815, 919-920, 970-975, 1103-1104).
+
+Design: one process per GPU, contiguous token chunks per rank (L/N tokens; attention is
+full 3-D so chunks need not be frame aligned, RoPE rows are looked up by the *global* token index),
+weights replicated, every op token-local except self-attention, which needs all keys/values:
+one RCCL all-gather of the block's post-norm, post-RoPE K|V per block ([B, L/N, 2C] bf16 per rank --
+17.9 MB at N = 8), plus one all-gather of the head output per step.  On the xGMI full mesh an
+all-gather maps 1:1 onto the point-to-point links (each peer pushes its shard over its own link).
+
+These helpers are backend-agnostic torch.distributed code (RCCL on GPUs; the CPU tests run them
+under gloo with world_size 2)."""
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def chunk_bounds(seq_len: int, rank: int, world: int) -> Tuple[int, int]:
+    """[start, end) of this rank's token chunk.  The sequence must divide evenly (11648 = 8 * 1456)."""
+    if seq_len % world:
+        raise ValueError(f"sequence length {seq_len} is not divisible by the sequence-parallel size {world}")
+    lc = seq_len // world
+    return rank * lc, (rank + 1) * lc
+
+
+def all_gather_seq(local: torch.Tensor, group=None, out: torch.Tensor = None, scratch: torch.Tensor = None) -> torch.Tensor:
+    """local [B, Lc, X] on every rank -> [B, N*Lc, X] with rank r's rows at [r*Lc, (r+1)*Lc)."""
+    world = dist.get_world_size(group)
+    b, lc, x = local.shape
+    if scratch is None:
+        scratch = torch.empty(world * b, lc, x, device=local.device, dtype=local.dtype)
+    dist.all_gather_into_tensor(scratch.view(world * b, lc, x), local.contiguous(), group=group)   # rank-major concat on dim 0
+    if out is None:
+        out = torch.empty(b, world * lc, x, device=local.device, dtype=local.dtype)
+    out.view(b, world, lc, x).copy_(scratch.view(world, b, lc, x).transpose(0, 1))
+    return out
+
+
+def shard_rows(full: torch.Tensor, batch: int, seq_len: int, rank: int, world: int) -> torch.Tensor:
+    """Per-token vector [B*L] (e.g. the AdaLN row index) -> this rank's [B*Lc] slice."""
+    s, e = chunk_bounds(seq_len, rank, world)
+    return full.view(batch, seq_len)[:, s:e].contiguous().view(-1)
+
+
+def get_sequence_parallel_world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def get_sequence_parallel_rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_initialized() else 0

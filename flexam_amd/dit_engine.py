@@ -299,7 +299,8 @@ class DiTEngine:
         hip.mod_table(self.hmod, e2, htab, rows_per_batch, 0b10, self.hmdens if hd_dens is not None else None, hd_dens,
                       0xF0 if hd_dens is not None else -1)
         if row_index is not None and sp > 1:
-            row_index = row_index.view(B, L)[:, tok0:tok0 + lc].contiguous().view(-1)
+            from .dist import shard_rows
+            row_index = shard_rows(row_index, B, L, rank, sp)
         rpb = lc                                   # used only when row_index is None: row = m // lc = b
 
         nh, hdim = self.nh, self.hd
@@ -340,8 +341,8 @@ class DiTEngine:
     # ------------------------------------------------------------------ sequence parallel
     def _gather_kv(self, qkv, B, lc):
         """All-gather of this block's post-norm, post-RoPE K and V over the sequence-parallel group
-        (RCCL over xGMI).  Returns K, V views [B, L, H, 128]."""
-        import torch.distributed as dist
+        (RCCL over xGMI, flexam_amd/dist.py).  Returns K, V views [B, L, H, 128]."""
+        from .dist import all_gather_seq
         d, sp = self.dim, self.sp_size
         ws = self._ws[(B, lc)]
         if "kv_send" not in ws:
@@ -349,9 +350,7 @@ class DiTEngine:
             ws["kv_full"] = torch.empty(sp, B, lc, 2 * d, device=self.device, dtype=BF16)
             ws["kv_cat"] = torch.empty(B, sp * lc, 2 * d, device=self.device, dtype=BF16)
         ws["kv_send"].copy_(qkv.view(B, lc, 3 * d)[:, :, d:])
-        dist.all_gather_into_tensor(ws["kv_full"], ws["kv_send"], group=self.sp_group)
-        ws["kv_cat"].view(B, sp, lc, 2 * d).copy_(ws["kv_full"].transpose(0, 1))
-        kv = ws["kv_cat"]
+        kv = all_gather_seq(ws["kv_send"], self.sp_group, out=ws["kv_cat"], scratch=ws["kv_full"])
         return kv[:, :, 0:d].unflatten(2, (self.nh, self.hd)), kv[:, :, d:].unflatten(2, (self.nh, self.hd))
 
     def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
@@ -359,8 +358,5 @@ class DiTEngine:
         wan_transformer3d_FlexAM.py:1103-1104)."""
         if self.sp_size == 1:
             return head_local
-        import torch.distributed as dist
-        B, lc, n = head_local.shape
-        out = torch.empty(self.sp_size, B, lc, n, device=head_local.device, dtype=head_local.dtype)
-        dist.all_gather_into_tensor(out, head_local.contiguous(), group=self.sp_group)
-        return out.transpose(0, 1).reshape(B, self.sp_size * lc, n)
+        from .dist import all_gather_seq
+        return all_gather_seq(head_local, self.sp_group)

@@ -23,7 +23,7 @@ _SIGNATURES = {
     "flexam_last_error": ([], c_char_p),
     "flexam_device_check": ([], c_int),
     "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P], c_int),
-    "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P], c_int),
+    "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
     "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
@@ -37,6 +37,13 @@ _SIGNATURES = {
     "flexam_pack_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_unpack_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _P], c_int),
     "flexam_groupnorm_silu_cl": ([_P, _L, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _I, _P], c_int),
+    "flexam_vae_prep_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P], c_int),
+    "flexam_upsample2x_cl": ([_P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P], c_int),
+    "flexam_dupup_add_cl": ([_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _P], c_int),
+    "flexam_softmax_rows": ([_P, _L, _L, _I, _F, _P, _L, _I, _P], c_int),
+    "flexam_scatter_add_cl": ([_P, _L, _P, _L, _I, _I, _I, _I, _P], c_int),
+    "flexam_vae_unpatchify_clamp": ([_P, _L, _I, _I, _I, _P, _I, _I, _F, _F, _P], c_int),
+    "flexam_pack_affine_cl": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
 }
 
 _lib = None
@@ -119,17 +126,18 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=No
     return out
 
 
-def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0):
-    """x[M,N] (fp32, in place) += bf16(a @ w^T + bias) * gate[row]."""
-    M, K, lda = _rows(a)
-    N, wk, ldw = _rows(w)
-    xm, xn, ldx = _rows(x)
-    if wk != K or (xm, xn) != (M, N):
+def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0, a_koff=None):
+    """x[M,N] (fp32, in place) += bf16(a @ w^T + bias) * gate[row].  With a_koff `a` is a base view
+    (implicit conv) and M, K come from x and w."""
+    am, ak, lda = _rows(a)
+    N, K, ldw = _rows(w)
+    M, xn, ldx = _rows(x)
+    if (a_koff is None and (ak != K or am != M)) or xn != N:
         raise RuntimeError("gemm_gate_residual: shape mismatch")
     gate_ld = gate.stride(0) if gate is not None else 0
     _check(lib().flexam_gemm_bf16_gate_residual(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(x, F32), ldx,
                                                 _ptr(gate, F32), gate_ld, _ptr(gate_row, I32), rows_per_batch, M, N, K,
-                                                _stream()), "flexam_gemm_bf16_gate_residual")
+                                                _ptr(a_koff, I64), _stream()), "flexam_gemm_bf16_gate_residual")
     return x
 
 
@@ -277,4 +285,49 @@ def groupnorm_silu_cl(x, C, F, H, W, groups, gamma, beta, dst, residual=None, ep
     _check(lib().flexam_groupnorm_silu_cl(_ptr(x, F32), x.stride(0), C, F, H, W, groups, eps, _ptr(gamma, F32), _ptr(beta, F32),
                                           _ptr(stats, F32), _ptr(residual, BF16), residual.shape[-1] if residual is not None else 0,
                                           _ptr(dst, BF16), dst.shape[-1], _stream()), "flexam_groupnorm_silu_cl")
+    return dst
+
+
+# ----------------------------------------------------------------------------- VAE decoder helpers
+def vae_prep_cl(src, C, T, H, W, dst, mode=0, gamma=None, t0=0, compact=False):
+    """src rows [T*(H+2)*(W+2), ld] (fp32/bf16) -> dst image [*, H+2, W+2, Cp] (frame offset t0) or compact [T*H*W, Cp]."""
+    _check(lib().flexam_vae_prep_cl(_ptr(src), 1 if src.dtype == BF16 else 0, src.stride(0), C, T, H, W, _ptr(gamma, F32), mode,
+                                    _ptr(dst, BF16), dst.shape[-1], t0, 1 if compact else 0, _stream()), "flexam_vae_prep_cl")
+    return dst
+
+
+def upsample2x_cl(src, C, T, H, W, dst, interleave=False):
+    _check(lib().flexam_upsample2x_cl(_ptr(src), 1 if src.dtype == BF16 else 0, src.stride(0), C, T, H, W, 1 if interleave else 0,
+                                      _ptr(dst, BF16), dst.shape[-1], _stream()), "flexam_upsample2x_cl")
+    return dst
+
+
+def dupup_add_cl(x_main, Co, To, Ho, Wo, x_in, Ci, ft, drop):
+    _check(lib().flexam_dupup_add_cl(_ptr(x_main, F32), x_main.stride(0), Co, To, Ho, Wo, _ptr(x_in, F32), x_in.stride(0), Ci, ft, drop,
+                                     _stream()), "flexam_dupup_add_cl")
+    return x_main
+
+
+def softmax_rows(s, scale, out, n_valid):
+    M = s.shape[0]
+    _check(lib().flexam_softmax_rows(_ptr(s, F32), s.stride(0), M, n_valid, scale, _ptr(out, BF16), out.stride(0), out.shape[1], _stream()),
+           "flexam_softmax_rows")
+    return out
+
+
+def scatter_add_cl(x, y, C, T, H, W):
+    _check(lib().flexam_scatter_add_cl(_ptr(x, F32), x.stride(0), _ptr(y, BF16), y.stride(0), C, T, H, W, _stream()), "flexam_scatter_add_cl")
+    return x
+
+
+def vae_unpatchify_clamp(src, T, H, W, video, f0, lo=-1.0, hi=1.0):
+    _check(lib().flexam_vae_unpatchify_clamp(_ptr(src, F32), src.stride(0), T, H, W, _ptr(video, F32), video.shape[1], f0, lo, hi, _stream()),
+           "flexam_vae_unpatchify_clamp")
+    return video
+
+
+def pack_affine_cl(src, mul, add, dst):
+    C, T, H, W = src.shape
+    _check(lib().flexam_pack_affine_cl(_ptr(src.contiguous(), F32), C, T, H, W, _ptr(mul, F32), _ptr(add, F32), _ptr(dst, BF16),
+                                       dst.shape[-1], _stream()), "flexam_pack_affine_cl")
     return dst

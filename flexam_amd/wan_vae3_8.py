@@ -1,0 +1,381 @@
+"""MI355X drop-in for `AutoencoderKLWan3_8` (Wan2.2 3D-VAE, z = 48, 4x16x16) -- decode path.
+
+Reference: FlexAM/models/wan_vae3_8.py (:892-1079 wrapper, :739-870 chunked model, :621-728 decoder).
+State-dict keys are the reference's (`model.decoder...`, `model.conv2...`; a full Wan2.2_VAE.pth loads
+with strict=False exactly as VAE.py:1073-1077 does -- encoder keys are ignored until the encode path,
+the next scope row, lands).  `decode(z).sample` runs entirely in libflexam_hip.so:
+
+  * activations are channels-last; every causal 3x3x3 / 3x3 convolution is ONE flexam_gemm_bf16
+    launch over a zero-bordered bf16 image with a per-K-block tap-offset table (implicit GEMM, no
+    im2col), 27 taps x Cin/64 K-blocks, fp32 accumulate on MFMA;
+  * the chunk-causal cache of the reference (feat_cache/feat_idx, CACHE_T = 2) is a 2-frame history
+    kept at the front of each conv's input image and rolled after the conv -- same arithmetic, see
+    DESIGN.md "VAE chunk cache";
+  * RMS_norm + SiLU, nearest-2x upsample (+ frame de-interleave), DupUp3D shortcut, the middle
+    attention (head_dim = C, as three GEMMs + a row softmax) and unpatchify + clamp are one-pass
+    bandwidth kernels (csrc/vae.hip); the residual stream between blocks stays fp32.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .wan_transformer3d_FlexAM import ModelConfig
+
+BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
+
+# latent normalisation statistics of the Wan2.2 VAE (published constants; VAE.py:906-1010)
+LATENT_MEAN = [-0.2289, -0.0052, -0.1323, -0.2339, -0.2799, 0.0174, 0.1838, 0.1557, -0.1382, 0.0542, 0.2813, 0.0891,
+               0.1570, -0.0098, 0.0375, -0.1825, -0.2246, -0.1207, -0.0698, 0.5109, 0.2665, -0.2108, -0.2158, 0.2502,
+               -0.2055, -0.0322, 0.1109, 0.1567, -0.0729, 0.0899, -0.2799, -0.1230, -0.0313, -0.1649, 0.0117, 0.0723,
+               -0.2839, -0.2083, -0.0520, 0.3748, 0.0152, 0.1957, 0.1433, -0.2944, 0.3573, -0.0548, -0.1681, -0.0667]
+LATENT_STD = [0.4765, 1.0364, 0.4514, 1.1677, 0.5313, 0.4990, 0.4818, 0.5013, 0.8158, 1.0344, 0.5894, 1.0901,
+              0.6885, 0.6165, 0.8454, 0.4978, 0.5759, 0.3523, 0.7135, 0.6804, 0.5833, 1.4146, 0.8986, 0.5659,
+              0.7069, 0.5338, 0.4889, 0.4917, 0.4069, 0.4999, 0.6866, 0.4093, 0.5709, 0.6065, 0.6415, 0.4944,
+              0.5726, 1.2042, 0.5458, 1.6887, 0.3971, 1.0600, 0.3943, 0.5537, 0.5444, 0.4089, 0.7468, 0.7744]
+
+
+class DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def decoder_param_shapes(z_dim=48, dec_dim=256, dim_mult=(1, 2, 4, 4), temporal_up=(True, True, False)) -> Dict[str, tuple]:
+    """Parameter inventory of conv2 + Decoder3d under the reference's names (VAE.py:621-675)."""
+    dims = [dec_dim * m for m in [dim_mult[-1]] + list(dim_mult[::-1])]
+    s: Dict[str, tuple] = {}
+
+    def conv(name, co, ci, k):
+        s[name + ".weight"], s[name + ".bias"] = (co, ci, *k), (co,)
+
+    def res(name, ci, co):
+        s[name + ".residual.0.gamma"] = (ci, 1, 1, 1)
+        conv(name + ".residual.2", co, ci, (3, 3, 3))
+        s[name + ".residual.3.gamma"] = (co, 1, 1, 1)
+        conv(name + ".residual.6", co, co, (3, 3, 3))
+        if ci != co:
+            conv(name + ".shortcut", co, ci, (1, 1, 1))
+    conv("conv2", z_dim, z_dim, (1, 1, 1))
+    conv("decoder.conv1", dims[0], z_dim, (3, 3, 3))
+    res("decoder.middle.0", dims[0], dims[0])
+    s["decoder.middle.1.norm.gamma"] = (dims[0], 1, 1)
+    conv("decoder.middle.1.to_qkv", dims[0] * 3, dims[0], (1, 1))
+    conv("decoder.middle.1.proj", dims[0], dims[0], (1, 1))
+    res("decoder.middle.2", dims[0], dims[0])
+    for i, (ci, co) in enumerate(zip(dims[:-1], dims[1:])):
+        c_in = ci
+        for j in range(3):
+            res(f"decoder.upsamples.{i}.upsamples.{j}", c_in, co)
+            c_in = co
+        if i != len(dims) - 2:
+            conv(f"decoder.upsamples.{i}.upsamples.3.resample.1", co, co, (3, 3))
+            if temporal_up[i]:
+                conv(f"decoder.upsamples.{i}.upsamples.3.time_conv", co * 2, co, (3, 1, 1))
+    s["decoder.head.0.gamma"] = (dims[-1], 1, 1, 1)
+    conv("decoder.head.2", 12, dims[-1], (3, 3, 3))
+    return s
+
+
+class _ParamTree(nn.Module):
+    """Holds parameters under dotted names ('decoder.middle.0.residual.2.weight') as nested modules."""
+
+    def add(self, dotted: str, shape):
+        head, _, rest = dotted.partition(".")
+        if not rest:
+            self.register_parameter(head, nn.Parameter(torch.zeros(shape)))
+            return
+        if head not in self._modules:
+            self.add_module(head, _ParamTree())
+        self._modules[head].add(rest, shape)
+
+
+class _Conv:
+    """One (causal) convolution as an implicit GEMM: packed bf16 weight [Cout, taps*Cp], fp32 bias,
+    a padded channels-last input image with `hist` leading history frames, tap-offset tables."""
+
+    def __init__(self, weight, bias, device, t_cap: int):
+        w = weight.detach().to(device, F32)
+        if w.dim() == 4:
+            w = w.unsqueeze(2)
+        co, ci, kt, kh, kw = w.shape
+        self.co, self.ci, self.kt, self.kh, self.kw = co, ci, kt, kh, kw
+        self.cp = _round_up(ci, 64)
+        wp = torch.zeros(co, kt, kh, kw, self.cp, device=device, dtype=F32)
+        wp[..., :ci] = w.permute(0, 2, 3, 4, 1)
+        self.weight = wp.reshape(co, kt * kh * kw * self.cp).to(BF16).contiguous()
+        self.bias = bias.detach().to(device, F32).contiguous()
+        self.hist = kt - 1
+        self.t_cap = t_cap
+        self.device = device
+        self.shape = None
+        self._koff = None
+
+    def image(self, h, w):
+        if self.shape != (h, w):
+            hp, wp = h + 2, w + 2
+            frames = self.hist + self.t_cap
+            guard = (wp + 1) * self.cp
+            self.buf = torch.zeros(guard * 2 + frames * hp * wp * self.cp, device=self.device, dtype=BF16)
+            self.img = self.buf[guard:guard + frames * hp * wp * self.cp].view(frames, hp, wp, self.cp)
+            offs = []
+            for dt in range(self.kt):
+                for dh in range(self.kh):
+                    for dw in range(self.kw):
+                        base = (dt * hp * wp + (dh - self.kh // 2) * wp + (dw - self.kw // 2)) * self.cp
+                        offs += [base + cb * 64 for cb in range(self.cp // 64)]
+            self._koff = torch.tensor(offs, dtype=I64, device=self.device)
+            self.shape = (h, w)
+        return self.img
+
+    def reset(self):
+        if self.shape is not None and self.hist:
+            self.img[:self.hist].zero_()
+
+    def run(self, t, h, w, out_dtype=F32, residual_into=None):
+        """Convolve the `t` current frames (image frames hist..hist+t); then roll the history."""
+        rows = t * (h + 2) * (w + 2)
+        a = self.img.view(-1, self.cp)
+        if residual_into is not None:
+            out = hip.gemm_gate_residual(a, self.weight, self.bias, residual_into, a_koff=self._koff)
+        else:
+            out = hip.gemm(a, self.weight, self.bias, a_koff=self._koff, m=rows, k=self.weight.shape[1], out_dtype=out_dtype)
+        if self.hist:
+            src = self.img[t:t + self.hist]
+            self.img[:self.hist].copy_(src.clone() if t < self.hist else src)
+        return out
+
+
+class _DecoderEngine:
+    def __init__(self, vae):
+        sd = {k: v for k, v in vae.model.state_dict().items()}
+        self.device = dev = next(vae.model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("flexam_amd: the VAE decoder runs only on a GPU through libflexam_hip.so (no CPU fallback)")
+        hip.device_check()
+        cfg = vae._arch
+        self.z_dim, self.temporal_up = cfg["z_dim"], tuple(cfg["temporal_up"])
+        dims = [cfg["dec_dim"] * m for m in [cfg["dim_mult"][-1]] + list(cfg["dim_mult"][::-1])]
+        self.dims = dims
+        f32 = lambda t: t.detach().to(dev, F32).reshape(-1).contiguous()
+        tmul = [1]
+        for up in self.temporal_up:
+            tmul.append(tmul[-1] * (2 if up else 1))                       # frames per chunk entering stage i
+
+        def conv(name, t_cap=1):
+            return _Conv(sd[name + ".weight"], sd[name + ".bias"], dev, t_cap)
+
+        def res(name, t_cap):
+            d = dict(g0=f32(sd[name + ".residual.0.gamma"]), c1=conv(name + ".residual.2", t_cap), g3=f32(sd[name + ".residual.3.gamma"]),
+                     c2=conv(name + ".residual.6", t_cap))
+            d["short"] = conv(name + ".shortcut", t_cap) if (name + ".shortcut.weight") in sd else None
+            return d
+        self.conv2 = conv("conv2")
+        self.conv1 = conv("decoder.conv1")
+        self.mid = [res("decoder.middle.0", 1), None, res("decoder.middle.2", 1)]
+        c = dims[0]
+        wqkv = sd["decoder.middle.1.to_qkv.weight"].detach().to(dev, F32).reshape(3 * c, c)
+        self.attn = dict(gamma=f32(sd["decoder.middle.1.norm.gamma"]), wqkv=wqkv.to(BF16).contiguous(),
+                         bqkv=f32(sd["decoder.middle.1.to_qkv.bias"]), wv=wqkv[2 * c:].to(BF16).contiguous(),
+                         bv=f32(sd["decoder.middle.1.to_qkv.bias"])[2 * c:].contiguous(),
+                         wproj=sd["decoder.middle.1.proj.weight"].detach().to(dev, BF16).reshape(c, c).contiguous(),
+                         bproj=f32(sd["decoder.middle.1.proj.bias"]))
+        self.stages = []
+        n_stage = len(dims) - 1
+        for i in range(n_stage):
+            p = f"decoder.upsamples.{i}.upsamples"
+            st = dict(res=[res(f"{p}.{j}", tmul[i]) for j in range(3)], up=i != n_stage - 1, cout=dims[i + 1])
+            if st["up"]:
+                st["temporal"] = bool(self.temporal_up[i])
+                st["resample"] = conv(f"{p}.3.resample.1", tmul[i] * (2 if st["temporal"] else 1))
+                st["time_conv"] = conv(f"{p}.3.time_conv", tmul[i]) if st["temporal"] else None
+            self.stages.append(st)
+        self.head_gamma = f32(sd["decoder.head.0.gamma"])
+        self.head_conv = conv("decoder.head.2", tmul[-1])
+        self.mean = torch.tensor(vae.latent_mean, device=dev, dtype=F32)
+        self.std = torch.tensor(vae.latent_std, device=dev, dtype=F32)
+        self._scratch = {}
+
+    def _all_convs(self):
+        out = [self.conv1, self.head_conv]
+        blocks = [self.mid[0], self.mid[2]] + [r for st in self.stages for r in st["res"]]
+        for r in blocks:
+            out += [r["c1"], r["c2"]]
+        for st in self.stages:
+            if st["up"] and st["time_conv"] is not None:
+                out.append(st["time_conv"])
+        return out
+
+    def _plain_image(self, key, frames, h, w, cp):
+        k = (key, frames, h, w, cp)
+        if k not in self._scratch:
+            self._scratch[k] = torch.zeros(frames, h + 2, w + 2, cp, device=self.device, dtype=BF16)
+        return self._scratch[k]
+
+    # ------------------------------------------------------------------ blocks
+    def _res(self, r, x, t, h, w):
+        """ResidualBlock (VAE.py:198-240) on rows x [t*(h+2)*(w+2), Cin] fp32 -> [.., Cout] fp32."""
+        c1, c2 = r["c1"], r["c2"]
+        hip.vae_prep_cl(x, c1.ci, t, h, w, c1.image(h, w), mode=2, gamma=r["g0"], t0=c1.hist)
+        t1 = c1.run(t, h, w, out_dtype=BF16)
+        hip.vae_prep_cl(t1, c2.ci, t, h, w, c2.image(h, w), mode=2, gamma=r["g3"], t0=c2.hist)
+        if r["short"] is not None:
+            sc = r["short"]
+            xb = self._plain_image(("short", sc.ci), t, h, w, sc.cp)
+            hip.vae_prep_cl(x, sc.ci, t, h, w, xb, mode=0)
+            x = hip.gemm(xb.view(-1, sc.cp), sc.weight, sc.bias, out_dtype=F32)
+        c2.run(t, h, w, residual_into=x)
+        return x
+
+    def _attention(self, x, t, h, w):
+        """AttentionBlock (VAE.py:243-282): per frame, one head with head_dim = C."""
+        a, c, dev = self.attn, self.dims[0], self.device
+        n = h * w
+        kp = _round_up(n, 64)
+        rows = (h + 2) * (w + 2)
+        for f in range(t):
+            xf = x[f * rows:(f + 1) * rows]
+            xn = torch.empty(n, c, device=dev, dtype=BF16)
+            hip.vae_prep_cl(xf, c, 1, h, w, xn, mode=1, gamma=a["gamma"], compact=True)
+            qk = hip.gemm(xn, a["wqkv"][:2 * c], a["bqkv"][:2 * c])                       # [n, 2c]
+            s = hip.gemm(qk[:, :c], qk[:, c:], out_dtype=F32)                              # q k^T  [n, n]
+            p = torch.empty(n, kp, device=dev, dtype=BF16)
+            hip.softmax_rows(s, c ** -0.5, p, n)
+            vt = torch.zeros(c, kp, device=dev, dtype=BF16)
+            hip.gemm(a["wv"], xn, out=vt[:, :n])                                           # V^T (bias folded below: rows of P sum to 1)
+            o = hip.gemm(p, vt, a["bv"])                                                   # [n, c]
+            y = hip.gemm(o, a["wproj"], a["bproj"])
+            hip.scatter_add_cl(xf, y, c, 1, h, w)
+        return x
+
+    def _chunk(self, src_rows, h, w, first, video, f0):
+        """Decoder3d.forward on one latent frame (VAE.py:677-728); writes 1 or 4 frames into `video`."""
+        t = 1
+        c1 = self.conv1
+        hip.vae_prep_cl(src_rows, c1.ci, t, h, w, c1.image(h, w), mode=0, t0=c1.hist)
+        x = c1.run(t, h, w, out_dtype=F32)
+        x = self._res(self.mid[0], x, t, h, w)
+        x = self._attention(x, t, h, w)
+        x = self._res(self.mid[2], x, t, h, w)
+        for st in self.stages:
+            x_in, cin = x, x.shape[1]
+            main = x.clone() if st["up"] else x
+            for r in st["res"]:
+                main = self._res(r, main, t, h, w)
+            if not st["up"]:
+                x = main
+                continue
+            co = st["cout"]
+            rs = st["resample"]
+            if st["temporal"] and not first:
+                tc = st["time_conv"]
+                hip.vae_prep_cl(main, co, t, h, w, tc.image(h, w), mode=0, t0=tc.hist)
+                y = tc.run(t, h, w, out_dtype=BF16)                                        # [rows, 2*co]
+                t2 = 2 * t
+                hip.upsample2x_cl(y, co, t, h, w, rs.image(2 * h, 2 * w), interleave=True)
+            else:
+                t2 = t
+                hip.upsample2x_cl(main, co, t, h, w, rs.image(2 * h, 2 * w), interleave=False)
+            out = rs.run(t2, 2 * h, 2 * w, out_dtype=F32)
+            ft = 2 if st["temporal"] else 1
+            hip.dupup_add_cl(out, co, t2, 2 * h, 2 * w, x_in, cin, ft, (ft - 1) if first else 0)
+            x, t, h, w = out, t2, 2 * h, 2 * w
+        hc = self.head_conv
+        hip.vae_prep_cl(x, hc.ci, t, h, w, hc.image(h, w), mode=2, gamma=self.head_gamma, t0=hc.hist)
+        y = hc.run(t, h, w, out_dtype=F32)                                                 # [rows, 12]
+        hip.vae_unpatchify_clamp(y, t, h, w, video, f0)
+        return t
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """z [zc, T, H, W] -> video [3, 1 + 4(T-1), 16H, 16W] fp32 in [-1, 1]."""
+        zc, tz, h, w = z.shape
+        for c in self._all_convs():
+            c.reset()
+        zi = self._plain_image("z", tz, h, w, self.conv2.cp)
+        hip.pack_affine_cl(z.to(self.device, F32), self.std, self.mean, zi)                # z / (1/std) + mean
+        x0 = hip.gemm(zi.view(-1, self.conv2.cp), self.conv2.weight, self.conv2.bias, out_dtype=F32)
+        rows = (h + 2) * (w + 2)
+        scale = 2 ** (len(self.stages) - 1)
+        tfac = 2 ** sum(self.temporal_up)
+        frames = 1 + tfac * (tz - 1)
+        video = torch.empty(3, frames, h * scale * 2, w * scale * 2, device=self.device, dtype=F32)
+        f0 = 0
+        for i in range(tz):
+            f0 += self._chunk(x0[i * rows:(i + 1) * rows], h, w, i == 0, video, f0)
+        return video
+
+
+class AutoencoderKLWan3_8(nn.Module):
+    def __init__(self, latent_channels=48, c_dim=160, vae_pth=None, dim_mult=[1, 2, 4, 4], temperal_downsample=[False, True, True],
+                 temporal_compression_ratio=4, spatial_compression_ratio=8, dec_dim=256):
+        super().__init__()
+        self.config = ModelConfig(latent_channels=latent_channels, c_dim=c_dim, vae_pth=vae_pth, dim_mult=list(dim_mult),
+                                  temperal_downsample=list(temperal_downsample), temporal_compression_ratio=temporal_compression_ratio,
+                                  spatial_compression_ratio=spatial_compression_ratio)
+        self.latent_channels = latent_channels
+        self.temporal_compression_ratio = temporal_compression_ratio
+        self.spatial_compression_ratio = spatial_compression_ratio
+        self.latent_mean, self.latent_std = LATENT_MEAN[:latent_channels], LATENT_STD[:latent_channels]
+        if latent_channels != len(LATENT_MEAN):
+            self.latent_mean, self.latent_std = [0.0] * latent_channels, [1.0] * latent_channels
+        temporal_up = list(temperal_downsample)[::-1]
+        self._arch = dict(z_dim=latent_channels, dec_dim=dec_dim, dim_mult=tuple(dim_mult), temporal_up=tuple(temporal_up))
+        self.model = _ParamTree()
+        for name, shape in decoder_param_shapes(latent_channels, dec_dim, tuple(dim_mult), tuple(temporal_up)).items():
+            self.model.add(name, shape)
+        self.supports_encode = False
+        self._engine: Optional[_DecoderEngine] = None
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+    @property
+    def dtype(self):
+        return next(self.model.parameters()).dtype
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    def engine(self) -> _DecoderEngine:
+        if self._engine is None:
+            self._engine = _DecoderEngine(self)
+        return self._engine
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        """VAE.py:1041-1056: per sample chunked decode, clamp(-1, 1)."""
+        eng = self.engine()
+        out = torch.stack([eng.decode(u) for u in z])
+        if z.dtype == BF16:
+            out = out.to(BF16)
+        return DecoderOutput(out) if return_dict else (out,)
+
+    def encode(self, x, return_dict: bool = True):
+        raise NotImplementedError("AutoencoderKLWan3_8.encode is the next scope row (SURVEY 8f1); this round covers decode")
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, additional_kwargs={}):
+        """VAE.py:1059-1079: raw Wan2.2_VAE.pth keys are prefixed with 'model.'; strict=False."""
+        import inspect
+        allowed = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        model = cls(**{k: v for k, v in additional_kwargs.items() if k in allowed})
+        if pretrained_model_path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            state = load_file(pretrained_model_path)
+        else:
+            state = torch.load(pretrained_model_path, map_location="cpu")
+        m, u = model.load_state_dict({"model." + k: v for k, v in state.items()}, strict=False)
+        print(f"### missing keys: {len(m)}; \n### unexpected keys: {len(u)};")
+        return model

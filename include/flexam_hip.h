@@ -50,10 +50,12 @@ int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, con
 /* X[m,n] += bf16(A.W^T + bias)[m,n] * gate[row(m), n]   (fp32 residual stream updated in place)
  * row(m) = gate_row[m] if gate_row else m / rows_per_batch; gate == NULL means gate = 1.
  * Replaces Linear + `x = x + y * e[2]` / `x + cross_attn(...)` / `x + y * e[5]`:
- * FlexAM/models/wan_transformer3d_FlexAM.py:261+456, 370+461, 416+468. */
+ * FlexAM/models/wan_transformer3d_FlexAM.py:261+456, 370+461, 416+468; with a_koff (see flexam_gemm_bf16)
+ * also the second conv + skip of the VAE ResidualBlock, FlexAM/models/wan_vae3_8.py:213,240. */
 int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* X,
                                    int64_t ldx, const float* gate, int64_t gate_ld, const int32_t* gate_row,
-                                   int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, void* stream);
+                                   int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, const int64_t* a_koff,
+                                   void* stream);
 
 /* Flash attention forward, head_dim 128, non-causal, keys [0, Lk): o = softmax(q k^T * scale) v.
  * q/k/v/o are [B, L, H, 128] views given by batch stride `*_bs` and row stride `*_rs` (elements);
@@ -132,6 +134,29 @@ int flexam_pack_cl(const void* src, int src_is_bf16, int C, int F, int H, int W,
 int flexam_unpack_cl(const void* src, int src_is_bf16, int64_t ld, int C, int F, int H, int W, float* dst, void* stream);
 int flexam_groupnorm_silu_cl(const float* x, int64_t ld, int C, int F, int H, int W, int groups, float eps, const float* gamma,
                              const float* beta, float* stats, const void* residual, int res_cp, void* dst, int Cp, void* stream);
+
+/* Wan2.2 3D-VAE decoder helpers (FlexAM/models/wan_vae3_8.py).  "rows" = [(t,hp,wp), ld] matrices
+ * indexed by PADDED position (GEMM outputs), "image" = zero-bordered bf16 [frames,H+2,W+2,Cp].
+ * vae_prep_cl: interior rows -> image (frame offset t0) or compact matrix; mode 0 cast, 1 RMS_norm
+ *   (F.normalize over channels * sqrt(C) * gamma, :50-64), 2 RMS_norm + SiLU (:206-212, :671-673).
+ * upsample2x_cl: nearest-exact 2x (+ frame de-interleave of the time_conv output, :153-156) -> image.
+ * dupup_add_cl: x_main += DupUp3D(x_in) (:375-417), drop = leading frames cropped on the first chunk.
+ * softmax_rows: bf16 softmax(scale * s) rows, zero padded to Npad columns (AttentionBlock :272).
+ * scatter_add_cl: x[padded rows] += y[compact rows] (AttentionBlock residual :282).
+ * vae_unpatchify_clamp: 12-channel rows -> video[3][Ftot][2H][2W] at frame f0, clamped (:304-318, :1043).
+ * pack_affine_cl: z [C,T,H,W] * mul[c] + add[c] -> image (latent de-normalisation, :823-828). */
+int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, const float* gamma, int mode,
+                       void* dst, int Cp, int t0, int dst_compact, void* stream);
+int flexam_upsample2x_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, int interleave, void* dst,
+                         int Cp, void* stream);
+int flexam_dupup_add_cl(float* x_main, int64_t ld_main, int Co, int To, int Ho, int Wo, const float* x_in, int64_t ld_in, int Ci,
+                        int ft, int drop, void* stream);
+int flexam_softmax_rows(const float* s, int64_t ld_s, int64_t M, int N, float scale, void* out, int64_t ld_out, int Npad, void* stream);
+int flexam_scatter_add_cl(float* x, int64_t ldx, const void* y, int64_t ldy, int C, int T, int H, int W, void* stream);
+int flexam_vae_unpatchify_clamp(const float* src, int64_t ld_src, int T, int H, int W, float* video, int Ftot, int f0, float lo,
+                                float hi, void* stream);
+int flexam_pack_affine_cl(const float* src, int C, int T, int H, int W, const float* mul, const float* add, void* dst, int Cp,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,114 @@
+"""CPU, world_size 2 under gloo: the sequence-parallel plumbing of flexam_amd/dist.py (same code
+path RCCL runs on GPUs).  Compute in these tests is the fp32 oracle; what is under test is the
+sharding: contiguous token chunks, K/V all-gather layout, global-token RoPE offsets, row-index
+sharding and the final token all-gather must reproduce the single-process result."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import dit as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run_world(fn, world=2):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, _free_port.port, fn, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    return [ret[r] for r in range(world)]
+
+
+@pytest.fixture(autouse=True)
+def _port():
+    _free_port.port = _free_port()
+
+
+def _gather_layout(rank, world):
+    from flexam_amd.dist import all_gather_seq, chunk_bounds, shard_rows
+    b, l, x = 2, 12, 5
+    full = torch.arange(b * l * x, dtype=torch.float32).view(b, l, x)
+    s, e = chunk_bounds(l, rank, world)
+    out = all_gather_seq(full[:, s:e].clone())
+    idx = torch.arange(b * l, dtype=torch.int32)
+    return bool(torch.equal(out, full)), shard_rows(idx, b, l, rank, world).tolist(), (s, e)
+
+
+def test_all_gather_seq_layout_and_row_sharding():
+    res = run_world(_gather_layout)
+    assert all(r[0] for r in res)
+    assert res[0][1] == list(range(0, 6)) + list(range(12, 18)) and res[1][1] == list(range(6, 12)) + list(range(18, 24))
+    assert res[0][2] == (0, 6) and res[1][2] == (6, 12)
+
+
+def _sp_self_attention(rank, world):
+    """Sequence-parallel self-attention = local q/k/v projection + RMSNorm + RoPE at GLOBAL token
+    positions, K/V all-gather, attention of the local queries against all keys, token all-gather."""
+    from flexam_amd.dist import all_gather_seq, chunk_bounds
+    from flexam_amd.rope import rope_tables
+    g = torch.Generator().manual_seed(0)
+    b, heads, d = 2, 2, 256
+    grid = (3, 2, 4)
+    l = 24 + 4                                              # 4 pass-through tokens
+    x = torch.randn(b, l, d, generator=g)
+    wq, wk, wv = (torch.randn(d, d, generator=g) / 16 for _ in range(3))
+    nq, nk = 1 + 0.1 * torch.randn(d, generator=g), 1 + 0.1 * torch.randn(d, generator=g)
+    ang = O.rope_angles(1024, 128)
+    q = O.rope_apply(O.rms_norm(x @ wq.t(), nq, 1e-6).view(b, l, heads, 128), grid, ang)
+    k = O.rope_apply(O.rms_norm(x @ wk.t(), nk, 1e-6).view(b, l, heads, 128), grid, ang)
+    v = (x @ wv.t()).view(b, l, heads, 128)
+    want = O.attention(q, k, v)
+    # sharded
+    s, e = chunk_bounds(l, rank, world)
+    cos, sin = rope_tables(grid, l, 128)
+
+    def rope_local(t):                                      # what flexam_rmsnorm_rope does with token_offset = s
+        t = t.view(b, e - s, heads, 64, 2)
+        c, sn = cos[s:e].view(1, e - s, 1, 64), sin[s:e].view(1, e - s, 1, 64)
+        re, im = t[..., 0], t[..., 1]
+        return torch.stack([re * c - im * sn, re * sn + im * c], dim=-1).reshape(b, e - s, heads, 128)
+    xl = x[:, s:e]
+    ql = rope_local(O.rms_norm(xl @ wq.t(), nq, 1e-6))
+    kl = rope_local(O.rms_norm(xl @ wk.t(), nk, 1e-6))
+    vl = (xl @ wv.t()).view(b, e - s, heads, 128)
+    kv = all_gather_seq(torch.cat([kl.flatten(2), vl.flatten(2)], dim=2))
+    kf, vf = kv[:, :, :d].unflatten(2, (heads, 128)), kv[:, :, d:].unflatten(2, (heads, 128))
+    out = all_gather_seq(O.attention(ql, kf, vf).flatten(2))
+    return float((out - want.flatten(2)).abs().max())
+
+
+def test_sequence_parallel_attention_matches_single_process():
+    errs = run_world(_sp_self_attention)
+    assert max(errs) < 5e-5, errs
+
+
+def test_chunk_bounds_requires_even_split():
+    from flexam_amd.dist import chunk_bounds
+    assert chunk_bounds(11648, 7, 8) == (10192, 11648)
+    with pytest.raises(ValueError):
+        chunk_bounds(11648, 0, 5)
