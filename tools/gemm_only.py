@@ -1,0 +1,22 @@
+"""Dev tool: run only the FFN1-shaped GEMM (and optionally attention) a few times, for rocprofv3 --pmc passes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from flexam_amd import hip as H
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+g = torch.Generator().manual_seed(0)
+M, d, f = 23296, 3072, 14336
+if what == "gemm":
+    a = (torch.randn(M, d, generator=g) * 0.5).to(BF).to(dev); w = (torch.randn(f, d, generator=g) * 0.5).to(BF).to(dev)
+    b = torch.randn(f, device=dev); out = torch.empty(M, f, dtype=BF, device=dev)
+    for _ in range(5):
+        H.gemm(a, w, b, out=out, epilogue=1)
+else:
+    L = 11648
+    qkv = (torch.randn(2, L, 3 * d, generator=g) * 0.5).to(BF).to(dev)
+    q, k, v = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (24, 128)) for i in range(3))
+    o = torch.empty(2, L, 24, 128, dtype=BF, device=dev)
+    for _ in range(3):
+        H.attn_fwd(q, k, v, out=o)
+torch.cuda.synchronize()
