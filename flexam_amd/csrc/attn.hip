@@ -17,6 +17,8 @@
 //    v_permlane32_swap, and the bf16-packed P registers are directly the B operand of
 //    O^T += V^T.P^T (accumulator-as-operand with the permuted-k order of the guide);
 //  * softmax scale and log2(e) are folded into one FMA in front of v_exp_f32.
+#include <type_traits>
+
 #include "common.h"
 #include "flexam_hip.h"
 
@@ -25,7 +27,6 @@ namespace {
 constexpr int QBLK = 256;     // query rows per workgroup
 constexpr int KVBLK = 64;     // keys per tile
 constexpr int HD = 128;       // head dim (fixed)
-constexpr int NT = 512;
 constexpr int KV_TILE_BYTES = KVBLK * HD * 2;   // 16 KiB
 
 struct AttnParams {
@@ -54,6 +55,18 @@ __device__ __forceinline__ int kv_off(int row, int ch) {
 __device__ __forceinline__ void half_swap(float& a, float& b) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+// 16-byte-per-lane LDS-DMA issued from inline asm: hipcc then does not know an LDS write is in flight and does
+// not put s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 intrinsic (it does for the builtin form,
+// which would drain the DMA in the middle of a tile).  Completion is tracked by hand: vmcnt(0) + s_barrier
+// at the top of each 64-key tile.  M0 (LDS base of the DMA) is saved / restored inside the statement.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
 __device__ __forceinline__ float pair_max(float x) {
   float a = x, b = x;
   half_swap(a, b);
@@ -65,14 +78,33 @@ __device__ __forceinline__ float pair_sum(float x) {
   return a + b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Structure: 8 waves x 32 query rows = 256 rows per workgroup, two waves per SIMD.
+//  * K/V tiles of 64 keys go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B/lane, swizzle applied to
+//    the source address) into a ring of 4 slots: no staging registers, no ds_write; ONE s_barrier per
+//    64 keys, and the DMA of tile t+2 is in flight for two tiles before the vmcnt(0) that precedes it;
+//  * the softmax pipeline runs on 32-key HALF tiles g.  Step g issues on the matrix pipe
+//        S(g+1) = K(g+1).Q^T          8 MFMA   (scores of the next half; S double-buffered: 32 VGPRs)
+//        O^T   += V(g-1)^T.P(g-1)^T   8 MFMA   (PV of the previous half; P kept packed in 8 VGPRs)
+//    in the same basic blocks as the VALU work of half g (row max, exp2, row sum, bf16 pack), so the
+//    wave overlaps its own MFMAs with its own softmax, and its SIMD partner fills the remaining gaps;
+//  * deferred rescale: the running max is raised (O, l and the pending P rescaled) only when a row max
+//    grew by more than 2^THR; P <= 2^THR is harmless in bf16 / fp32 floating point.
+// (A 4-wave x 64-row variant -- each K/V fragment feeding two MFMAs -- was tried in r1: hipcc cannot keep
+//  Q in the accumulator file and spills 150+ VGPRs; see DESIGN.md.)
+// ------------------------------------------------------------------------------------------------
+constexpr int NT = 512;
+constexpr int NSLOT = 4;
+constexpr float RESCALE_THR_LOG2 = 8.0f;
+
+template <int KIND>   // 0 = self-attention, 1 = short-context (text) attention: distinct profiler symbols
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ring: [4][K tile | V tile]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- workgroup -> (batch, head, q block); XCD-chunked so one XCD's L2 serves few heads at a time
   const int nwg = p.B * p.H * p.q_blocks;
   int bid = blockIdx.x;
   {
@@ -84,8 +116,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const int head = bh % p.H, b = bh / p.H;
 
   const bf16* qbase = p.q + (int64_t)b * p.q_bs + head * HD;
-  const bf16* kbase = p.k + (int64_t)b * p.k_bs + head * HD;
-  const bf16* vbase = p.v + (int64_t)b * p.v_bs + head * HD;
+  const char* kbase = (const char*)(p.k + (int64_t)b * p.k_bs + head * HD);
+  const char* vbase = (const char*)(p.v + (int64_t)b * p.v_bs + head * HD);
 
   // ---- Q fragment (B operand of S^T = K.Q^T): lane (r, h) holds Q[q0 + r][16*ds + 8h .. +7]
   const int q0 = qb * QBLK + wave * 32;
@@ -94,16 +126,13 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
   for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qbase + (int64_t)qrow * p.q_rs + ds * 16 + h * 8);
 
-  // ---- LDS read offsets
-  // K row read: row = 32*kt + r, chunk = 2*ds + h
+  // ---- LDS read offsets (dual-use swizzled image, see kv_off)
   int koff[8];
   {
     const int sw = ((r & 3) << 2) | ((r >> 2) & 3);
 #pragma unroll
     for (int ds = 0; ds < 8; ++ds) koff[ds] = 256 * r + 16 * ((2 * ds + h) ^ sw);
   }
-  // V transposed read: group g = lane>>4 (h = g>>1), i = lane&15, q_ = i>>2, p_ = i&3
-  // block rows r0 + q_ with r0 = 32kt + 16s + 8*half + 4h, columns 32dt + 16(g&1) + 4p_ ..
   int voff[2][4];
   {
     const int g = lane >> 4, i = lane & 15, q_ = i >> 2, p_ = i & 3;
@@ -112,130 +141,167 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
         voff[half][dt] = kv_off(8 * half + 4 * h + q_, 4 * dt + 2 * (g & 1) + (p_ >> 1)) + 8 * (p_ & 1);
-    // (kv_off's swizzle depends on row&3 = q_ and (row>>2)&3 = 2*half + h: unchanged by + 32kt + 16s)
   }
 
-  // ---- staging map: thread -> chunks id = tid + 512*i (i = 0, 1): row = id/16, ch = id%16
-  int st_row[2], st_lds[2];
+  // ---- LDS-DMA staging: piece id = tid + 512*i (i < 2) lands at LDS byte id*16 of the tile, i.e. row id/16,
+  //      slot id%16; it must carry chunk (slot ^ swizzle(row)) of that key row
+  const int ntiles = (p.Lk + KVBLK - 1) / KVBLK;
+  const unsigned k_step = (unsigned)(KVBLK * p.k_rs * 2), v_step = (unsigned)(KVBLK * p.v_rs * 2);
+  unsigned k_go[2], v_go[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int id = tid + NT * i;
-    st_row[i] = id >> 4;
-    st_lds[i] = kv_off(id >> 4, id & 15);
+    const int row = (tid + NT * i) >> 4;
+    const int ch = (tid & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    k_go[i] = (unsigned)(row * p.k_rs * 2 + ch * 16);
+    v_go[i] = (unsigned)(row * p.v_rs * 2 + ch * 16);
   }
-  const int st_col = (tid & 15) * 8;
-
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+  auto issue_tile = [&](int t) {
+    const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * (2 * KV_TILE_BYTES) + wave * 1024);   // wave-uniform
+    if ((t + 1) * KVBLK <= p.Lk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        lds_dma16(kbase + (k_go[i] + (unsigned)t * k_step), slot + i * 8192);
+        lds_dma16(vbase + (v_go[i] + (unsigned)t * v_step), slot + KV_TILE_BYTES + i * 8192);
+      }
+    } else {                                 // last, partial tile: rows past Lk re-read the last key (masked later)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (tid + NT * i) >> 4;
+        const int col = ((tid & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 16;
+        const int key = min(t * KVBLK + row, p.Lk - 1);
+        lds_dma16(kbase + ((int64_t)key * p.k_rs * 2 + col), slot + i * 8192);
+        lds_dma16(vbase + ((int64_t)key * p.v_rs * 2 + col), slot + KV_TILE_BYTES + i * 8192);
+      }
+    }
+  };
+  auto k_half = [&](int g) -> const char* { return smem + ((g >> 1) & (NSLOT - 1)) * (2 * KV_TILE_BYTES) + (g & 1) * 8192; };
+  auto v_half = [&](int g) -> const char* { return smem + ((g >> 1) & (NSLOT - 1)) * (2 * KV_TILE_BYTES) + KV_TILE_BYTES + (g & 1) * 8192; };
+  // ds0 == 0 starts a new accumulation: the first MFMA takes a literal-zero C operand (no register zeroing)
+  auto qk_part = [&](const char* kh, int ds0, int ds1, f32x16& sacc) {
+#pragma unroll
+    for (int ds = ds0; ds < ds1; ++ds) {
+      const bf16x8 kf = *(const bf16x8*)(kh + koff[ds]);
+      if (ds == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], zero, 0, 0, 0);
+      } else {
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc, 0, 0, 0);
+      }
+    }
+  };
+  auto mask_half = [&](int g, f32x16& sacc) {
+    if ((g + 1) * 32 > p.Lk) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = g * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= p.Lk) sacc[e] = -INFINITY;
+      }
+    }
+  };
   f32x16 o_acc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) o_acc[dt][j] = 0.f;
+    for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.f;
+  bf16x8 pf_prev[2];       // packed P of the previous half, one fragment per 16-key step
+  auto pv_half = [&](const char* vh) {
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vh + ss * 4096 + voff[0][dt]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vh + ss * 4096 + voff[1][dt]));
+        const bf16x4 lo_b = __builtin_bit_cast(bf16x4, lo), hi_b = __builtin_bit_cast(bf16x4, hi);
+        bf16x8 vf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          vf[e] = lo_b[e];
+          vf[4 + e] = hi_b[e];
+        }
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf_prev[ss], o_acc[dt], 0, 0, 0);
+      }
+    }
+  };
+
   float m_run = -INFINITY, l_run = 0.f;
   const float c = p.scale_log2e;
 
-  const int ntiles = (p.Lk + KVBLK - 1) / KVBLK;
-  bf16x8 kreg[2], vreg[2];
-  auto load_tile = [&](int t) {
+  // ---- prologue: tiles 0 and 1 on their way, S(half 0) computed; zero the V half that PV(-1) multiplies by P = 0
+  *(u32x4*)(smem + (NSLOT - 1) * (2 * KV_TILE_BYTES) + KV_TILE_BYTES + 8192 + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  f32x16 s_a, s_b;         // scores of the current / next half, ping-ponged statically (no register copies)
+  qk_part(k_half(0), 0, 8, s_a);
+  mask_half(0, s_a);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = min(t * KVBLK + st_row[i], p.Lk - 1);
-      kreg[i] = *(const bf16x8*)(kbase + (int64_t)key * p.k_rs + st_col);
-      vreg[i] = *(const bf16x8*)(vbase + (int64_t)key * p.v_rs + st_col);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* kt_ = smem + buf * (2 * KV_TILE_BYTES);
+  for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *(bf16x8*)(kt_ + st_lds[i]) = kreg[i];
-      *(bf16x8*)(kt_ + KV_TILE_BYTES + st_lds[i]) = vreg[i];
-    }
-  };
+    for (int e = 0; e < 8; ++e) pf_prev[ss][e] = (bf16)0.f;
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+  // one half-tile step g, the same straight-line shape for every g:
+  //  * S(g+1) is always computed; past the last half it reads stale LDS, mask_half turns it into -inf and the
+  //    step that consumes it adds exactly 0 (exp2(-inf) = 0, no rescale);
+  //  * PV(g-1) is always issued; for g = 0 P is zero and the V half it reads (slot 3, second half) was zeroed.
+  auto step = [&](int g, f32x16& s_cur, f32x16& s_nxt) {
+    const char* kn = k_half(g + 1);
+    // ---- A: first half of S(g+1) on the matrix pipe | row maximum of S(g) on the VALU
+    qk_part(kn, 0, 4, s_nxt);
+    float m = s_cur[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) m = fmaxf(m, s_cur[e]);
+    const float mx = pair_max(m);
+    // ---- deferred rescale (always taken for half 0): O, l AND the pending P(g-1) move to the new max
+    if (__any((mx - m_run) * c > RESCALE_THR_LOG2)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf_prev[ss][e] = f2bf(bf2f(pf_prev[ss][e]) * alpha);
+    }
+    // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
+    qk_part(kn, 4, 8, s_nxt);
+    pv_half(v_half(g - 1));
+    const float mc = m_run * c;
+    float psum = 0.f;
+    bf16x8 pn[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], c, -mc));
+      psum += pv;
+      pn[e >> 3][e & 7] = f2bf(pv);
+    }
+    l_run += psum;
+    pf_prev[0] = pn[0];            // PV(g-1) above consumed the old value (program order)
+    pf_prev[1] = pn[1];
+    mask_half(g + 1, s_nxt);
+  };
 
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    const char* ktile = smem + buf * (2 * KV_TILE_BYTES);
-    const char* vtile = ktile + KV_TILE_BYTES;
-    if (t + 1 < ntiles) load_tile(t + 1);      // in flight during the MFMA work below
-
-    // ---- S^T[kt] = K[kt] . Q^T      (keys on rows/registers, query on the lane)
-    f32x16 s[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) s[kt][j] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 8; ++ds) {
-        const bf16x8 kf = *(const bf16x8*)(ktile + kt * 8192 + koff[ds]);
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], s[kt], 0, 0, 0);
-      }
+    if (t > 0) {
+      // top of 64-key tile t: tile t+1 (issued one tile ago) has landed and becomes visible; the slot of tile
+      // t-2 (last read by the PV of its second half, in the previous step) is free again
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- mask keys beyond Lk (last tile only; wave-uniform branch)
-    if ((t + 1) * KVBLK > p.Lk) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int key = t * KVBLK + 32 * kt + (j & 3) + 8 * (j >> 2) + 4 * h;
-          if (key >= p.Lk) s[kt][j] = -INFINITY;
-        }
-    }
-    // ---- online softmax for this lane's query row (the other half of the row lives in lane^32)
-    float mx = s[0][0];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[kt][j]);
-    mx = pair_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    float psum = 0.f;
-    bf16x8 pf[2][2];   // [kt][s]: B operand fragments of O^T += V^T . P^T
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][j], c, -mc));
-        psum += pv;
-        pf[kt][j >> 3][j & 7] = f2bf(pv);
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o_acc[dt][j] *= alpha;
-
-    // ---- O^T[dt] += V^T[dt][keys] . P^T[keys]
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-        const char* vb = vtile + kt * 8192 + ss * 4096;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + voff[0][dt]));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + voff[1][dt]));
-          const bf16x4 lo_b = __builtin_bit_cast(bf16x4, lo), hi_b = __builtin_bit_cast(bf16x4, hi);
-          bf16x8 vf;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            vf[j] = lo_b[j];
-            vf[4 + j] = hi_b[j];
-          }
-          o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][ss], o_acc[dt], 0, 0, 0);
-        }
-      }
-
-    // ---- publish tile t+1
-    if (t + 1 < ntiles) store_tile(buf ^ 1);
-    __syncthreads();
+    if (t + 2 < ntiles) issue_tile(t + 2);
+    step(2 * t, s_a, s_b);
+    step(2 * t + 1, s_b, s_a);
   }
+  pv_half(v_half(2 * ntiles - 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: O[q][32dt + 8i + 4h + (0..3)] = o_acc[dt][4i + (0..3)] / l
   const float inv_l = 1.0f / pair_sum(l_run);
@@ -248,7 +314,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       for (int i = 0; i < 4; ++i) {
         bf16x4 ov;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ov[j] = f2bf(o_acc[dt][4 * i + j] * inv_l);
+        for (int e = 0; e < 4; ++e) ov[e] = f2bf(o_acc[dt][4 * i + e] * inv_l);
         *(bf16x4*)(orow + 32 * dt + 8 * i + 4 * h) = ov;
       }
   }
@@ -272,13 +338,17 @@ extern "C" int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const 
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
   p.scale_log2e = softmax_scale * 1.4426950408889634f;
   p.q_blocks = (Lq + QBLK - 1) / QBLK;
-  static bool attr_set = false;
-  const int smem = 4 * KV_TILE_BYTES;   // 64 KiB
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+  FX_REQUIRE((int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
+             "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
+  const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 x (K tile | V tile): 128 KiB
+  const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
+  auto kern = cross ? attn_fwd_kernel<1> : attn_fwd_kernel<0>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[cross]) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return flexam_fail(FLEXAM_E_LAUNCH, "attn_fwd: cannot raise dynamic LDS to %d bytes", smem);
-    attr_set = true;
+    attr_set[cross] = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H * p.q_blocks), dim3(NT), smem, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kern, dim3(B * H * p.q_blocks), dim3(NT), smem, (hipStream_t)stream, p);
   return flexam_check_launch("flexam_attn_fwd");
 }
