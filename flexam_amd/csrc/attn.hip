@@ -95,6 +95,8 @@ __device__ __forceinline__ float pair_sum(float x) {
 // ------------------------------------------------------------------------------------------------
 constexpr int NT = 512;
 constexpr int NSLOT = 4;
+template <int V>
+using IC = std::integral_constant<int, V>;
 constexpr float RESCALE_THR_LOG2 = 8.0f;
 
 template <int KIND>   // 0 = self-attention, 1 = short-context (text) attention: distinct profiler symbols
@@ -175,18 +177,37 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       }
     }
   };
-  auto k_half = [&](int g) -> const char* { return smem + ((g >> 1) & (NSLOT - 1)) * (2 * KV_TILE_BYTES) + (g & 1) * 8192; };
-  auto v_half = [&](int g) -> const char* { return smem + ((g >> 1) & (NSLOT - 1)) * (2 * KV_TILE_BYTES) + KV_TILE_BYTES + (g & 1) * 8192; };
-  // ds0 == 0 starts a new accumulation: the first MFMA takes a literal-zero C operand (no register zeroing)
-  auto qk_part = [&](const char* kh, int ds0, int ds1, f32x16& sacc) {
+  // Half tile g lives in ring slot (g>>1)&3.  With the tile loop unrolled by 4 the slot is a compile-time constant:
+  // the per-lane fragment addresses are precomputed ONCE for slots 0 and 2 (two register sets) and everything
+  // else -- slot parity, K/V region, half, 16-key step -- is folded into the ds_read immediate (< 64 KiB).
+  const char* kaddr[2][8];
+  const char* vaddr[2][2][4];
 #pragma unroll
-    for (int ds = ds0; ds < ds1; ++ds) {
-      const bf16x8 kf = *(const bf16x8*)(kh + koff[ds]);
+  for (int set = 0; set < 2; ++set) {
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) kaddr[set][ds] = smem + set * (4 * KV_TILE_BYTES) + koff[ds];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vaddr[set][half][dt] = smem + set * (4 * KV_TILE_BYTES) + voff[half][dt];
+  }
+  // ds0 == 0 starts a new accumulation: the first MFMA takes a literal-zero C operand (no register zeroing)
+  // `ghalf` (half-tile index modulo 8) must be a compile-time constant at every call site
+  auto qk_part = [&](auto ghalf_c, auto ds0_c, f32x16& sacc) {      // 4 K fragments ds0 .. ds0+3 of half `ghalf`
+    constexpr int ghalf = decltype(ghalf_c)::value, ds0 = decltype(ds0_c)::value;
+    constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
+    constexpr int imm = (slot & 1) * (2 * KV_TILE_BYTES) + (ghalf & 1) * 8192;
+    bf16x8 kf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(kaddr[slot >> 1][ds0 + i] + imm);   // fragments first ...
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                                             // ... then the MFMAs
+      const int ds = ds0 + i;
       if (ds == 0) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], zero, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[ds], zero, 0, 0, 0);
       } else {
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[ds], sacc, 0, 0, 0);
       }
     }
   };
@@ -205,22 +226,27 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) o_acc[dt][e] = 0.f;
   bf16x8 pf_prev[2];       // packed P of the previous half, one fragment per 16-key step
-  auto pv_half = [&](const char* vh) {
+  auto pv_half = [&](auto ghalf_c) {
+    constexpr int ghalf = decltype(ghalf_c)::value;
+    constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
+    constexpr int imm = (slot & 1) * (2 * KV_TILE_BYTES) + KV_TILE_BYTES + (ghalf & 1) * 8192;
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
+      bf16x8 vf[4];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vh + ss * 4096 + voff[0][dt]));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vh + ss * 4096 + voff[1][dt]));
+      for (int dt = 0; dt < 4; ++dt) {                                                   // 8 transposed reads first ...
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[slot >> 1][0][dt] + imm + ss * 4096));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[slot >> 1][1][dt] + imm + ss * 4096));
         const bf16x4 lo_b = __builtin_bit_cast(bf16x4, lo), hi_b = __builtin_bit_cast(bf16x4, hi);
-        bf16x8 vf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          vf[e] = lo_b[e];
-          vf[4 + e] = hi_b[e];
+          vf[dt][e] = lo_b[e];
+          vf[dt][4 + e] = hi_b[e];
         }
-        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf_prev[ss], o_acc[dt], 0, 0, 0);
       }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)                                                     // ... then 4 MFMAs
+        o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf_prev[ss], o_acc[dt], 0, 0, 0);
     }
   };
 
@@ -235,8 +261,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   f32x16 s_a, s_b;         // scores of the current / next half, ping-ponged statically (no register copies)
-  qk_part(k_half(0), 0, 8, s_a);
-  mask_half(0, s_a);
+  qk_part(IC<0>{}, IC<0>{}, s_a);
+  qk_part(IC<0>{}, IC<4>{}, s_a);
 #pragma unroll
   for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -246,10 +272,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   //  * S(g+1) is always computed; past the last half it reads stale LDS, mask_half turns it into -inf and the
   //    step that consumes it adds exactly 0 (exp2(-inf) = 0, no rescale);
   //  * PV(g-1) is always issued; for g = 0 P is zero and the V half it reads (slot 3, second half) was zeroed.
-  auto step = [&](int g, f32x16& s_cur, f32x16& s_nxt) {
-    const char* kn = k_half(g + 1);
+  auto step = [&](int g, auto g8_c, f32x16& s_cur, f32x16& s_nxt) {     // g8 = g mod 8 as a compile-time constant
+    constexpr int g8 = decltype(g8_c)::value;
+    mask_half(g, s_cur);             // keys past Lk -> -inf (uniform branch, only taken in the last tile)
     // ---- A: first half of S(g+1) on the matrix pipe | row maximum of S(g) on the VALU
-    qk_part(kn, 0, 4, s_nxt);
+    qk_part(IC<((g8 + 1) & 7)>{}, IC<0>{}, s_nxt);
     float m = s_cur[0];
 #pragma unroll
     for (int e = 1; e < 16; ++e) m = fmaxf(m, s_cur[e]);
@@ -270,8 +297,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
         for (int e = 0; e < 8; ++e) pf_prev[ss][e] = f2bf(bf2f(pf_prev[ss][e]) * alpha);
     }
     // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
-    qk_part(kn, 4, 8, s_nxt);
-    pv_half(v_half(g - 1));
+    qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
+    pv_half(IC<((g8 + 7) & 7)>{});
     const float mc = m_run * c;
     float psum = 0.f;
     bf16x8 pn[2];
@@ -284,10 +311,20 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     l_run += psum;
     pf_prev[0] = pn[0];            // PV(g-1) above consumed the old value (program order)
     pf_prev[1] = pn[1];
-    mask_half(g + 1, s_nxt);
+    // pin the softmax results here: hipcc otherwise sinks the whole exp chain below the next step's branch
+    asm volatile("" : "+v"(pf_prev[0]), "+v"(pf_prev[1]), "+v"(l_run));
+    // Block B schedule: hipcc otherwise emits the 12 MFMAs first and the exp chain after them, leaving the matrix
+    // pipe idle during the softmax.  Interleave: per MFMA two LDS reads (20 in the block) and ~5 VALU ops.
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU (exp2 / fma / add / cvt)
+    }
   };
 
-  for (int t = 0; t < ntiles; ++t) {
+  auto tile = [&](int t, auto t4_c) {       // t4 = t mod 4 as a compile-time constant
+    constexpr int t4 = decltype(t4_c)::value;
     if (t > 0) {
       // top of 64-key tile t: tile t+1 (issued one tile ago) has landed and becomes visible; the slot of tile
       // t-2 (last read by the PV of its second half, in the previous step) is free again
@@ -297,10 +334,27 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (t + 2 < ntiles) issue_tile(t + 2);
-    step(2 * t, s_a, s_b);
-    step(2 * t + 1, s_b, s_a);
+    step(2 * t, IC<2 * t4>{}, s_a, s_b);
+    step(2 * t + 1, IC<2 * t4 + 1>{}, s_b, s_a);
+  };
+  int t = 0;
+  for (; t + 4 <= ntiles; t += 4) {
+    tile(t, IC<0>{});
+    tile(t + 1, IC<1>{});
+    tile(t + 2, IC<2>{});
+    tile(t + 3, IC<3>{});
   }
-  pv_half(v_half(2 * ntiles - 1));
+  const int rem = ntiles - t;               // 0..3 tail tiles, same code with static slots
+  if (rem > 0) tile(t, IC<0>{});
+  if (rem > 1) tile(t + 1, IC<1>{});
+  if (rem > 2) tile(t + 2, IC<2>{});
+  // pending PV of the last half (2*ntiles - 1): its slot is (ntiles - 1) & 3
+  switch ((ntiles - 1) & 3) {
+    case 0: pv_half(IC<1>{}); break;
+    case 1: pv_half(IC<3>{}); break;
+    case 2: pv_half(IC<5>{}); break;
+    default: pv_half(IC<7>{}); break;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: O[q][32dt + 8i + 4h + (0..3)] = o_acc[dt][4i + (0..3)] / l
