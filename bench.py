@@ -9,8 +9,9 @@ Workload (BASELINE config 2): Wan2.2-Fun-5B-FLEXAM DiT (dim 3072, 24 
 (448 reference-image tokens + 11200 video tokens), CFG pair (B = 2), flow-match Euler, 50-step schedule,
 synthetic seeded conditioning.  One *step* = one iteration of the reference loop
 (pipeline_wan2_2_fun_control_FlexAM.py:844-949): two DiT sample-forwards + CFG + Euler + masked blend.
-N > 1: one process per GPU, the token sequence is split into N contiguous chunks, K/V are all-gathered
-per block over RCCL/xGMI (strong scaling of ONE clip).
+N > 1: one process per GPU; the two CFG rows are split first (independent until the guidance combine), then
+the token sequence into N/2 contiguous chunks whose K/V are all-gathered per block over RCCL/xGMI
+(strong scaling of ONE clip).
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the self-attention flash kernel, timed
 live with events on the launch stream) and `cpu_baseline` (the fp32 oracle on the host cores, one of the
@@ -140,6 +141,30 @@ def cpu_baseline(L, cfg):
                        f"took {sec:.1f} s; value = 1/(60 x that), extrapolated", block_seconds=sec)
 
 
+def time_vae_decode(device, frames, height, width):
+    """Wan2.2 3D-VAE decode of one clip (random-init weights, PIPE.py:951-955) -> seconds."""
+    from flexam_amd import AutoencoderKLWan3_8
+    torch.manual_seed(1)
+    with torch.device(device):
+        vae = AutoencoderKLWan3_8(spatial_compression_ratio=16)
+        for n, prm in vae.named_parameters():
+            if n.endswith("gamma"):
+                torch.nn.init.ones_(prm)
+            elif prm.dim() > 1:
+                torch.nn.init.normal_(prm, std=(1.0 / prm.shape[1:].numel()) ** 0.5)
+            else:
+                torch.nn.init.zeros_(prm)
+    vae = vae.to(torch.bfloat16)
+    z = torch.randn(1, 48, (frames - 1) // 4 + 1, height // 16, width // 16, device=device)
+    vae.decode(z)                                   # warm-up (allocations, tap tables)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = vae.decode(z).sample
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    return sec, bool(torch.isfinite(out.float()).all())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +176,7 @@ def main():
     ap.add_argument("--layers", type=int, default=30, help="debug only: fewer layers makes the number INVALID")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-vae", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,11 +228,20 @@ def main():
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(pipe._state["latents"]).all())
 
-    lc = L // world
-    kern = None if args.no_kernel_timing else kernel_rooflines(eng, B, L, lc)
+    lc = L // eng.sp_size
+    b_local = 1 if eng.cfg_size == 2 else B
+    kern = None if args.no_kernel_timing else kernel_rooflines(eng, b_local, L, lc)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(L, cfg)
+
+    eng_cfg, eng_sp = eng.cfg_size, eng.sp_size
+    vae_sec = None
+    if rank == 0 and world == 1 and not args.no_vae:
+        del pipe, model, eng
+        torch.cuda.empty_cache()
+        vae_sec, vae_finite = time_vae_decode(device, args.frames, args.height, args.width)
+        finite = finite and vae_finite
 
     if rank == 0:
         steps_per_sec = args.steps / elapsed
@@ -219,16 +254,19 @@ def main():
             "config": {"workload": f"Wan2.2-Fun-5B-FLEXAM DiT denoise step, {args.frames}x{args.height}x{args.width}, "
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
                                    f"random-init bf16 weights, synthetic conditioning (BASELINE configs[1])",
-                       "parallelism": f"sp{world} (token-chunk sequence parallel, RCCL K/V all-gather per block)" if world > 1 else "single GPU",
+                       "parallelism": (f"cfg{eng_cfg} x sp{eng_sp}: CFG rows split first (no per-block traffic), then token-chunk sequence "
+                                       f"parallel with one RCCL K/V all-gather per block") if world > 1 else "single GPU",
                        "layers": cfg["num_layers"]},
             "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
+            "vae_decode_sec": vae_sec,
+            "sec_per_clip": (total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
             "dit_block_tflops": step_block_flops * steps_per_sec / 1e12,
             "dit_block_mfma_frac": step_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
             "finite": finite,
         }
         if kern is not None:
             a = kern["attn_self"]
-            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel (self-attention, head_dim 128)", "achieved": a["tflops"],
+            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0> (self-attention, head_dim 128)", "achieved": a["tflops"],
                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
                                   "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"]}
             result["kernels"] = {k: {"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1),

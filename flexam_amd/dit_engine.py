@@ -92,6 +92,8 @@ class DiTEngine:
         hip.device_check()
         self.sp_group = None
         self.sp_rank, self.sp_size = 0, 1
+        self.world_group, self.world_size = None, 1
+        self.cfg_size, self.cfg_row = 1, 0          # cfg_size 2: this rank computes only CFG row `cfg_row`
         self._ws = {}
         self._angles = None
         self.cond = None
@@ -141,9 +143,18 @@ class DiTEngine:
                 gn=[(f32(getattr(m, f"cnn_conv{i}")[1].weight), f32(getattr(m, f"cnn_conv{i}")[1].bias)) for i in range(1, 5)],
                 conv5=_ConvCL(m.cnn_conv5.weight, m.cnn_conv5.bias, 128, dev), groups=[24, 24, 12, 12], cp=cin)
 
-    def set_sequence_parallel(self, group, rank: int, size: int):
-        self.sp_group, self.sp_rank, self.sp_size = group, rank, size
+    def set_parallel(self, sp_group, sp_rank: int, sp_size: int, world_group=None, world_size: int = None, cfg_size: int = 1,
+                     cfg_row: int = 0):
+        """Parallel layout of this rank: token chunk `sp_rank` of `sp_size` inside `sp_group`; with cfg_size = 2 the
+        world is two such groups, one per CFG row (world rank = cfg_row * sp_size + sp_rank)."""
+        self.sp_group, self.sp_rank, self.sp_size = sp_group, sp_rank, sp_size
+        self.world_group = world_group if cfg_size > 1 else sp_group
+        self.world_size = world_size if world_size is not None else sp_size
+        self.cfg_size, self.cfg_row = cfg_size, cfg_row
         self._ws.clear()
+
+    def set_sequence_parallel(self, group, rank: int, size: int):
+        self.set_parallel(group, rank, size)
 
     # ------------------------------------------------------------------ per-clip state
     def _cnn_block(self, control: torch.Tensor, additional: torch.Tensor) -> torch.Tensor:
@@ -356,7 +367,16 @@ class DiTEngine:
     def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
         """All-gather of the head output [B, Lc, 192] -> [B, L, 192] (the reference's one collective,
         wan_transformer3d_FlexAM.py:1103-1104)."""
-        if self.sp_size == 1:
+        if self.world_size == 1:
             return head_local
         from .dist import all_gather_seq
-        return all_gather_seq(head_local, self.sp_group)
+        if self.cfg_size == 1:
+            return all_gather_seq(head_local, self.sp_group)
+        # world rank = cfg_row * sp + sp_rank, one local row each: the rank-major gather IS [2, sp, Lc, n]
+        import torch.distributed as dist
+        bl, lc, n = head_local.shape
+        if bl != 1:
+            raise RuntimeError("cfg-parallel ranks carry exactly one CFG row")
+        out = torch.empty(self.world_size * lc, n, device=head_local.device, dtype=head_local.dtype)   # rank-major concat
+        dist.all_gather_into_tensor(out, head_local.reshape(lc, n).contiguous(), group=self.world_group)
+        return out.view(self.cfg_size, self.sp_size * lc, n)

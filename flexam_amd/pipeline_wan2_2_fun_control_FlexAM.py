@@ -182,6 +182,8 @@ class Wan2_2FunControlPipeline_FlexAM:
             latents = (1 - mask) * known + mask * latents                       # PIPE.py:690 (once, torch)
         y = torch.cat([cond.control_latents.to(dev, F32), mask_latents, known], dim=1)   # PIPE.py:868-875
         context = (list(context_uncond) + list(context_cond)) if cfg else list(context_cond)
+        if eng.cfg_size == 2:                      # CFG-parallel: this rank carries one row of the pair
+            context = [context[eng.cfg_row]] if cfg else list(context_cond)
         nrow = len(context)
         dens = torch.full((nrow,), float(density), device=dev, dtype=F32)
         eng.set_conditioning(context, y, cond.ref_latents, cond.additional_control, dens, (c, f, h, w), shared=True)
@@ -214,6 +216,7 @@ class Wan2_2FunControlPipeline_FlexAM:
             raise NotImplementedError("cfg_skip inside the fused sampler is a later-round feature; use transformer.forward")
         head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"]))
         c, f, h, w = st["shape"]
+        # head: [rows, L, 192] with rows = (uncond, cond) after the gather, whatever the parallel layout
         hip.cfg_euler_blend(head[0], head[1] if st["cfg"] else None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i),
                             st["latents"], st["known"], st["mask"])
         return st["latents"]

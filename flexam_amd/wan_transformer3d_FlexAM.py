@@ -122,6 +122,7 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         self.num_inference_steps = None
         self.gradient_checkpointing = False
         self.sp_world_size, self.sp_world_rank, self._sp_group = 1, 0, None
+        self._parallel = None
         self._engine: Optional[DiTEngine] = None
         self.init_weights()
 
@@ -178,8 +179,8 @@ class WanTransformer3DModel_FlexAM(nn.Module):
     def engine(self) -> DiTEngine:
         if self._engine is None:
             self._engine = DiTEngine(self)
-            if self.sp_world_size > 1:
-                self._engine.set_sequence_parallel(self._sp_group, self.sp_world_rank, self.sp_world_size)
+            if self._parallel is not None:
+                self._engine.set_parallel(**self._parallel)
         return self._engine
 
     # ------------------------------------------------------------------ feature switches (reference API)
@@ -219,16 +220,34 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         if self._engine is not None:
             self._engine._angles = None
 
-    def enable_multi_gpus_inference(self, group=None):
-        """Sequence-parallel inference over `group` (default: the world group): contiguous token
-        chunks per rank, RCCL all-gather of K/V per block (flexam_amd/dit_engine.py).  Stands in for
-        the reference's missing FlexAM/dist + xfuser USP (wan_transformer3d_FlexAM.py:801-815)."""
+    def enable_multi_gpus_inference(self, group=None, cfg_parallel=None):
+        """Multi-GPU inference over `group` (default: the world group).  Stands in for the reference's missing
+        FlexAM/dist + xfuser USP (wan_transformer3d_FlexAM.py:801-815).  Layout (flexam_amd/dist.py):
+          * cfg_parallel (default: on when the group size is even): the two classifier-free-guidance rows are
+            independent until the guidance combine (PIPE.py:926-928), so the first split is by CFG row -- no
+            per-block traffic at all;
+          * inside each half, contiguous token chunks per rank with one RCCL all-gather of K/V per block;
+          * one all-gather of the head output per step over the whole group."""
         import torch.distributed as dist
-        self._sp_group = group
-        self.sp_world_size = dist.get_world_size(group)
-        self.sp_world_rank = dist.get_rank(group)
+        world = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        if cfg_parallel is None:
+            cfg_parallel = world % 2 == 0
+        if cfg_parallel and world % 2:
+            raise ValueError("cfg_parallel needs an even number of ranks")
+        if cfg_parallel:
+            sp = world // 2
+            members = dist.get_process_group_ranks(group) if group is not None else list(range(world))
+            halves = [dist.new_group(members[i * sp:(i + 1) * sp]) for i in range(2)]     # every rank creates both
+            self._parallel = dict(sp_group=halves[rank // sp], sp_rank=rank % sp, sp_size=sp, world_group=group, world_size=world,
+                                  cfg_size=2, cfg_row=rank // sp)
+            self.sp_world_size, self.sp_world_rank = sp, rank % sp
+        else:
+            self._parallel = dict(sp_group=group, sp_rank=rank, sp_size=world, world_group=group, world_size=world)
+            self.sp_world_size, self.sp_world_rank = world, rank
+        self._sp_group = self._parallel["sp_group"]
         if self._engine is not None:
-            self._engine.set_sequence_parallel(group, self.sp_world_rank, self.sp_world_size)
+            self._engine.set_parallel(**self._parallel)
 
     # ------------------------------------------------------------------ forward
     @staticmethod
@@ -261,6 +280,13 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         eng = self.engine()
         if isinstance(x, (list, tuple)):
             x = torch.stack(list(x))
+        B_full = x.shape[0]
+        if eng.cfg_size == 2:                      # this rank computes one of the two CFG rows
+            if B_full != 2:
+                raise NotImplementedError("cfg-parallel inference expects the CFG pair (batch 2)")
+            r = eng.cfg_row
+            sl = lambda v: v[r:r + 1] if torch.is_tensor(v) else ([v[r]] if isinstance(v, (list, tuple)) else v)
+            x, t, context, y, full_ref, additional_control, density = (sl(v) for v in (x, t, context, y, full_ref, additional_control, density))
         B = x.shape[0]
         cond = eng.set_conditioning(list(context), y, full_ref, additional_control, density, tuple(x.shape[1:]))
         L, ref_len = cond["L"], cond["ref_len"]
@@ -278,8 +304,8 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         tokens = eng.gather_tokens(head_local)
         from . import hip
         c, f, h, w = x.shape[1:]
-        out = torch.empty(B, self.out_dim, f, h, w, device=eng.device, dtype=x.dtype if x.dtype in (F32, torch.bfloat16) else F32)
-        for b in range(B):
+        out = torch.empty(B_full, self.out_dim, f, h, w, device=eng.device, dtype=x.dtype if x.dtype in (F32, torch.bfloat16) else F32)
+        for b in range(B_full):
             hip.unpatchify(tokens[b], ref_len, self.out_dim, f, h, w, out=out[b])
         return out
 
