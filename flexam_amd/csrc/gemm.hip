@@ -19,6 +19,8 @@
 //  * workgroup -> tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
 //    chunks of the tile list, walked in groups of 8 tile-rows so concurrently resident tiles
 //    share A row-panels and W column-panels in L2.
+#include <stdlib.h>
+
 #include "common.h"
 #include "flexam_hip.h"
 
@@ -47,24 +49,30 @@ struct GemmParams {
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 
-__device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, const int64_t (&row_off)[4], int64_t kcol,
+template <int PASSES>
+__device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, const int64_t (&row_off)[PASSES], int64_t kcol,
                                            char* lds_tile, int wave) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < PASSES; ++i) {
     const bf16* src = base + row_off[i] + kcol;
-    char* dst = lds_tile + i * 8192 + wave * 1024;   // wave-uniform; hardware adds lane*16
+    char* dst = lds_tile + i * (32768 / PASSES) + wave * 1024;   // wave-uniform; hardware adds lane*16
     __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
   }
 }
 
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
+// WN = waves along N (4: 8 waves of 128x64 outputs, two per SIMD; 2: 4 waves of 128x128 outputs, one per SIMD with
+// the 512-register budget -- a third fewer LDS fragment reads per MFMA)
+template <int EPI, typename OutT, int WN>
+__global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
+  constexpr int NTHR = 128 * WN;          // 2 x WN waves
+  constexpr int NTW = 16 / WN;            // 16-wide n-tiles per wave (4 or 8)
+  constexpr int PASSES = 2048 / NTHR;     // 16-byte pieces per thread per operand tile (4 or 8)
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
 
   // ---- XCD-aware, grouped tile order
   const int nwg = p.tiles_m * p.tiles_n;
@@ -84,10 +92,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const in
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- staging addresses: thread -> (row = i*64 + tid/8, LDS slot = tid%8), source chunk = slot ^ swz(row)
-  int64_t a_off[4], w_off[4];
+  int64_t a_off[PASSES], w_off[PASSES];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 64 + (tid >> 3);
+  for (int i = 0; i < PASSES; ++i) {
+    const int row = i * (NTHR / 8) + (tid >> 3);
     const int chunk = (tid & 7) ^ ((row >> 1) & 7);
     const int gm = min(m0 + row, p.M - 1);
     const int gn = min(n0 + row, p.N - 1);
@@ -100,17 +108,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const in
   const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
   const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NTW];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
   auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
 
-  stage_tile(p.A, a_off, kcol_a(0), smem, wave);
-  stage_tile(p.W, w_off, 0, smem + TILE_BYTES, wave);
+  stage_tile<PASSES>(p.A, a_off, kcol_a(0), smem, wave);
+  stage_tile<PASSES>(p.W, w_off, 0, smem + TILE_BYTES, wave);
   int64_t kcol_next = kcol_a(1);          // offset of tile kb+1, fetched one iteration ahead
   __syncthreads();
 
@@ -118,24 +126,24 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const in
     char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
     if (kb + 1 < nk) {
       char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
-      stage_tile(p.A, a_off, kcol_next, nxt, wave);
-      stage_tile(p.W, w_off, (int64_t)(kb + 1) * BK, nxt + TILE_BYTES, wave);
+      stage_tile<PASSES>(p.A, a_off, kcol_next, nxt, wave);
+      stage_tile<PASSES>(p.W, w_off, (int64_t)(kb + 1) * BK, nxt + TILE_BYTES, wave);
     }
     kcol_next = kcol_a(kb + 2);
     const char* at = cur + wm * (128 * 128);
-    const char* wt = cur + TILE_BYTES + wn * (64 * 128);
+    const char* wt = cur + TILE_BYTES + wn * (16 * NTW * 128);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int fo = ks ? frag_off1 : frag_off0;
-      bf16x8 wf[4], af[8];
+      bf16x8 wf[NTW], af[8];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) wf[nt] = *(const bf16x8*)(wt + nt * 2048 + fo);
+      for (int nt = 0; nt < NTW; ++nt) wf[nt] = *(const bf16x8*)(wt + nt * 2048 + fo);
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt) af[mt] = *(const bf16x8*)(at + mt * 2048 + fo);
 #pragma unroll
       for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTW; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
     }
     __syncthreads();
@@ -143,10 +151,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const in
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
   const int mrow = m0 + wm * 128 + (lane & 15);
-  const int ncol = n0 + wn * 64 + (lane >> 4) * 4;
-  f32x4 bias[4];
+  const int ncol = n0 + wn * (16 * NTW) + (lane >> 4) * 4;
+  f32x4 bias[NTW];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
+  for (int nt = 0; nt < NTW; ++nt) {
     const int n = ncol + nt * 16;
     bias[nt] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const in
       }
     }
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NTW; ++nt) {
       const int n = ncol + nt * 16;
       if (n >= p.N) continue;
       f32x4 v = acc[mt][nt] + bias[nt];
@@ -190,9 +198,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_kernel(GemmParams p, const in
   }
 }
 
-template <int EPI, typename OutT>
-int launch(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
-  auto kern = gemm_bf16_kernel<EPI, OutT>;
+template <int EPI, typename OutT, int WN>
+int launch_w(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
+  auto kern = gemm_bf16_kernel<EPI, OutT, WN>;
   static bool attr_set = false;
   const int smem = 4 * TILE_BYTES;   // 128 KiB
   if (!attr_set) {
@@ -200,8 +208,14 @@ int launch(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
       return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(NT), smem, s, p, a_koff);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(128 * WN), smem, s, p, a_koff);
   return flexam_check_launch("flexam_gemm_bf16");
+}
+
+template <int EPI, typename OutT>
+int launch(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
+  static const int four_wave = [] { const char* e = getenv("FLEXAM_GEMM_4WAVE"); return e ? atoi(e) : 0; }();
+  return four_wave ? launch_w<EPI, OutT, 2>(p, a_koff, s) : launch_w<EPI, OutT, 4>(p, a_koff, s);
 }
 
 }  // namespace
