@@ -1,0 +1,125 @@
+"""GPU: direct parity tests of the channels-last conv / VAE helper kernels against torch fp32
+formulas (the end-to-end VAE and cnn-block tests cover them too; these localise a failure)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf16_close(got, want, atol=1e-3):
+    got, want = got.float().cpu(), want.float()
+    tol = 2.0 ** -8 * want.abs() + atol
+    assert bool(((got - want).abs() <= tol).all()), f"max err {(got - want).abs().max():.4g}"
+
+
+def padded_rows(x):
+    """[C,F,H,W] fp32 -> rows [(f,hp,wp), C] with zero borders."""
+    c, f, h, w = x.shape
+    p = torch.zeros(f, h + 2, w + 2, c)
+    p[:, 1:-1, 1:-1] = x.permute(1, 2, 3, 0)
+    return p.view(-1, c)
+
+
+def test_pack_conv3x3_unpack_equals_conv2d():
+    from flexam_amd import hip as H
+    g = torch.Generator().manual_seed(1)
+    c, f, h, w, co = 40, 2, 6, 10, 24
+    x = torch.randn(c, f, h, w, generator=g).to(BF).float()
+    wt = (torch.randn(co, c, 3, 3, generator=g) / math.sqrt(c * 9)).to(BF).float()
+    b = torch.randn(co, generator=g)
+    cp = 64
+    guard = (w + 2 + 1) * cp
+    buf = torch.zeros(guard * 2 + f * (h + 2) * (w + 2) * cp, dtype=BF, device=dev())
+    img = buf[guard:guard + f * (h + 2) * (w + 2) * cp].view(f, h + 2, w + 2, cp)
+    H.pack_cl(x.to(dev()), img, 0)
+    wp = torch.zeros(co, 3, 3, cp)
+    wp[..., :c] = wt.permute(0, 2, 3, 1)
+    koff = torch.tensor([((dh - 1) * (w + 2) + (dw - 1)) * cp for dh in range(3) for dw in range(3)], dtype=torch.int64)
+    rows = f * (h + 2) * (w + 2)
+    y = H.gemm(img.view(rows, cp), wp.view(co, 9 * cp).to(BF).to(dev()), b.to(dev()), a_koff=koff.to(dev()), m=rows, k=9 * cp,
+               out_dtype=torch.float32)
+    got = H.unpack_cl(y, co, f, h, w)
+    want = torch.stack([F.conv2d(x[:, i][None], wt, b, padding=1)[0] for i in range(f)], dim=1)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_groupnorm_silu_with_residual():
+    from flexam_amd import hip as H
+    g = torch.Generator().manual_seed(2)
+    c, f, h, w, groups = 48, 2, 5, 7, 6
+    x = torch.randn(c, f, h, w, generator=g) * 2 + 0.3
+    res = torch.randn(c, f, h, w, generator=g).to(BF)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    rows = padded_rows(x) + 7.0 * (padded_rows(torch.ones_like(x)) == 0)        # garbage in the border rows must be ignored
+    rimg = torch.zeros(f, h + 2, w + 2, 64, dtype=BF)
+    rimg[:, 1:-1, 1:-1, :c] = res.permute(1, 2, 3, 0)
+    dst = torch.zeros(f, h + 2, w + 2, 64, dtype=BF, device=dev())
+    H.groupnorm_silu_cl(rows.to(dev()), c, f, h, w, groups, gamma.to(dev()), beta.to(dev()), dst, residual=rimg.to(dev()))
+    want = F.silu(F.group_norm(x[None], groups, gamma, beta, 1e-5))[0] + res.float()
+    got = dst[:, 1:-1, 1:-1, :c].permute(3, 0, 1, 2)
+    bf16_close(got, want, atol=2e-3)
+    assert float(dst[:, 0].abs().max()) == 0 and float(dst[..., c:].abs().max()) == 0     # borders / pad channels untouched
+
+
+def test_vae_prep_modes_upsample_dupup_scatter_softmax_unpatchify():
+    from flexam_amd import hip as H
+    g = torch.Generator().manual_seed(3)
+    c, t, h, w = 32, 2, 3, 5
+    x = torch.randn(c, t, h, w, generator=g)
+    rows = padded_rows(x).to(dev())
+    gamma = 1 + 0.1 * torch.randn(c, generator=g)
+    # prep mode 2 (RMS_norm + SiLU) into an image with 2 history frames; mode 1 compact
+    img = torch.zeros(t + 2, h + 2, w + 2, 64, dtype=BF, device=dev())
+    H.vae_prep_cl(rows, c, t, h, w, img, mode=2, gamma=gamma.to(dev()), t0=2)
+    want = F.silu(F.normalize(x, dim=0) * math.sqrt(c) * gamma.view(c, 1, 1, 1))
+    bf16_close(img[2:, 1:-1, 1:-1, :c].permute(3, 0, 1, 2), want)
+    assert float(img[:2].abs().max()) == 0
+    comp = torch.zeros(t * h * w, c, dtype=BF, device=dev())
+    H.vae_prep_cl(rows, c, t, h, w, comp, mode=1, gamma=gamma.to(dev()), compact=True)
+    bf16_close(comp.view(t, h, w, c).permute(3, 0, 1, 2), F.normalize(x, dim=0) * math.sqrt(c) * gamma.view(c, 1, 1, 1))
+    # nearest 2x upsample with frame de-interleave of a [rows, 2c'] matrix
+    cc = c // 2
+    up = torch.zeros(2 * t, 2 * h + 2, 2 * w + 2, 64, dtype=BF, device=dev())
+    H.upsample2x_cl(rows, cc, t, h, w, up, interleave=True)
+    y = x.view(2, cc, t, h, w)
+    inter = torch.stack((y[0], y[1]), dim=2).reshape(cc, 2 * t, h, w)
+    want_up = F.interpolate(inter.permute(1, 0, 2, 3), scale_factor=2.0, mode="nearest-exact").permute(1, 0, 2, 3)
+    bf16_close(up[:, 1:-1, 1:-1, :cc].permute(3, 0, 1, 2), want_up)
+    # DupUp3D add (temporal factor 2, first-chunk crop and regular)
+    co = 16
+    for first, t_in in ((True, 1), (False, 2)):
+        xin = torch.randn(c, t_in, h, w, generator=g)
+        to = 1 if first else 2 * t_in
+        main = torch.randn(co, to, 2 * h, 2 * w, generator=g)
+        mrows = padded_rows(main).to(dev())
+        H.dupup_add_cl(mrows, co, to, 2 * h, 2 * w, padded_rows(xin).to(dev()), c, 2, 1 if first else 0)
+        rep = co * 8 // c
+        d = xin[None].repeat_interleave(rep, dim=1).view(1, co, 2, 2, 2, t_in, h, w).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(1, co, 2 * t_in, 2 * h, 2 * w)
+        d = d[:, :, 1:] if first else d
+        got = mrows.view(to, 2 * h + 2, 2 * w + 2, co)[:, 1:-1, 1:-1].permute(3, 0, 1, 2).cpu()
+        torch.testing.assert_close(got, main + d[0], rtol=1e-6, atol=1e-6)
+    # scatter-add of compact rows, row softmax, final unpatchify + clamp
+    yb = torch.randn(t * h * w, c, generator=g).to(BF)
+    xr = padded_rows(x).to(dev())
+    H.scatter_add_cl(xr, yb.to(dev()), c, t, h, w)
+    got = xr.view(t, h + 2, w + 2, c)[:, 1:-1, 1:-1].permute(3, 0, 1, 2).cpu()
+    torch.testing.assert_close(got, x + yb.float().view(t, h, w, c).permute(3, 0, 1, 2), rtol=1e-6, atol=1e-6)
+    s = torch.randn(9, 24, generator=g) * 3
+    p = torch.empty(9, 64, dtype=BF, device=dev())
+    H.softmax_rows(s.to(dev()), 0.25, p, 24)
+    bf16_close(p[:, :24], torch.softmax(s * 0.25, dim=1), atol=1e-4)
+    assert float(p[:, 24:].abs().max()) == 0
+    v = torch.randn(12, t, h, w, generator=g) * 1.5
+    video = torch.zeros(3, 5, 2 * h, 2 * w, device=dev())
+    H.vae_unpatchify_clamp(padded_rows(v).to(dev()), t, h, w, video, 3)
+    want_v = v.view(3, 2, 2, t, h, w).permute(0, 3, 4, 2, 5, 1).reshape(3, t, 2 * h, 2 * w).clamp(-1, 1)      # (c r q) -> (h q) (w r)
+    torch.testing.assert_close(video[:, 3:5].cpu(), want_v, rtol=0, atol=0)
+    assert float(video[:, :3].abs().max()) == 0
