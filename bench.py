@@ -97,7 +97,7 @@ def kernel_rooflines(eng, B, L, lc):
         k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hd))
         v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hd))
     else:
-        kv = ws["kv_cat"]
+        kv = ws["kv_cat"]                      # gathered K|V of the last block (same shape as every block's)
         k4, v4 = kv[:, :, 0:d].unflatten(2, (nh, hd)), kv[:, :, d:].unflatten(2, (nh, hd))
     t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd)), iters=8)
     out["attn_self"] = dict(flops=4.0 * B * lc * L * d, sec=t)

@@ -38,6 +38,32 @@ def all_gather_seq(local: torch.Tensor, group=None, out: torch.Tensor = None, sc
     return out
 
 
+class SeqGather:
+    """Asynchronous form of all_gather_seq: start() launches the collective (overlaps with whatever the caller
+    enqueues next on its compute stream), finish() waits for it and returns [B, N*Lc, X].  With B == 1 the
+    rank-major concatenation already IS the token order, so no re-layout pass is needed."""
+
+    def __init__(self, local: torch.Tensor, group=None, out: torch.Tensor = None, scratch: torch.Tensor = None):
+        self.world = dist.get_world_size(group)
+        self.shape = tuple(local.shape)
+        b, lc, x = self.shape
+        self.out = out
+        if b == 1:
+            self.scratch = out.view(self.world * b, lc, x) if out is not None else torch.empty(self.world, lc, x, device=local.device, dtype=local.dtype)
+        else:
+            self.scratch = scratch if scratch is not None else torch.empty(self.world * b, lc, x, device=local.device, dtype=local.dtype)
+        self.work = dist.all_gather_into_tensor(self.scratch.view(self.world * b, lc, x), local.contiguous(), group=group, async_op=True)
+
+    def finish(self) -> torch.Tensor:
+        self.work.wait()
+        b, lc, x = self.shape
+        if b == 1:
+            return self.scratch.view(1, self.world * lc, x)
+        out = self.out if self.out is not None else torch.empty(b, self.world * lc, x, device=self.scratch.device, dtype=self.scratch.dtype)
+        out.view(b, self.world, lc, x).copy_(self.scratch.view(self.world, b, lc, x).transpose(0, 1))
+        return out
+
+
 def shard_rows(full: torch.Tensor, batch: int, seq_len: int, rank: int, world: int) -> torch.Tensor:
     """Per-token vector [B*L] (e.g. the AdaLN row index) -> this rank's [B*Lc] slice."""
     s, e = chunk_bounds(seq_len, rank, world)

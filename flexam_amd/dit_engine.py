@@ -267,13 +267,21 @@ class DiTEngine:
             hip.small_linear(e[sl], *self.time[2], silu_in=True, out=e0[sl])
         return e, e0.view(R, 6, d)
 
-    def run(self, x: torch.Tensor, t_rows: torch.Tensor, row_index: Optional[torch.Tensor], rows_per_batch: int) -> torch.Tensor:
+    def run(self, x: torch.Tensor, t_rows: torch.Tensor, row_index: Optional[torch.Tensor], rows_per_batch: int,
+            only_row: Optional[int] = None) -> torch.Tensor:
         """x [Bx, 48, F, H, W] (Bx = B, or 1 when all rows share the latent); t_rows [R] distinct
         timesteps with R = B * rows_per_batch table rows (rows of batch b are b*rows_per_batch ..);
         row_index int32 [B * L] global table row per token, or None (then token (b, l) uses row b).
         Returns the head output tokens fp32 [B, Lc, 4*out_dim] of this rank's token chunk."""
         cd, dev, d = self.cond, self.device, self.dim
         B, L, lvid, ref_len = cd["B"], cd["L"], cd["lvid"], cd["ref_len"]
+        # only_row: run a single conditioning row (cfg_skip: the unconditional row is dropped, cfg_optimization.py:5-37);
+        # t_rows / row_index then describe that one row
+        rsel = slice(None) if only_row is None else slice(only_row, only_row + 1)
+        if only_row is not None:
+            B = 1
+        dens0 = cd["dens0"][rsel] if cd["dens0"] is not None else None
+        dens_emb = cd["dens_emb"][rsel] if cd["dens_emb"] is not None else None
         cx, f, h, w = cd["latent_shape"]
         sp, rank = self.sp_size, self.sp_rank
         if L % sp:
@@ -303,10 +311,11 @@ class DiTEngine:
         R = t_rows.numel()
         e, e0 = self.embed_time(t_rows)
         tab = torch.empty(self.nl, R, 6, d, device=dev, dtype=F32)
-        hip.mod_table(self.mod, e0, tab, rows_per_batch, 0b010010, self.mdens, cd["dens0"], 0xFF1FF0 if cd["dens0"] is not None else -1)
+        hip.mod_table(self.mod, e0, tab, rows_per_batch, 0b010010, self.mdens, dens0.contiguous() if dens0 is not None else None,
+                      0xFF1FF0 if dens0 is not None else -1)
         htab = torch.empty(1, R, 2, d, device=dev, dtype=F32)
         e2 = e.unsqueeze(1).expand(R, 2, d).contiguous()
-        hd_dens = cd["dens_emb"].view(B, 1, d) if cd["dens_emb"] is not None else None
+        hd_dens = dens_emb.reshape(B, 1, d).contiguous() if dens_emb is not None else None
         hip.mod_table(self.hmod, e2, htab, rows_per_batch, 0b10, self.hmdens if hd_dens is not None else None, hd_dens,
                       0xF0 if hd_dens is not None else -1)
         if row_index is not None and sp > 1:
@@ -322,13 +331,22 @@ class DiTEngine:
         for i, p in enumerate(self.blocks):
             T = tab[i]
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
-            hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
-            hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
-                             tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
             if sp > 1:
-                kf, vf = self._gather_kv(qkv, B, lc)
-                hip.attn_fwd(q4, kf, vf, out=ao4)
+                # K|V projection + K norm/RoPE first, all-gather them asynchronously (RCCL over xGMI) and run the
+                # Q projection + Q norm/RoPE underneath the collective
+                hip.gemm(hbuf, p["wqkv"][d:], p["bqkv"][d:], out=qkv[:, d:])
+                hip.rmsnorm_rope(qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc,
+                                 token_offset=tok0, head_dim=hdim)
+                gather = self._gather_kv_start(qkv, B, lc)
+                hip.gemm(hbuf, p["wqkv"][:d], p["bqkv"][:d], out=qkv[:, 0:d])
+                hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc,
+                                 token_offset=tok0, head_dim=hdim)
+                kv = gather.finish()
+                hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4)
             else:
+                hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
+                hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                                 tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
                 hip.attn_fwd(q4, k4, v4, out=ao4)
             hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             # cross-attention on the text context (K/V precomputed per clip)
@@ -336,7 +354,7 @@ class DiTEngine:
             qc = qkv[:, 0:d]
             hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
             hip.rmsnorm_rope(qc, p["cnq"], eps=self.eps)
-            kv = cd["cross_kv"][i]
+            kv = cd["cross_kv"][i][rsel]
             hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4)
             hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
             # FFN
@@ -350,19 +368,18 @@ class DiTEngine:
         return head.view(B, lc, -1)
 
     # ------------------------------------------------------------------ sequence parallel
-    def _gather_kv(self, qkv, B, lc):
-        """All-gather of this block's post-norm, post-RoPE K and V over the sequence-parallel group
-        (RCCL over xGMI, flexam_amd/dist.py).  Returns K, V views [B, L, H, 128]."""
-        from .dist import all_gather_seq
+    def _gather_kv_start(self, qkv, B, lc):
+        """Starts the all-gather of this block's post-norm, post-RoPE K|V over the sequence-parallel group (RCCL over
+        xGMI, flexam_amd/dist.py); .finish() returns [B, L, 2C] with heads packed along the row."""
+        from .dist import SeqGather
         d, sp = self.dim, self.sp_size
         ws = self._ws[(B, lc)]
         if "kv_send" not in ws:
             ws["kv_send"] = torch.empty(B, lc, 2 * d, device=self.device, dtype=BF16)
-            ws["kv_full"] = torch.empty(sp, B, lc, 2 * d, device=self.device, dtype=BF16)
+            ws["kv_full"] = torch.empty(sp * B, lc, 2 * d, device=self.device, dtype=BF16)
             ws["kv_cat"] = torch.empty(B, sp * lc, 2 * d, device=self.device, dtype=BF16)
         ws["kv_send"].copy_(qkv.view(B, lc, 3 * d)[:, :, d:])
-        kv = all_gather_seq(ws["kv_send"], self.sp_group, out=ws["kv_cat"], scratch=ws["kv_full"])
-        return kv[:, :, 0:d].unflatten(2, (self.nh, self.hd)), kv[:, :, d:].unflatten(2, (self.nh, self.hd))
+        return SeqGather(ws["kv_send"], self.sp_group, out=ws["kv_cat"], scratch=ws["kv_full"])
 
     def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
         """All-gather of the head output [B, Lc, 192] -> [B, L, 192] (the reference's one collective,

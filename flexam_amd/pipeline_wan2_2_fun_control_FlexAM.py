@@ -212,13 +212,22 @@ class Wan2_2FunControlPipeline_FlexAM:
         t_rows = (st["uniq"] * t).repeat(st["nrow"])
         skip_uncond = (st["cfg"] and tr.cfg_skip_ratio is not None and tr.num_inference_steps is not None
                        and i >= tr.num_inference_steps * (1 - tr.cfg_skip_ratio))
-        if skip_uncond:
-            raise NotImplementedError("cfg_skip inside the fused sampler is a later-round feature; use transformer.forward")
-        head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"]))
         c, f, h, w = st["shape"]
+        if skip_uncond and eng.cfg_size == 1:
+            # cfg_skip (cfg_optimization.py:5-37): only the conditional row runs and is duplicated, so
+            # uncond + g (cond - uncond) = cond
+            U = st["U"]
+            head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows[:U], st["row_index"][: st["row_index"].numel() // st["nrow"]],
+                                             U, only_row=st["nrow"] - 1))
+            hip.cfg_euler_blend(head[0], None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i), st["latents"], st["known"], st["mask"])
+            return st["latents"]
+        head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"]))
         # head: [rows, L, 192] with rows = (uncond, cond) after the gather, whatever the parallel layout
-        hip.cfg_euler_blend(head[0], head[1] if st["cfg"] else None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i),
-                            st["latents"], st["known"], st["mask"])
+        if skip_uncond:                                  # CFG-parallel ranks: both rows were computed anyway, take cond
+            hip.cfg_euler_blend(head[1], None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i), st["latents"], st["known"], st["mask"])
+        else:
+            hip.cfg_euler_blend(head[0], head[1] if st["cfg"] else None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i),
+                                st["latents"], st["known"], st["mask"])
         return st["latents"]
 
     def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:

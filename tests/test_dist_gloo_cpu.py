@@ -112,3 +112,22 @@ def test_chunk_bounds_requires_even_split():
     assert chunk_bounds(11648, 7, 8) == (10192, 11648)
     with pytest.raises(ValueError):
         chunk_bounds(11648, 0, 5)
+
+
+def _async_gather(rank, world):
+    from flexam_amd.dist import SeqGather, chunk_bounds
+    ok = True
+    for b in (1, 2):
+        l, x = 12, 5
+        full = torch.arange(b * l * x, dtype=torch.float32).view(b, l, x)
+        s, e = chunk_bounds(l, rank, world)
+        g = SeqGather(full[:, s:e].clone())
+        ok = ok and bool(torch.equal(g.finish(), full))
+        out = torch.empty(b, l, x)
+        g = SeqGather(full[:, s:e].clone(), out=out)
+        ok = ok and bool(torch.equal(g.finish(), full))
+    return ok
+
+
+def test_async_seq_gather_both_layouts():
+    assert all(run_world(_async_gather))

@@ -60,3 +60,33 @@ def test_sampler_without_cfg_and_input_checks():
         pipe(height=250, width=256, prompt_embeds=sc["context_cond"])
     with pytest.raises(ValueError):
         pipe(height=256, width=256)
+
+
+def test_sampler_cfg_skip_uses_conditional_row_only():
+    """cfg_skip (cfg_optimization.py:5-37) in the fused loop: for the last half of the steps only the
+    conditional row runs; the result must equal an oracle loop that does v = cond on those steps."""
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    from oracle import sampler as S
+    cfg = dict(O.DIT_TINY)
+    pipe = make_pipe(cfg, 7)
+    sd = C.dit_weights(cfg, 7)
+    sc = C.sampler_case(cfg)
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], sc["mask_pixels"])
+    pipe.transformer.enable_cfg_skip(0.5, 4)
+    out = pipe(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+               num_inference_steps=4, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent")
+    pipe.transformer.disable_cfg_skip()
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    calls = {"n": 0}
+
+    def model(**kw):
+        out_ = O.dit_forward(sd, cfg, **kw)
+        step = calls["n"]
+        calls["n"] += 1
+        return torch.cat([out_[1:], out_[1:]]) if step >= 2 else out_        # duplicated cond row on skipped steps
+    ref = S.denoise_loop(model, S.FlowMatchEulerSchedule(1000, 5.0), 4, sc["latents"], sc["context_uncond"], sc["context_cond"],
+                         sc["control_latents"], sc["additional_control"], ml, sc["masked_video_latents"], sc["ref_latents"], mask, pinned,
+                         0.1, 6.0)
+    p = C.psnr(out.videos.float().cpu(), ref)
+    print(f"cfg_skip sampler: psnr {p:.1f} dB")
+    assert p >= 40.0
