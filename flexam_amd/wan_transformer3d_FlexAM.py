@@ -313,7 +313,7 @@ class WanTransformer3DModel_FlexAM(nn.Module):
     @classmethod
     def from_config(cls, config: dict, **extra):
         import inspect
-        allowed = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        allowed = set(inspect.signature(WanTransformer3DModel_FlexAM.__init__).parameters) - {"self"}
         kw = {k: v for k, v in {**config, **extra}.items() if k in allowed}
         return cls(**kw)
 
