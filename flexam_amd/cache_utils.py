@@ -1,7 +1,7 @@
 """TeaCache bookkeeping (host logic only) with the reference's field names and thresholds
-(FlexAM/models/cache_utils.py:21-76).  The residual re-use inside the DiT forward
-(wan_transformer3d_FlexAM.py:977-1051) is a later-round feature; the state object and
-the coefficient table exist so `enable_teacache` / `share_teacache` keep their signatures."""
+(FlexAM/models/cache_utils.py:21-76).  The decision and the residual re-use inside the DiT forward
+(wan_transformer3d_FlexAM.py:977-1051) live in DiTEngine._teacache_decide / DiTEngine.run; residuals stay on
+the GPU (the reference's `offload=True` moves them to the host every computed step)."""
 import numpy as np
 import torch
 

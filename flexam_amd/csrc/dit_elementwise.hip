@@ -339,6 +339,15 @@ __global__ __launch_bounds__(256) void cfg_euler_blend_kernel(const float* __res
   }
 }
 
+// y = a*x + b*y over n fp32 elements (TeaCache residual bookkeeping, FX.py:1003-1051)
+__global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, float a, const float* __restrict__ x, float b, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 xv = ((const f32x4*)x)[i];
+    f32x4 yv = ((f32x4*)y)[i];
+    ((f32x4*)y)[i] = xv * a + yv * b;
+  }
+}
+
 inline int grid_for(int64_t total, int block) {
   int64_t g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -467,4 +476,10 @@ extern "C" int flexam_cfg_euler_blend(const float* tok_uncond, const float* tok_
   hipLaunchKernelGGL(cfg_euler_blend_kernel, dim3(grid_for((int64_t)C * F * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
                      tok_uncond, tok_cond, ldt, tok0, guidance, dt, latents, known, mask, C, F, H, W);
   return flexam_check_launch("flexam_cfg_euler_blend");
+}
+
+extern "C" int flexam_axpby_f32(float* y, float a, const float* x, float b, int64_t n, void* stream) {
+  FX_REQUIRE(y && x && n > 0 && n % 4 == 0, FLEXAM_E_ARG, "axpby_f32: null pointer or n %% 4 != 0");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, a, x, b, n / 4);
+  return flexam_check_launch("flexam_axpby_f32");
 }

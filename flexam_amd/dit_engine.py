@@ -268,7 +268,7 @@ class DiTEngine:
         return e, e0.view(R, 6, d)
 
     def run(self, x: torch.Tensor, t_rows: torch.Tensor, row_index: Optional[torch.Tensor], rows_per_batch: int,
-            only_row: Optional[int] = None) -> torch.Tensor:
+            only_row: Optional[int] = None, teacache=None, cond_flag: bool = True) -> torch.Tensor:
         """x [Bx, 48, F, H, W] (Bx = B, or 1 when all rows share the latent); t_rows [R] distinct
         timesteps with R = B * rows_per_batch table rows (rows of batch b are b*rows_per_batch ..);
         row_index int32 [B * L] global table row per token, or None (then token (b, l) uses row b).
@@ -318,6 +318,9 @@ class DiTEngine:
         hd_dens = dens_emb.reshape(B, 1, d).contiguous() if dens_emb is not None else None
         hip.mod_table(self.hmod, e2, htab, rows_per_batch, 0b10, self.hmdens if hd_dens is not None else None, hd_dens,
                       0xF0 if hd_dens is not None else -1)
+        calc = True
+        if teacache is not None:
+            calc = self._teacache_decide(teacache, e0, row_index, B, L, cond_flag)
         if row_index is not None and sp > 1:
             from .dist import shard_rows
             row_index = shard_rows(row_index, B, L, rank, sp)
@@ -328,7 +331,13 @@ class DiTEngine:
         k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hdim))
         v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hdim))
         ao4 = ao.view(B, lc, nh, hdim)
-        for i, p in enumerate(self.blocks):
+        if teacache is not None:
+            key = "previous_residual_cond" if cond_flag else "previous_residual_uncond"
+            if not calc:                                   # skipped step: x += residual of the last computed step (FX.py:1003-1006)
+                hip.axpby(xres, 1.0, getattr(teacache, key), 1.0)
+            else:
+                ori = xres.clone()
+        for i, p in enumerate(self.blocks if calc else ()):
             T = tab[i]
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
             if sp > 1:
@@ -361,11 +370,41 @@ class DiTEngine:
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
             hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
             hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
+        if teacache is not None and calc:                  # residual = x_after_blocks - x_before (FX.py:1048-1051), kept on the GPU
+            hip.axpby(ori, 1.0, xres, -1.0)
+            setattr(teacache, key, ori)
         # ---- head
         H = htab[0]
         hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=H[:, 0], scale=H[:, 1], row_index=row_index, rows_per_batch=rpb)
         hip.gemm(hbuf, self.head_w, self.head_b, out=head)
         return head.view(B, lc, -1)
+
+    # ------------------------------------------------------------------ TeaCache
+    @staticmethod
+    def _teacache_decide(tc, e0, row_index, B, L, cond_flag: bool) -> bool:
+        """Step-skipping decision of wan_transformer3d_FlexAM.py:977-1000 (host logic on the tiny AdaLN input).
+        e0 [R, 6, C]; the reference looks at the LAST token's row (`e0[:, -1, :]`) or at e0 itself for 1-D t."""
+        if not cond_flag:
+            return tc.should_calc
+        if row_index is not None:
+            mod_inp = e0[row_index.view(B, L)[:, -1].long()]
+        else:
+            mod_inp = e0
+        if tc.cnt < tc.num_skip_start_steps:
+            calc = True
+            tc.accumulated_rel_l1_distance = 0
+        else:
+            prev = tc.previous_modulated_input
+            rel = ((mod_inp - prev).abs().mean() / prev.abs().mean()).item()
+            tc.accumulated_rel_l1_distance += tc.rescale_func(rel)
+            if tc.accumulated_rel_l1_distance < tc.rel_l1_thresh:
+                calc = False
+            else:
+                calc = True
+                tc.accumulated_rel_l1_distance = 0
+        tc.previous_modulated_input = mod_inp.clone()
+        tc.should_calc = calc
+        return calc
 
     # ------------------------------------------------------------------ sequence parallel
     def _gather_kv_start(self, qkv, B, lc):

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "flexam_patchify": ([_P, _I, _I, _I, _I, _I, _P, _L, _I, _L, _P], c_int),
     "flexam_unpatchify": ([_P, _L, _L, _I, _I, _I, _I, _P, _I, _P], c_int),
     "flexam_cfg_euler_blend": ([_P, _P, _L, _L, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P], c_int),
+    "flexam_axpby_f32": ([_P, _F, _P, _F, _L, _P], c_int),
     "flexam_pack_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_unpack_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _P], c_int),
     "flexam_groupnorm_silu_cl": ([_P, _L, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _I, _P], c_int),
@@ -256,6 +257,14 @@ def cfg_euler_blend(tok_uncond, tok_cond, tok0, guidance, dt, latents, known=Non
                                         _ptr(latents, F32), _ptr(known, F32), _ptr(mask, F32), C, F, H, W, _stream()),
            "flexam_cfg_euler_blend")
     return latents
+
+
+def axpby(y, a, x, b):
+    """y = a*x + b*y (fp32, same shape, contiguous)."""
+    if y.shape != x.shape or not y.is_contiguous() or not x.is_contiguous():
+        raise RuntimeError("axpby: contiguous tensors of equal shape required")
+    _check(lib().flexam_axpby_f32(_ptr(y, F32), a, _ptr(x, F32), b, y.numel(), _stream()), "flexam_axpby_f32")
+    return y
 
 
 # ----------------------------------------------------------------------------- channels-last conv helpers

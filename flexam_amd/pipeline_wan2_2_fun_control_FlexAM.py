@@ -221,7 +221,12 @@ class Wan2_2FunControlPipeline_FlexAM:
                                              U, only_row=st["nrow"] - 1))
             hip.cfg_euler_blend(head[0], None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i), st["latents"], st["known"], st["mask"])
             return st["latents"]
-        head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"]))
+        tc = tr.teacache
+        head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"], teacache=tc))
+        if tc is not None:
+            tc.cnt += 1
+            if tc.cnt == tc.num_steps:
+                tc.reset()
         # head: [rows, L, 192] with rows = (uncond, cond) after the gather, whatever the parallel layout
         if skip_uncond:                                  # CFG-parallel ranks: both rows were computed anyway, take cond
             hip.cfg_euler_blend(head[1], None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i), st["latents"], st["known"], st["mask"])

@@ -298,9 +298,11 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         else:
             rows, index, U = self._timestep_rows(t, B, L, ref_len)
             index = index.to(eng.device)
-        if self.teacache is not None:
-            raise NotImplementedError("TeaCache step skipping is a later-round feature (SURVEY 8f3); disable_teacache()")
-        head_local = eng.run(x, rows, index, U)
+        head_local = eng.run(x, rows, index, U, teacache=self.teacache, cond_flag=cond_flag)
+        if self.teacache is not None and cond_flag:          # FX.py:1119-1122
+            self.teacache.cnt += 1
+            if self.teacache.cnt == self.teacache.num_steps:
+                self.teacache.reset()
         tokens = eng.gather_tokens(head_local)
         from . import hip
         c, f, h, w = x.shape[1:]

@@ -121,6 +121,10 @@ int flexam_unpatchify(const float* tok, int64_t ldt, int64_t tok0, int C, int F,
 int flexam_cfg_euler_blend(const float* tok_uncond, const float* tok_cond, int64_t ldt, int64_t tok0, float guidance, float dt,
                            float* latents, const float* known, const float* mask, int C, int F, int H, int W, void* stream);
 
+/* y[i] = a*x[i] + b*y[i], fp32, n % 4 == 0.  TeaCache bookkeeping: residual = x_after_blocks - x_before and
+ * x += cached residual on skipped steps (wan_transformer3d_FlexAM.py:1003-1051). */
+int flexam_axpby_f32(float* y, float a, const float* x, float b, int64_t n, void* stream);
+
 /* Channels-last helpers around the implicit-GEMM convolutions (cnn-block: wan_transformer3d_FlexAM.py:
  * 680-705,869-881; VAE decoder: wan_vae3_8.py).  A conv input is a spatially zero-padded bf16 image
  * img[f][H+2][W+2][Cp]; tap (dh,dw) of a 3x3 kernel is then the constant A offset

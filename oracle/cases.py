@@ -76,6 +76,10 @@ def block_weights(dim: int, ffn: int, seed: int = 12) -> Dict[str, Tensor]:
     return O.seeded_state_dict(shapes, seed)
 
 
+TEACACHE_CASE = dict(coefficients=[1.0, 0.0], num_steps=6, thresh=2.0, skip_start=1,
+                     t_values=[950.0, 900.0, 880.0, 860.0, 500.0, 480.0])
+
+
 # ----------------------------------------------------------------------------- sampler case (BASELINE config 1)
 def sampler_case(cfg: dict, seed: int = 21, frames: int = 3, h: int = 16, w: int = 16) -> dict:
     """9x256x256 -> latent [1,48,3,16,16]; motion_transfer mask (frame 0 known)."""

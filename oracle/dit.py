@@ -194,11 +194,32 @@ def text_embed(sd, cfg, context: List[Tensor]) -> Tensor:
     return linear(sd, "text_embedding.2", F.gelu(linear(sd, "text_embedding.0", ctx), approximate="tanh"))
 
 
+# ----------------------------------------------------------------------------- TeaCache (FX.py:977-1051, cache_utils.py:21-76)
+def teacache_state(coefficients, num_steps: int, rel_l1_thresh: float, num_skip_start_steps: int = 0) -> dict:
+    import numpy as np
+    return dict(rescale=np.poly1d(coefficients), num_steps=num_steps, thresh=rel_l1_thresh, skip_start=num_skip_start_steps,
+                cnt=0, acc=0.0, prev_mod=None, residual=None, should_calc=True)
+
+
+def _teacache_decide(tc: dict, e0: Tensor) -> bool:
+    mod_inp = e0[:, -1, :] if e0.dim() > 3 else e0                              # FX.py:980-983
+    if tc["cnt"] < tc["skip_start"]:
+        calc, tc["acc"] = True, 0.0
+    else:
+        rel = ((mod_inp - tc["prev_mod"]).abs().mean() / tc["prev_mod"].abs().mean()).item()
+        tc["acc"] += float(tc["rescale"](rel))
+        calc = not (tc["acc"] < tc["thresh"])
+        if calc:
+            tc["acc"] = 0.0
+    tc["prev_mod"], tc["should_calc"] = mod_inp, calc
+    return calc
+
+
 # ----------------------------------------------------------------------------- full forward
 def dit_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, context: List[Tensor], seq_len: int,
                 y: Optional[Tensor] = None, full_ref: Optional[Tensor] = None,
                 additional_control: Optional[Tensor] = None, density: Optional[Tensor] = None,
-                taps: Optional[dict] = None) -> Tensor:
+                taps: Optional[dict] = None, teacache: Optional[dict] = None) -> Tensor:
     """WanTransformer3DModel_FlexAM.forward, FX.py:817-1123 (inference, sp=1, no TeaCache, no
     camera adapter, no subject_ref, clip_fea=None -- the FlexAM 5B call contract).
 
@@ -233,10 +254,21 @@ def dit_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, context:
     angles = rope_angles(1024, dim // nh)
     if taps is not None:
         taps.update(x_embed=x.clone(), e=e, e0=e0, dens0=dens0, context=ctx)
-    for i in range(nl):
-        x = block_forward(sd, f"blocks.{i}", x, e0, dens0, grid, angles, ctx, nh, eps)
-        if taps is not None:
-            taps[f"block{i}"] = x.clone()
+    calc = True if teacache is None else _teacache_decide(teacache, e0)
+    if not calc:
+        x = x + teacache["residual"]                                              # FX.py:1003-1006
+    else:
+        x_in = x
+        for i in range(nl):
+            x = block_forward(sd, f"blocks.{i}", x, e0, dens0, grid, angles, ctx, nh, eps)
+            if taps is not None:
+                taps[f"block{i}"] = x.clone()
+        if teacache is not None:
+            teacache["residual"] = x - x_in                                       # FX.py:1048-1051
+    if teacache is not None:                                                      # FX.py:1119-1122
+        teacache["cnt"] += 1
+        if teacache["cnt"] == teacache["num_steps"]:
+            teacache.update(cnt=0, acc=0.0, prev_mod=None, residual=None, should_calc=True)
     x = head_forward(sd, x, e, dens, eps)                                         # FX.py:1101
     if "ref_conv.weight" in sd and full_ref is not None:                          # FX.py:1106-1109
         x = x[:, r.size(1):]

@@ -12,6 +12,7 @@ Fixtures:
   g4_dit_tokent      tiny Wan2_2Transformer3DModel_FlexAM, per-token t, all FlexAM inputs      FX.py:817-1123
   g4b_dit_nonsquare  same as g4 on a non-square latent [2,48,3,8,24] (catches h/w swaps)
   g5_dit_scalart     same, 1-D t branch                                                         FX.py:941-944
+  g6_teacache        6 forwards with TeaCache on (identity rescale, threshold 2.0): computed and skipped steps  FX.py:977-1051
   g7_vae_decode      small AutoencoderKLWan2_2_ decode [1,48,3,4,6] -> [1,3,9,64,96] + taps    VAE.py:820-849
   g9_sampler         4-step CFG/Euler/blend trace at latent [1,48,3,16,16] driving the
                      reference DiT module through oracle.sampler.denoise_loop                  PIPE.py:840-949
@@ -107,6 +108,17 @@ def main():
         flat = {k: v for k, v in case.items() if torch.is_tensor(v)}
         flat.update({f"ctx{i}": u for i, u in enumerate(case["context"])})
         _save(name, dict(out=out, in_sum=C.checksum(flat), w_sum=C.checksum(sd)))
+
+    # ---- G6 TeaCache: 6 calls, identity rescale, threshold 2.0 -> calc / skip / skip / calc / skip / calc
+    m.enable_teacache(C.TEACACHE_CASE["coefficients"], C.TEACACHE_CASE["num_steps"], rel_l1_thresh=C.TEACACHE_CASE["thresh"],
+                      num_skip_start_steps=C.TEACACHE_CASE["skip_start"], offload=False)
+    outs, calcs = [], []
+    for tv in C.TEACACHE_CASE["t_values"]:
+        outs.append(m(**C.dit_case(cfg, 41, per_token_t=True, t_value=tv)))
+        calcs.append(float(m.should_calc))
+    m.disable_teacache()
+    assert calcs == [1.0, 0.0, 0.0, 1.0, 0.0, 1.0], calcs
+    _save("g6_teacache", dict(outs=torch.stack(outs), should_calc=torch.tensor(calcs), w_sum=C.checksum(sd)))
 
     # ---- G9 sampler trace (reference DiT module inside the restated loop)
     sc_ = C.sampler_case(cfg)

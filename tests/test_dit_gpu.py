@@ -77,3 +77,19 @@ def test_dit_ragged_tokens_and_cfg_skip():
     torch.testing.assert_close(out[0], out[1])
     check(out[1:], want[1:], "dit cfg_skip row")
     m.disable_cfg_skip()
+
+
+def test_dit_teacache_matches_reference_golden(golden):
+    """TeaCache on the HIP path: same calc/skip decisions as the reference and PSNR >= 40 dB on computed and
+    skipped steps (golden G6: calc, skip, skip, calc, skip, calc)."""
+    fx = golden("g6_teacache")
+    cfg = dict(O.DIT_TINY)
+    m, _ = build(cfg, 7)
+    tcase = C.TEACACHE_CASE
+    m.enable_teacache(tcase["coefficients"], tcase["num_steps"], rel_l1_thresh=tcase["thresh"], num_skip_start_steps=tcase["skip_start"])
+    for i, tv in enumerate(tcase["t_values"]):
+        out = m(**to_dev(C.dit_case(cfg, 41, per_token_t=True, t_value=tv)))
+        assert float(m.teacache.should_calc) == float(fx["should_calc"][i]) or m.teacache.cnt == 0, f"step {i}"
+        check(out, fx["outs"][i], f"teacache step {i} ({'calc' if fx['should_calc'][i] else 'skip'})")
+    assert m.teacache.cnt == 0
+    m.disable_teacache()

@@ -129,3 +129,18 @@ def test_g9_sampler_trace(golden):
     torch.testing.assert_close(final, fx["final"], rtol=1e-3, atol=1e-4)
     # frame 0 stays pinned to the known latent after every step (PIPE.py:933-934)
     torch.testing.assert_close(final[:, :, 0], sc["masked_video_latents"][:, :, 0])
+
+
+def test_g6_teacache(golden):
+    """TeaCache (FX.py:977-1051): decisions and outputs of computed AND skipped steps vs the reference."""
+    fx = golden("g6_teacache")
+    cfg = dict(O.DIT_TINY)
+    sd = C.dit_weights(cfg, 7)
+    _same_problem(fx, "w_sum", sd)
+    tcase = C.TEACACHE_CASE
+    tc = O.teacache_state(tcase["coefficients"], tcase["num_steps"], tcase["thresh"], tcase["skip_start"])
+    for i, tv in enumerate(tcase["t_values"]):
+        out = O.dit_forward(sd, cfg, **C.dit_case(cfg, 41, per_token_t=True, t_value=tv), teacache=tc)
+        assert float(tc["should_calc"]) == float(fx["should_calc"][i]) or tc["cnt"] == 0
+        torch.testing.assert_close(out, fx["outs"][i], **TOL)
+    assert tc["cnt"] == 0                                     # reset after num_steps calls (FX.py:1121-1122)
