@@ -185,6 +185,82 @@ __global__ __launch_bounds__(256) void pack_affine_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Encoder side (wan_vae3_8.py:285-301 patchify, :104-113 downsample convs, :321-372 AvgDown3D).
+// video[c][f0 + t][2h + q][2w + r] -> image interior (t + t0, h, w), channel c*4 + r*2 + q
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vae_patchify_kernel(const float* __restrict__ video, int Ftot, int f0, int T, int H, int W,
+                                                           bf16* __restrict__ dst, int Cp, int t0) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t total = (int64_t)3 * T * (2 * H) * (2 * W);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % (2 * W));
+    int64_t r = i / (2 * W);
+    const int y = (int)(r % (2 * H));
+    r /= (2 * H);
+    const int t = (int)(r % T);
+    const int c = (int)(r / T);
+    const float v = video[(((int64_t)c * Ftot + f0 + t) * (2 * H) + y) * (2 * W) + x];
+    dst[(((int64_t)(t + t0) * Hp + (y >> 1) + 1) * Wp + (x >> 1) + 1) * Cp + c * 4 + (x & 1) * 2 + (y & 1)] = f2bf(v);
+  }
+}
+
+// rows [(t, hp, wp), ld] at H x W -> space-to-depth image at H/2 x W/2 with 4 sub-pixel channel groups:
+//   dst[(t + t0, h2 + 1, w2 + 1), (a*2 + b)*Cs + c] = src[(t, 2*h2 + a + 1, 2*w2 + b + 1), c]
+// so ZeroPad2d((0,1,0,1)) + Conv2d(3x3, stride 2) becomes a unit-stride implicit GEMM whose 9 taps
+// address (row offset th, col offset tw, channel group) of this image; its zero border at h2 = H/2,
+// w2 = W/2 is exactly the reference's right/bottom zero pad.
+template <typename TI>
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
+                                                             bf16* __restrict__ dst, int Cs, int t0) {
+  const int Hp = H + 2, Wp = W + 2, H2p = H / 2 + 2, W2p = W / 2 + 2;
+  const int cvec = C >> 2;
+  const int64_t total = (int64_t)T * H * W * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cvec) * 4;
+    int64_t r = i / cvec;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int t = (int)(r / H);
+    const TI* s = src + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * lds_ + c;
+    bf16x4 o;
+    o[0] = f2bf(ld(s));
+    o[1] = f2bf(ld(s + 1));
+    o[2] = f2bf(ld(s + 2));
+    o[3] = f2bf(ld(s + 3));
+    *(bf16x4*)(dst + ((((int64_t)(t + t0) * H2p + (h >> 1) + 1) * W2p + (w >> 1) + 1) * 4 + (h & 1) * 2 + (w & 1)) * Cs + c) = o;
+  }
+}
+
+// x_main[(to, ho, wo), co] += mean_{k < g} x_in[(to*ft + st - pad_t, ho*fs + sh, wo*fs + sw), c]      (AvgDown3D)
+//   flat = co*g + k,  c = flat / (ft*fs*fs),  (st, sh, sw) = digits of flat % (ft*fs*fs);  frames < 0 are the zero front pad
+__global__ __launch_bounds__(256) void avgdown_add_kernel(float* __restrict__ xm, int64_t ldm, int Co, int To, int Ho, int Wo,
+                                                          const float* __restrict__ xin, int64_t ldi, int Ci, int ft, int fs, int pad_t) {
+  const int Hp = Ho * fs + 2, Wp = Wo * fs + 2, Hop = Ho + 2, Wop = Wo + 2;
+  const int factor = ft * fs * fs;
+  const int g = Ci * factor / Co;
+  const float inv = 1.f / (float)g;
+  const int64_t total = (int64_t)To * Ho * Wo * Co;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Co);
+    int64_t r = i / Co;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int to = (int)(r / Ho);
+    float acc = 0.f;
+    for (int k = 0; k < g; ++k) {
+      const int flat = co * g + k;
+      const int c = flat / factor, rem = flat - c * factor;
+      const int st = rem / (fs * fs), sh = (rem / fs) % fs, sw = rem % fs;
+      const int t = to * ft + st - pad_t;
+      if (t >= 0) acc += xin[(((int64_t)t * Hp + ho * fs + sh + 1) * Wp + wo * fs + sw + 1) * ldi + c];
+    }
+    xm[(((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + co] += acc * inv;
+  }
+}
+
 }  // namespace
 
 extern "C" int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, const float* gamma,
@@ -251,4 +327,36 @@ extern "C" int flexam_pack_affine_cl(const float* src, int C, int T, int H, int 
   hipLaunchKernelGGL(pack_affine_kernel, dim3(grid_for((int64_t)T * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, src, C, T, H, W,
                      mul, add, (bf16*)dst, Cp);
   return flexam_check_launch("flexam_pack_affine_cl");
+}
+
+extern "C" int flexam_vae_patchify_cl(const float* video, int Ftot, int f0, int T, int H, int W, void* dst, int Cp, int t0, void* stream) {
+  FX_REQUIRE(video && dst && Cp >= 12, FLEXAM_E_ARG, "vae_patchify_cl: bad arguments");
+  FX_REQUIRE(f0 >= 0 && T > 0 && f0 + T <= Ftot && H > 0 && W > 0, FLEXAM_E_SHAPE, "vae_patchify_cl: frames %d+%d exceed %d", f0, T, Ftot);
+  hipLaunchKernelGGL(vae_patchify_kernel, dim3(grid_for((int64_t)12 * T * H * W, 256)), dim3(256), 0, (hipStream_t)stream, video, Ftot, f0,
+                     T, H, W, (bf16*)dst, Cp, t0);
+  return flexam_check_launch("flexam_vae_patchify_cl");
+}
+
+extern "C" int flexam_space_to_depth_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, void* dst, int Cs,
+                                        int t0, void* stream) {
+  FX_REQUIRE(src && dst, FLEXAM_E_ARG, "space_to_depth_cl: null pointer");
+  FX_REQUIRE(C % 4 == 0 && C <= Cs && Cs % 4 == 0 && C <= ld_src && H % 2 == 0 && W % 2 == 0 && T > 0, FLEXAM_E_SHAPE,
+             "space_to_depth_cl: bad shape C=%d Cs=%d H=%d W=%d", C, Cs, H, W);
+  const int64_t total = (int64_t)T * H * W * (C / 4);
+  if (src_is_bf16)
+    hipLaunchKernelGGL(space_to_depth_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cs, t0);
+  else
+    hipLaunchKernelGGL(space_to_depth_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, (bf16*)dst, Cs, t0);
+  return flexam_check_launch("flexam_space_to_depth_cl");
+}
+
+extern "C" int flexam_avgdown_add_cl(float* x_main, int64_t ld_main, int Co, int To, int Ho, int Wo, const float* x_in, int64_t ld_in,
+                                     int Ci, int Ti, int ft, int fs, void* stream) {
+  FX_REQUIRE(x_main && x_in, FLEXAM_E_ARG, "avgdown_add_cl: null pointer");
+  FX_REQUIRE((ft == 1 || ft == 2) && (fs == 1 || fs == 2) && (Ci * ft * fs * fs) % Co == 0, FLEXAM_E_SHAPE, "avgdown_add_cl: bad factors");
+  const int pad_t = (ft - Ti % ft) % ft;
+  FX_REQUIRE((Ti + pad_t) / ft == To, FLEXAM_E_SHAPE, "avgdown_add_cl: %d input frames do not give %d output frames", Ti, To);
+  hipLaunchKernelGGL(avgdown_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * Co, 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
+                     Co, To, Ho, Wo, x_in, ld_in, Ci, ft, fs, pad_t);
+  return flexam_check_launch("flexam_avgdown_add_cl");
 }

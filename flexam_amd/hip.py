@@ -45,6 +45,9 @@ _SIGNATURES = {
     "flexam_scatter_add_cl": ([_P, _L, _P, _L, _I, _I, _I, _I, _P], c_int),
     "flexam_vae_unpatchify_clamp": ([_P, _L, _I, _I, _I, _P, _I, _I, _F, _F, _P], c_int),
     "flexam_pack_affine_cl": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
+    "flexam_vae_patchify_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
+    "flexam_space_to_depth_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
+    "flexam_avgdown_add_cl": ([_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P], c_int),
 }
 
 _lib = None
@@ -340,3 +343,25 @@ def pack_affine_cl(src, mul, add, dst):
     _check(lib().flexam_pack_affine_cl(_ptr(src.contiguous(), F32), C, T, H, W, _ptr(mul, F32), _ptr(add, F32), _ptr(dst, BF16),
                                        dst.shape[-1], _stream()), "flexam_pack_affine_cl")
     return dst
+
+
+# ----------------------------------------------------------------------------- VAE encoder helpers
+def vae_patchify_cl(video, f0, T, dst, t0=0):
+    """video [3, Ftot, 2H, 2W] fp32 frames f0..f0+T -> dst image [*, H+2, W+2, Cp] frames t0.., 12 channels (c r q)."""
+    _, ftot, h2, w2 = video.shape
+    _check(lib().flexam_vae_patchify_cl(_ptr(video, F32), ftot, f0, T, h2 // 2, w2 // 2, _ptr(dst, BF16), dst.shape[-1], t0, _stream()),
+           "flexam_vae_patchify_cl")
+    return dst
+
+
+def space_to_depth_cl(src, C, T, H, W, dst, Cs, t0=0):
+    """src rows [T*(H+2)*(W+2), ld] -> dst image [*, H/2+2, W/2+2, 4*Cs]."""
+    _check(lib().flexam_space_to_depth_cl(_ptr(src), 1 if src.dtype == BF16 else 0, src.stride(0), C, T, H, W, _ptr(dst, BF16), Cs, t0,
+                                          _stream()), "flexam_space_to_depth_cl")
+    return dst
+
+
+def avgdown_add_cl(x_main, Co, To, Ho, Wo, x_in, Ci, Ti, ft, fs):
+    _check(lib().flexam_avgdown_add_cl(_ptr(x_main, F32), x_main.stride(0), Co, To, Ho, Wo, _ptr(x_in, F32), x_in.stride(0), Ci, Ti, ft, fs,
+                                       _stream()), "flexam_avgdown_add_cl")
+    return x_main

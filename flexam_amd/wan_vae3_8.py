@@ -1,9 +1,9 @@
-"""MI355X drop-in for `AutoencoderKLWan3_8` (Wan2.2 3D-VAE, z = 48, 4x16x16) -- decode path.
+"""MI355X drop-in for `AutoencoderKLWan3_8` (Wan2.2 3D-VAE, z = 48, 4x16x16) -- decode and encode paths.
 
 Reference: FlexAM/models/wan_vae3_8.py (:892-1079 wrapper, :739-870 chunked model, :621-728 decoder).
-State-dict keys are the reference's (`model.decoder...`, `model.conv2...`; a full Wan2.2_VAE.pth loads
-with strict=False exactly as VAE.py:1073-1077 does -- encoder keys are ignored until the encode path,
-the next scope row, lands).  `decode(z).sample` runs entirely in libflexam_hip.so:
+State-dict keys are the reference's (`model.encoder...`, `model.conv1...`, `model.decoder...`,
+`model.conv2...`; a full Wan2.2_VAE.pth loads as VAE.py:1073-1077 does).  `decode(z).sample` and
+`encode(x).latent_dist` run entirely in libflexam_hip.so:
 
   * activations are channels-last; every causal 3x3x3 / 3x3 convolution is ONE flexam_gemm_bf16
     launch over a zero-bordered bf16 image with a per-K-block tap-offset table (implicit GEMM, no
@@ -13,7 +13,12 @@ the next scope row, lands).  `decode(z).sample` runs entirely in libflexam_hip.s
     DESIGN.md "VAE chunk cache";
   * RMS_norm + SiLU, nearest-2x upsample (+ frame de-interleave), DupUp3D shortcut, the middle
     attention (head_dim = C, as three GEMMs + a row softmax) and unpatchify + clamp are one-pass
-    bandwidth kernels (csrc/vae.hip); the residual stream between blocks stays fp32.
+    bandwidth kernels (csrc/vae.hip); the residual stream between blocks stays fp32;
+  * encode (VAE.py:788-818, Encoder3d :505-618): patchify writes the 12-channel conv1 image directly; the
+    stride-2 spatial convs run as unit-stride implicit GEMMs over a space-to-depth image (the 9 taps address
+    (row, col, sub-pixel channel group)); the stride-2 temporal conv is one GEMM per output frame over the
+    same history image; AvgDown3D shortcuts are a fused gather-mean-add; the final 1x1 conv and the latent
+    normalisation are folded into the head conv's weights (exact in fp32, one GEMM fewer).
 """
 import math
 from typing import Dict, List, Optional
@@ -40,6 +45,36 @@ LATENT_STD = [0.4765, 1.0364, 0.4514, 1.1677, 0.5313, 0.4990, 0.4818, 0.5013, 0.
 class DecoderOutput:
     def __init__(self, sample):
         self.sample = sample
+
+
+class DiagonalGaussianDistribution:
+    """The posterior object `encode` returns (diffusers' class of the same name, used by VAE.py:1034):
+    parameters = [mean | logvar] along dim 1, logvar clamped to [-30, 20]."""
+
+    def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.parameters.device, dtype=self.parameters.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
+class AutoencoderKLOutput:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
+
+    def __getitem__(self, i):
+        return (self.latent_dist,)[i]
 
 
 def _round_up(v, m):
@@ -79,6 +114,42 @@ def decoder_param_shapes(z_dim=48, dec_dim=256, dim_mult=(1, 2, 4, 4), temporal_
                 conv(f"decoder.upsamples.{i}.upsamples.3.time_conv", co * 2, co, (3, 1, 1))
     s["decoder.head.0.gamma"] = (dims[-1], 1, 1, 1)
     conv("decoder.head.2", 12, dims[-1], (3, 3, 3))
+    return s
+
+
+def encoder_param_shapes(z_dim=48, dim=160, dim_mult=(1, 2, 4, 4), temporal_down=(False, True, True)) -> Dict[str, tuple]:
+    """Parameter inventory of conv1 + Encoder3d under the reference's names (VAE.py:505-562, :757-758)."""
+    dims = [dim * m for m in [1] + list(dim_mult)]
+    s: Dict[str, tuple] = {}
+
+    def conv(name, co, ci, k):
+        s[name + ".weight"], s[name + ".bias"] = (co, ci, *k), (co,)
+
+    def res(name, ci, co):
+        s[name + ".residual.0.gamma"] = (ci, 1, 1, 1)
+        conv(name + ".residual.2", co, ci, (3, 3, 3))
+        s[name + ".residual.3.gamma"] = (co, 1, 1, 1)
+        conv(name + ".residual.6", co, co, (3, 3, 3))
+        if ci != co:
+            conv(name + ".shortcut", co, ci, (1, 1, 1))
+    conv("conv1", z_dim * 2, z_dim * 2, (1, 1, 1))
+    conv("encoder.conv1", dims[0], 12, (3, 3, 3))
+    n_stage = len(dims) - 1
+    for i, (ci, co) in enumerate(zip(dims[:-1], dims[1:])):
+        q = f"encoder.downsamples.{i}.downsamples"
+        res(f"{q}.0", ci, co)
+        res(f"{q}.1", co, co)
+        if i != n_stage - 1:
+            conv(f"{q}.2.resample.1", co, co, (3, 3))
+            if i < len(temporal_down) and temporal_down[i]:
+                conv(f"{q}.2.time_conv", co, co, (3, 1, 1))
+    res("encoder.middle.0", dims[-1], dims[-1])
+    s["encoder.middle.1.norm.gamma"] = (dims[-1], 1, 1)
+    conv("encoder.middle.1.to_qkv", dims[-1] * 3, dims[-1], (1, 1))
+    conv("encoder.middle.1.proj", dims[-1], dims[-1], (1, 1))
+    res("encoder.middle.2", dims[-1], dims[-1])
+    s["encoder.head.0.gamma"] = (dims[-1], 1, 1, 1)
+    conv("encoder.head.2", z_dim * 2, dims[-1], (3, 3, 3))
     return s
 
 
@@ -145,71 +216,100 @@ class _Conv:
             out = hip.gemm_gate_residual(a, self.weight, self.bias, residual_into, a_koff=self._koff)
         else:
             out = hip.gemm(a, self.weight, self.bias, a_koff=self._koff, m=rows, k=self.weight.shape[1], out_dtype=out_dtype)
+        self.roll(t)
+        return out
+
+    def roll(self, t):
+        """The last `hist` frames become the history of the next chunk."""
         if self.hist:
             src = self.img[t:t + self.hist]
             self.img[:self.hist].copy_(src.clone() if t < self.hist else src)
+
+    def run_time_stride2(self, t, h, w, out_dtype=F32):
+        """(3,1,1) conv with temporal stride 2 and one cached frame (Resample downsample3d, VAE.py:162-174):
+        output frame j reads [prev | x][2j .. 2j+2] = image frames 1+2j .. 3+2j; one GEMM per output frame."""
+        if t % 2 or (self.kt, self.kh, self.kw) != (3, 1, 1):
+            raise RuntimeError("run_time_stride2: needs an even frame count and a (3,1,1) kernel")
+        rows = (h + 2) * (w + 2)
+        out = torch.empty(t // 2 * rows, self.co, device=self.device, dtype=out_dtype)
+        for j in range(t // 2):
+            hip.gemm(self.img[1 + 2 * j:].reshape(-1, self.cp), self.weight, self.bias, a_koff=self._koff, m=rows, k=self.weight.shape[1],
+                     out=out[j * rows:(j + 1) * rows])
+        self.roll(t)
         return out
 
 
-class _DecoderEngine:
-    def __init__(self, vae):
-        sd = {k: v for k, v in vae.model.state_dict().items()}
+class _ConvS2D:
+    """ZeroPad2d((0,1,0,1)) + Conv2d(3x3, stride 2) (Resample downsample2d/3d, VAE.py:104-113) as a unit-stride
+    implicit GEMM over a space-to-depth image [t, H/2+2, W/2+2, 4*Cs]: tap (dh, dw) of the strided conv is
+    (row dh>>1, col dw>>1, channel group (dh&1)*2 + (dw&1)) of that image."""
+
+    def __init__(self, weight, bias, device, t_cap: int):
+        w = weight.detach().to(device, F32)
+        co, ci, kh, kw = w.shape
+        assert (kh, kw) == (3, 3)
+        self.co, self.ci, self.cs = co, ci, _round_up(ci, 64)
+        wp = torch.zeros(co, 3, 3, self.cs, device=device, dtype=F32)
+        wp[..., :ci] = w.permute(0, 2, 3, 1)
+        self.weight = wp.reshape(co, 9 * self.cs).to(BF16).contiguous()
+        self.bias = bias.detach().to(device, F32).contiguous()
+        self.t_cap, self.device, self.shape = t_cap, device, None
+
+    def image(self, h2, w2):
+        """h2, w2: OUTPUT resolution."""
+        if self.shape != (h2, w2):
+            hp, wp, c4 = h2 + 2, w2 + 2, 4 * self.cs
+            guard = (wp + 2) * c4
+            self.buf = torch.zeros(self.t_cap * hp * wp * c4 + guard, device=self.device, dtype=BF16)
+            self.img = self.buf[:self.t_cap * hp * wp * c4].view(self.t_cap, hp, wp, c4)
+            offs = []
+            for dh in range(3):
+                for dw in range(3):
+                    base = (((dh >> 1) * wp + (dw >> 1)) * 4 + (dh & 1) * 2 + (dw & 1)) * self.cs
+                    offs += [base + cb * 64 for cb in range(self.cs // 64)]
+            self._koff = torch.tensor(offs, dtype=I64, device=self.device)
+            self.shape = (h2, w2)
+        return self.img
+
+    def run(self, t, h2, w2, out_dtype=F32):
+        return hip.gemm(self.img.view(-1, 4 * self.cs), self.weight, self.bias, a_koff=self._koff, m=t * (h2 + 2) * (w2 + 2),
+                        k=self.weight.shape[1], out_dtype=out_dtype)
+
+
+class _EngineBase:
+    """Blocks shared by the decoder and the encoder: ResidualBlock and the middle AttentionBlock."""
+
+    def _setup(self, vae):
+        self.sd = sd = {k: v for k, v in vae.model.state_dict().items()}
         self.device = dev = next(vae.model.parameters()).device
         if dev.type != "cuda":
-            raise RuntimeError("flexam_amd: the VAE decoder runs only on a GPU through libflexam_hip.so (no CPU fallback)")
+            raise RuntimeError("flexam_amd: the VAE runs only on a GPU through libflexam_hip.so (no CPU fallback)")
         hip.device_check()
-        cfg = vae._arch
-        self.z_dim, self.temporal_up = cfg["z_dim"], tuple(cfg["temporal_up"])
-        dims = [cfg["dec_dim"] * m for m in [cfg["dim_mult"][-1]] + list(cfg["dim_mult"][::-1])]
-        self.dims = dims
-        f32 = lambda t: t.detach().to(dev, F32).reshape(-1).contiguous()
-        tmul = [1]
-        for up in self.temporal_up:
-            tmul.append(tmul[-1] * (2 if up else 1))                       # frames per chunk entering stage i
-
-        def conv(name, t_cap=1):
-            return _Conv(sd[name + ".weight"], sd[name + ".bias"], dev, t_cap)
-
-        def res(name, t_cap):
-            d = dict(g0=f32(sd[name + ".residual.0.gamma"]), c1=conv(name + ".residual.2", t_cap), g3=f32(sd[name + ".residual.3.gamma"]),
-                     c2=conv(name + ".residual.6", t_cap))
-            d["short"] = conv(name + ".shortcut", t_cap) if (name + ".shortcut.weight") in sd else None
-            return d
-        self.conv2 = conv("conv2")
-        self.conv1 = conv("decoder.conv1")
-        self.mid = [res("decoder.middle.0", 1), None, res("decoder.middle.2", 1)]
-        c = dims[0]
-        wqkv = sd["decoder.middle.1.to_qkv.weight"].detach().to(dev, F32).reshape(3 * c, c)
-        self.attn = dict(gamma=f32(sd["decoder.middle.1.norm.gamma"]), wqkv=wqkv.to(BF16).contiguous(),
-                         bqkv=f32(sd["decoder.middle.1.to_qkv.bias"]), wv=wqkv[2 * c:].to(BF16).contiguous(),
-                         bv=f32(sd["decoder.middle.1.to_qkv.bias"])[2 * c:].contiguous(),
-                         wproj=sd["decoder.middle.1.proj.weight"].detach().to(dev, BF16).reshape(c, c).contiguous(),
-                         bproj=f32(sd["decoder.middle.1.proj.bias"]))
-        self.stages = []
-        n_stage = len(dims) - 1
-        for i in range(n_stage):
-            p = f"decoder.upsamples.{i}.upsamples"
-            st = dict(res=[res(f"{p}.{j}", tmul[i]) for j in range(3)], up=i != n_stage - 1, cout=dims[i + 1])
-            if st["up"]:
-                st["temporal"] = bool(self.temporal_up[i])
-                st["resample"] = conv(f"{p}.3.resample.1", tmul[i] * (2 if st["temporal"] else 1))
-                st["time_conv"] = conv(f"{p}.3.time_conv", tmul[i]) if st["temporal"] else None
-            self.stages.append(st)
-        self.head_gamma = f32(sd["decoder.head.0.gamma"])
-        self.head_conv = conv("decoder.head.2", tmul[-1])
-        self.mean = torch.tensor(vae.latent_mean, device=dev, dtype=F32)
-        self.std = torch.tensor(vae.latent_std, device=dev, dtype=F32)
         self._scratch = {}
+        return sd, dev
 
-    def _all_convs(self):
-        out = [self.conv1, self.head_conv]
-        blocks = [self.mid[0], self.mid[2]] + [r for st in self.stages for r in st["res"]]
-        for r in blocks:
-            out += [r["c1"], r["c2"]]
-        for st in self.stages:
-            if st["up"] and st["time_conv"] is not None:
-                out.append(st["time_conv"])
-        return out
+    @staticmethod
+    def _f32(t, dev):
+        return t.detach().to(dev, F32).reshape(-1).contiguous()
+
+    def _mk_conv(self, name, t_cap=1):
+        return _Conv(self.sd[name + ".weight"], self.sd[name + ".bias"], self.device, t_cap)
+
+    def _mk_res(self, name, t_cap):
+        sd, dev = self.sd, self.device
+        d = dict(g0=self._f32(sd[name + ".residual.0.gamma"], dev), c1=self._mk_conv(name + ".residual.2", t_cap),
+                 g3=self._f32(sd[name + ".residual.3.gamma"], dev), c2=self._mk_conv(name + ".residual.6", t_cap))
+        d["short"] = self._mk_conv(name + ".shortcut", t_cap) if (name + ".shortcut.weight") in sd else None
+        return d
+
+    def _mk_attn(self, name, c):
+        sd, dev = self.sd, self.device
+        wqkv = sd[name + ".to_qkv.weight"].detach().to(dev, F32).reshape(3 * c, c)
+        bqkv = self._f32(sd[name + ".to_qkv.bias"], dev)
+        return dict(c=c, gamma=self._f32(sd[name + ".norm.gamma"], dev), wqkv=wqkv.to(BF16).contiguous(), bqkv=bqkv,
+                    wv=wqkv[2 * c:].to(BF16).contiguous(), bv=bqkv[2 * c:].contiguous(),
+                    wproj=sd[name + ".proj.weight"].detach().to(dev, BF16).reshape(c, c).contiguous(),
+                    bproj=self._f32(sd[name + ".proj.bias"], dev))
 
     def _plain_image(self, key, frames, h, w, cp):
         k = (key, frames, h, w, cp)
@@ -217,9 +317,9 @@ class _DecoderEngine:
             self._scratch[k] = torch.zeros(frames, h + 2, w + 2, cp, device=self.device, dtype=BF16)
         return self._scratch[k]
 
-    # ------------------------------------------------------------------ blocks
     def _res(self, r, x, t, h, w):
-        """ResidualBlock (VAE.py:198-240) on rows x [t*(h+2)*(w+2), Cin] fp32 -> [.., Cout] fp32."""
+        """ResidualBlock (VAE.py:198-240) on rows x [t*(h+2)*(w+2), Cin] fp32 -> [.., Cout] fp32
+        (in place when there is no shortcut conv)."""
         c1, c2 = r["c1"], r["c2"]
         hip.vae_prep_cl(x, c1.ci, t, h, w, c1.image(h, w), mode=2, gamma=r["g0"], t0=c1.hist)
         t1 = c1.run(t, h, w, out_dtype=BF16)
@@ -232,9 +332,9 @@ class _DecoderEngine:
         c2.run(t, h, w, residual_into=x)
         return x
 
-    def _attention(self, x, t, h, w):
+    def _attention(self, a, x, t, h, w):
         """AttentionBlock (VAE.py:243-282): per frame, one head with head_dim = C."""
-        a, c, dev = self.attn, self.dims[0], self.device
+        c, dev = a["c"], self.device
         n = h * w
         kp = _round_up(n, 64)
         rows = (h + 2) * (w + 2)
@@ -253,6 +353,48 @@ class _DecoderEngine:
             hip.scatter_add_cl(xf, y, c, 1, h, w)
         return x
 
+
+class _DecoderEngine(_EngineBase):
+    def __init__(self, vae):
+        sd, dev = self._setup(vae)
+        cfg = vae._arch
+        self.z_dim, self.temporal_up = cfg["z_dim"], tuple(cfg["temporal_up"])
+        dims = [cfg["dec_dim"] * m for m in [cfg["dim_mult"][-1]] + list(cfg["dim_mult"][::-1])]
+        self.dims = dims
+        tmul = [1]
+        for up in self.temporal_up:
+            tmul.append(tmul[-1] * (2 if up else 1))                       # frames per chunk entering stage i
+        conv, res = self._mk_conv, self._mk_res
+        self.conv2 = conv("conv2")
+        self.conv1 = conv("decoder.conv1")
+        self.mid = [res("decoder.middle.0", 1), None, res("decoder.middle.2", 1)]
+        self.attn = self._mk_attn("decoder.middle.1", dims[0])
+        self.stages = []
+        n_stage = len(dims) - 1
+        for i in range(n_stage):
+            p = f"decoder.upsamples.{i}.upsamples"
+            st = dict(res=[res(f"{p}.{j}", tmul[i]) for j in range(3)], up=i != n_stage - 1, cout=dims[i + 1])
+            if st["up"]:
+                st["temporal"] = bool(self.temporal_up[i])
+                st["resample"] = conv(f"{p}.3.resample.1", tmul[i] * (2 if st["temporal"] else 1))
+                st["time_conv"] = conv(f"{p}.3.time_conv", tmul[i]) if st["temporal"] else None
+            self.stages.append(st)
+        self.head_gamma = self._f32(sd["decoder.head.0.gamma"], dev)
+        self.head_conv = conv("decoder.head.2", tmul[-1])
+        self.mean = torch.tensor(vae.latent_mean, device=dev, dtype=F32)
+        self.std = torch.tensor(vae.latent_std, device=dev, dtype=F32)
+        del self.sd
+
+    def _all_convs(self):
+        out = [self.conv1, self.head_conv]
+        blocks = [self.mid[0], self.mid[2]] + [r for st in self.stages for r in st["res"]]
+        for r in blocks:
+            out += [r["c1"], r["c2"]]
+        for st in self.stages:
+            if st["up"] and st["time_conv"] is not None:
+                out.append(st["time_conv"])
+        return out
+
     def _chunk(self, src_rows, h, w, first, video, f0):
         """Decoder3d.forward on one latent frame (VAE.py:677-728); writes 1 or 4 frames into `video`."""
         t = 1
@@ -260,7 +402,7 @@ class _DecoderEngine:
         hip.vae_prep_cl(src_rows, c1.ci, t, h, w, c1.image(h, w), mode=0, t0=c1.hist)
         x = c1.run(t, h, w, out_dtype=F32)
         x = self._res(self.mid[0], x, t, h, w)
-        x = self._attention(x, t, h, w)
+        x = self._attention(self.attn, x, t, h, w)
         x = self._res(self.mid[2], x, t, h, w)
         for st in self.stages:
             x_in, cin = x, x.shape[1]
@@ -311,6 +453,112 @@ class _DecoderEngine:
         return video
 
 
+class _EncoderEngine(_EngineBase):
+    """Encoder3d + conv1 + latent normalisation (VAE.py:505-618, :788-818), chunked 1 + 4 + 4 + ... frames."""
+
+    def __init__(self, vae):
+        sd, dev = self._setup(vae)
+        cfg = vae._arch
+        z2 = 2 * cfg["z_dim"]
+        self.z2 = z2
+        self.temporal_down = tuple(cfg["temporal_down"])
+        dims = [cfg["enc_dim"] * m for m in [1] + list(cfg["dim_mult"])]
+        self.dims = dims
+        tcap = [4]
+        for down in self.temporal_down:
+            tcap.append(max(1, tcap[-1] // (2 if down else 1)))             # frames per chunk entering stage i
+        tcap += [tcap[-1]] * (len(dims) - len(tcap))
+        conv, res = self._mk_conv, self._mk_res
+        self.conv1 = conv("encoder.conv1", tcap[0])
+        self.stages = []
+        n_stage = len(dims) - 1
+        for i in range(n_stage):
+            p = f"encoder.downsamples.{i}.downsamples"
+            st = dict(res=[res(f"{p}.{j}", tcap[i]) for j in range(2)], down=i != n_stage - 1, cout=dims[i + 1], temporal=False)
+            if st["down"]:
+                st["temporal"] = bool(self.temporal_down[i]) if i < len(self.temporal_down) else False
+                st["resample"] = _ConvS2D(sd[f"{p}.2.resample.1.weight"], sd[f"{p}.2.resample.1.bias"], dev, tcap[i])
+                st["time_conv"] = conv(f"{p}.2.time_conv", tcap[i]) if st["temporal"] else None
+            self.stages.append(st)
+        t_last = tcap[n_stage - 1] if n_stage - 1 < len(tcap) else 1
+        self.mid = [res("encoder.middle.0", t_last), None, res("encoder.middle.2", t_last)]
+        self.attn = self._mk_attn("encoder.middle.1", dims[-1])
+        self.head_gamma = self._f32(sd["encoder.head.0.gamma"], dev)
+        # head conv (C -> 2z) followed by conv1 (1x1x1, 2z -> 2z) and (mu - mean) / std: one linear map, folded in fp32
+        w1 = sd["conv1.weight"].detach().to(dev, F32).reshape(z2, z2)
+        b1 = sd["conv1.bias"].detach().to(dev, F32)
+        wh = sd["encoder.head.2.weight"].detach().to(dev, F32)
+        bh = sd["encoder.head.2.bias"].detach().to(dev, F32)
+        inv_std = torch.ones(z2, device=dev, dtype=F32)
+        mean = torch.zeros(z2, device=dev, dtype=F32)
+        inv_std[:z2 // 2] = 1.0 / torch.tensor(vae.latent_std, device=dev, dtype=F32)
+        mean[:z2 // 2] = torch.tensor(vae.latent_mean, device=dev, dtype=F32)
+        wf = torch.einsum("oc,cikhw->oikhw", w1, wh) * inv_std.view(-1, 1, 1, 1, 1)
+        bf = (w1 @ bh + b1 - mean) * inv_std
+        self.head_conv = _Conv(wf, bf, dev, t_last)
+        del self.sd
+
+    def _all_convs(self):
+        out = [self.conv1, self.head_conv]
+        blocks = [self.mid[0], self.mid[2]] + [r for st in self.stages for r in st["res"]]
+        for r in blocks:
+            out += [r["c1"], r["c2"]]
+        out += [st["time_conv"] for st in self.stages if st.get("time_conv") is not None]
+        return out
+
+    def _chunk(self, video, f0, t, h, w, first):
+        """Encoder3d.forward (VAE.py:564-618) on frames f0..f0+t of `video`; returns rows [t'*(h'+2)*(w'+2), 2z] fp32."""
+        c1 = self.conv1
+        hip.vae_patchify_cl(video, f0, t, c1.image(h, w), t0=c1.hist)
+        x = c1.run(t, h, w, out_dtype=F32)
+        for st in self.stages:
+            x_in, cin, t_in = x, x.shape[1], t
+            main = x.clone() if st["res"][0]["short"] is None else x
+            for r in st["res"]:
+                main = self._res(r, main, t, h, w)
+            co = st["cout"]
+            if st["down"]:
+                ds = st["resample"]
+                h, w = h // 2, w // 2
+                hip.space_to_depth_cl(main, co, t, 2 * h, 2 * w, ds.image(h, w), ds.cs)
+                main = ds.run(t, h, w, out_dtype=F32)
+                if st["temporal"]:
+                    tc = st["time_conv"]
+                    hip.vae_prep_cl(main, co, t, h, w, tc.image(h, w), mode=0, t0=tc.hist)
+                    if first:
+                        tc.roll(t)                                          # first chunk: the frame is only cached (VAE.py:165-166)
+                    else:
+                        main = tc.run_time_stride2(t, h, w, out_dtype=F32)
+                        t //= 2
+            hip.avgdown_add_cl(main, co, t, h, w, x_in, cin, t_in, 2 if st["temporal"] else 1, 2 if st["down"] else 1)
+            x = main
+        x = self._res(self.mid[0], x, t, h, w)
+        x = self._attention(self.attn, x, t, h, w)
+        x = self._res(self.mid[2], x, t, h, w)
+        hc = self.head_conv
+        hip.vae_prep_cl(x, hc.ci, t, h, w, hc.image(h, w), mode=2, gamma=self.head_gamma, t0=hc.hist)
+        return hc.run(t, h, w, out_dtype=F32), t, h, w
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """x [3, 1 + 4k, H, W] in [-1, 1] -> [2z, 1 + k, H/16, W/16] fp32: normalised mu | log_var."""
+        c, frames, hh, ww = x.shape
+        n_down = sum(1 for st in self.stages if st["down"])
+        if c != 3 or hh % (2 << n_down) or ww % (2 << n_down):
+            raise ValueError(f"encode: expected [3, F, H, W] with H, W multiples of {2 << n_down}, got {tuple(x.shape)}")
+        for cv in self._all_convs():
+            cv.reset()
+        video = x.to(self.device, F32).contiguous()
+        h, w = hh // 2, ww // 2
+        outs, t_out = [], 0
+        for i in range(1 + (frames - 1) // 4):
+            f0, t = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
+            rows, to, ho, wo = self._chunk(video, f0, t, h, w, i == 0)
+            outs.append(rows)
+            t_out += to
+        return hip.unpack_cl(torch.cat(outs) if len(outs) > 1 else outs[0], self.z2, t_out, ho, wo)
+
+
 class AutoencoderKLWan3_8(nn.Module):
     def __init__(self, latent_channels=48, c_dim=160, vae_pth=None, dim_mult=[1, 2, 4, 4], temperal_downsample=[False, True, True],
                  temporal_compression_ratio=4, spatial_compression_ratio=8, dec_dim=256):
@@ -325,19 +573,23 @@ class AutoencoderKLWan3_8(nn.Module):
         if latent_channels != len(LATENT_MEAN):
             self.latent_mean, self.latent_std = [0.0] * latent_channels, [1.0] * latent_channels
         temporal_up = list(temperal_downsample)[::-1]
-        self._arch = dict(z_dim=latent_channels, dec_dim=dec_dim, dim_mult=tuple(dim_mult), temporal_up=tuple(temporal_up))
+        self._arch = dict(z_dim=latent_channels, dec_dim=dec_dim, enc_dim=c_dim, dim_mult=tuple(dim_mult), temporal_up=tuple(temporal_up),
+                          temporal_down=tuple(temperal_downsample))
         self.model = _ParamTree()
+        for name, shape in encoder_param_shapes(latent_channels, c_dim, tuple(dim_mult), tuple(temperal_downsample)).items():
+            self.model.add(name, shape)
         for name, shape in decoder_param_shapes(latent_channels, dec_dim, tuple(dim_mult), tuple(temporal_up)).items():
             self.model.add(name, shape)
-        self.supports_encode = False
+        self.supports_encode = True
         self._engine: Optional[_DecoderEngine] = None
+        self._enc_engine: Optional[_EncoderEngine] = None
 
     def _apply(self, fn, *a, **k):
-        self._engine = None
+        self._engine = self._enc_engine = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._engine = None
+        self._engine = self._enc_engine = None
         return super().load_state_dict(*a, **k)
 
     @property
@@ -362,8 +614,20 @@ class AutoencoderKLWan3_8(nn.Module):
             out = out.to(BF16)
         return DecoderOutput(out) if return_dict else (out,)
 
-    def encode(self, x, return_dict: bool = True):
-        raise NotImplementedError("AutoencoderKLWan3_8.encode is the next scope row (SURVEY 8f1); this round covers decode")
+    def encoder_engine(self) -> _EncoderEngine:
+        if self._enc_engine is None:
+            self._enc_engine = _EncoderEngine(self)
+        return self._enc_engine
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """VAE.py:1021-1039: per sample chunked encode -> DiagonalGaussianDistribution([normalised mu | log_var])."""
+        eng = self.encoder_engine()
+        h = torch.stack([eng.encode(u) for u in x])
+        if x.dtype == BF16:
+            h = h.to(BF16)
+        posterior = DiagonalGaussianDistribution(h)
+        return AutoencoderKLOutput(latent_dist=posterior) if return_dict else (posterior,)
 
     @classmethod
     def from_pretrained(cls, pretrained_model_path, additional_kwargs={}):

@@ -162,6 +162,19 @@ int flexam_vae_unpatchify_clamp(const float* src, int64_t ld_src, int T, int H, 
 int flexam_pack_affine_cl(const float* src, int C, int T, int H, int W, const float* mul, const float* add, void* dst, int Cp,
                           void* stream);
 
+
+/* Wan2.2 3D-VAE encoder helpers (FlexAM/models/wan_vae3_8.py:505-618 Encoder3d, :420-457 Down_ResidualBlock).
+ * vae_patchify_cl: video[3][Ftot][2H][2W] frames f0..f0+T -> 12-channel image (patchify :285-301,
+ *   channel c*4 + r*2 + q), frame offset t0 (history frames of the causal conv1).
+ * space_to_depth_cl: rows at HxW -> image at H/2 x W/2 with 4 sub-pixel channel groups of Cs channels, so
+ *   that ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2) (:104-113) is a unit-stride implicit GEMM.
+ * avgdown_add_cl: x_main += AvgDown3D(x_in) (:321-372; front zero pad in time when Ti % ft != 0). */
+int flexam_vae_patchify_cl(const float* video, int Ftot, int f0, int T, int H, int W, void* dst, int Cp, int t0, void* stream);
+int flexam_space_to_depth_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, void* dst, int Cs, int t0,
+                             void* stream);
+int flexam_avgdown_add_cl(float* x_main, int64_t ld_main, int Co, int To, int Ho, int Wo, const float* x_in, int64_t ld_in, int Ci,
+                          int Ti, int ft, int fs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,20 @@ def vae_case(seed: int = 32, frames: int = 3, h: int = 4, w: int = 4, z_dim: int
     return randn(g, 1, z_dim, frames, h, w)
 
 
+VAE_ENC_SMALL = dict(z_dim=48, dim=16, dim_mult=(1, 2, 4, 4), temporal_down=(False, True, True))
+
+
+def vae_enc_weights(vcfg: dict, seed: int = 41, prefix: str = "model.") -> Dict[str, Tensor]:
+    shp = OV.vae_encoder_param_shapes(vcfg["z_dim"], vcfg["dim"], vcfg["dim_mult"], vcfg["temporal_down"], prefix)
+    return O.seeded_state_dict(shp, seed)
+
+
+def vae_enc_case(seed: int = 42, frames: int = 9, h: int = 32, w: int = 64) -> Tensor:
+    """Pixel clip in [-1, 1], [1, 3, 1+4k, h, w] (h, w multiples of 16)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(1, 3, frames, h, w, generator=g, dtype=torch.float32) * 2 - 1
+
+
 def psnr(a: Tensor, b: Tensor, peak: float = None) -> float:
     """PSNR of a vs reference b; peak defaults to the reference's max-abs range."""
     a, b = a.double(), b.double()

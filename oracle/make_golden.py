@@ -13,6 +13,7 @@ Fixtures:
   g4b_dit_nonsquare  same as g4 on a non-square latent [2,48,3,8,24] (catches h/w swaps)
   g5_dit_scalart     same, 1-D t branch                                                         FX.py:941-944
   g6_teacache        6 forwards with TeaCache on (identity rescale, threshold 2.0): computed and skipped steps  FX.py:977-1051
+  g8_vae_encode      small AutoencoderKLWan2_2_ encode [1,3,9,32,64] / [1,3,1,32,32] -> normalised mu          VAE.py:788-818
   g7_vae_decode      small AutoencoderKLWan2_2_ decode [1,48,3,4,6] -> [1,3,9,64,96] + taps    VAE.py:820-849
   g9_sampler         4-step CFG/Euler/blend trace at latent [1,48,3,16,16] driving the
                      reference DiT module through oracle.sampler.denoise_loop                  PIPE.py:840-949
@@ -150,6 +151,19 @@ def main():
     for h in hooks:
         h.remove()
     _save("g7_vae_decode", dict(out=out, middle=torch.cat(taps["middle"], dim=2), up1_last=taps["up1"][-1], in_sum=C.checksum(dict(z=z)), w_sum=C.checksum(vsd)))
+
+    # ---- G8: VAE encode (posterior mode, normalised) on a 9-frame clip (chunks 1+4+4) and a single image
+    VE = ref.vae.AutoencoderKLWan2_2_(dim=C.VAE_ENC_SMALL["dim"], dec_dim=16, z_dim=48,
+                                      temperal_downsample=list(C.VAE_ENC_SMALL["temporal_down"])).eval()
+    esd = C.vae_enc_weights(C.VAE_ENC_SMALL, prefix="")
+    missing, unexpected = VE.load_state_dict(esd, strict=False)
+    assert not unexpected and all(k.startswith(("decoder.", "conv2.")) for k in missing), (missing, unexpected)
+    mean, std = torch.tensor(OV.LATENT_MEAN), torch.tensor(OV.LATENT_STD)
+    xv, xi = C.vae_enc_case(), C.vae_enc_case(seed=43, frames=1, h=32, w=32)
+    with torch.no_grad():
+        mu_v = VE.encode(xv, [mean, 1.0 / std])[:, :48]
+        mu_i = VE.encode(xi, [mean, 1.0 / std])[:, :48]
+    _save("g8_vae_encode", dict(mu_video=mu_v, mu_image=mu_i, in_sum=C.checksum(dict(v=xv, i=xi)), w_sum=C.checksum(esd)))
     print("golden fixtures written to", OUT)
 
 

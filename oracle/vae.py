@@ -210,3 +210,149 @@ def vae_decoder_param_shapes(z_dim: int = 48, dec_dim: int = 256, dim_mult=(1, 2
     s[d + ".head.0.gamma"] = (dims[-1], 1, 1, 1)
     conv(d + ".head.2", 12, dims[-1], (3, 3, 3))
     return s
+
+
+# ============================================================================= encode path
+# AutoencoderKLWan3_8.encode (VAE.py:1021-1039) -> AutoencoderKLWan2_2_.encode (:788-818) -> Encoder3d (:505-618)
+# with Down_ResidualBlock (:420-457), AvgDown3D (:321-372), Resample downsample2d/3d (:104-113,162-174), patchify (:285-301).
+
+def patchify2(x: Tensor) -> Tensor:
+    """patchify(patch_size=2): 'b c f (h q) (w r) -> b (c r q) f h w'."""
+    b, c, f, hq, wr = x.shape
+    y = x.view(b, c, f, hq // 2, 2, wr // 2, 2)          # [b, c, f, h, q, w, r]
+    return y.permute(0, 1, 6, 4, 2, 3, 5).reshape(b, c * 4, f, hq // 2, wr // 2)
+
+
+def avg_down3d(x: Tensor, out_c: int, ft: int, fs: int) -> Tensor:
+    """AvgDown3D, VAE.py:340-372 (front zero-pad in time to a multiple of ft)."""
+    pad_t = (ft - x.shape[2] % ft) % ft
+    x = F.pad(x, (0, 0, 0, 0, pad_t, 0))
+    b, c, t, h, w = x.shape
+    y = x.view(b, c, t // ft, ft, h // fs, fs, w // fs, fs).permute(0, 1, 3, 5, 7, 2, 4, 6)
+    y = y.reshape(b, c * ft * fs * fs, t // ft, h // fs, w // fs)
+    g = c * ft * fs * fs // out_c
+    return y.view(b, out_c, g, t // ft, h // fs, w // fs).mean(dim=2)
+
+
+class _EncHist:
+    """Per-conv chunk caches of the encoder.  3x3x3 causal convs: rolling two-frame history (as in the decoder).
+    Strided time conv (3,1,1)/(2,1,1) of downsample3d: caches ONE frame and is skipped on the first chunk
+    (VAE.py:162-174: the first chunk only stores its frame)."""
+
+    def __init__(self):
+        self.h: Dict[str, Tensor] = {}
+
+    def conv(self, sd, name, x):
+        w, b = sd[name + ".weight"], sd[name + ".bias"]
+        kt, kh, kw = w.shape[2:]
+        if kt == 1:
+            return F.conv3d(x, w, b, padding=(0, kh // 2, kw // 2))
+        prev = self.h.get(name)
+        if prev is None:
+            prev = x.new_zeros(x.shape[0], x.shape[1], kt - 1, *x.shape[3:])
+        xin = torch.cat([prev, x], dim=2)
+        self.h[name] = xin[:, :, -(kt - 1):].clone()
+        return F.conv3d(xin, w, b, padding=(0, kh // 2, kw // 2))
+
+    def time_down(self, sd, name, x):
+        prev = self.h.get(name)
+        self.h[name] = x[:, :, -1:].clone()
+        if prev is None:                                   # first chunk: no temporal conv
+            return x
+        return F.conv3d(torch.cat([prev, x], dim=2), sd[name + ".weight"], sd[name + ".bias"], stride=(2, 1, 1))
+
+
+def _enc_res(sd, p, x, hist):
+    h = hist.conv(sd, p + ".shortcut", x) if (p + ".shortcut.weight") in sd else x
+    y = F.silu(rms_norm_cf(x, sd[p + ".residual.0.gamma"]))
+    y = hist.conv(sd, p + ".residual.2", y)
+    y = F.silu(rms_norm_cf(y, sd[p + ".residual.3.gamma"]))
+    y = hist.conv(sd, p + ".residual.6", y)
+    return y + h
+
+
+def encoder_chunk(sd, p: str, x: Tensor, hist: _EncHist, temporal_down) -> Tensor:
+    """Encoder3d.forward on one chunk (1 frame, then 4 frames), VAE.py:564-618."""
+    x = hist.conv(sd, p + ".conv1", x)
+    n_stage = len(temporal_down) + 1
+    for i in range(n_stage):
+        q = f"{p}.downsamples.{i}"
+        down = i != n_stage - 1
+        t_down = bool(temporal_down[i]) if i < len(temporal_down) else False
+        x_in = x
+        for j in range(2):
+            x = _enc_res(sd, f"{q}.downsamples.{j}", x, hist)
+        if down:
+            b, c, t, h, w = x.shape
+            y = F.pad(x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w), (0, 1, 0, 1))
+            y = F.conv2d(y, sd[f"{q}.downsamples.2.resample.1.weight"], sd[f"{q}.downsamples.2.resample.1.bias"], stride=2)
+            x = y.view(b, t, c, h // 2, w // 2).permute(0, 2, 1, 3, 4)
+            if t_down:
+                x = hist.time_down(sd, f"{q}.downsamples.2.time_conv", x)
+        out_c = x.shape[1]
+        x = x + avg_down3d(x_in, out_c, 2 if t_down else 1, 2 if down else 1)
+    x = _enc_res(sd, p + ".middle.0", x, hist)
+    x = attention_block(sd, p + ".middle.1", x)
+    x = _enc_res(sd, p + ".middle.2", x, hist)
+    x = F.silu(rms_norm_cf(x, sd[p + ".head.0.gamma"]))
+    return hist.conv(sd, p + ".head.2", x)
+
+
+def vae_encode(sd: Dict[str, Tensor], x: Tensor, temporal_down=(False, True, True), mean=None, std=None, prefix: str = "model.") -> Tensor:
+    """AutoencoderKLWan3_8.encode(x)[0].mode() for x [B, 3, 1+4k, H, W] in [-1, 1] -> mu [B, zc, 1+k, H/16, W/16]
+    (already normalised: (mu - mean) / std, VAE.py:810-815)."""
+    outs = []
+    for u in x:
+        u = patchify2(u.unsqueeze(0))
+        t = u.shape[2]
+        hist = _EncHist()
+        chunks = []
+        for i in range(1 + (t - 1) // 4):
+            sl = u[:, :, :1] if i == 0 else u[:, :, 1 + 4 * (i - 1):1 + 4 * i]
+            chunks.append(encoder_chunk(sd, prefix + "encoder", sl, hist, temporal_down))
+        out = torch.cat(chunks, dim=2)
+        mu = F.conv3d(out, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"]).chunk(2, dim=1)[0]
+        if mean is not None:
+            m = torch.as_tensor(mean, dtype=mu.dtype).view(1, -1, 1, 1, 1)
+            s = torch.as_tensor(std, dtype=mu.dtype).view(1, -1, 1, 1, 1)
+            mu = (mu - m) * (1.0 / s)
+        outs.append(mu.squeeze(0))
+    return torch.stack(outs)
+
+
+def vae_encoder_param_shapes(z_dim: int = 48, dim: int = 160, dim_mult=(1, 2, 4, 4), temporal_down=(False, True, True),
+                             prefix: str = "model.") -> Dict[str, tuple]:
+    dims = [dim * m for m in [1] + list(dim_mult)]
+    s = {}
+
+    def conv(name, co, ci, k):
+        s[name + ".weight"] = (co, ci, *k)
+        s[name + ".bias"] = (co,)
+
+    def res(name, ci, co):
+        s[name + ".residual.0.gamma"] = (ci, 1, 1, 1)
+        conv(name + ".residual.2", co, ci, (3, 3, 3))
+        s[name + ".residual.3.gamma"] = (co, 1, 1, 1)
+        conv(name + ".residual.6", co, co, (3, 3, 3))
+        if ci != co:
+            conv(name + ".shortcut", co, ci, (1, 1, 1))
+    conv(prefix + "conv1", z_dim * 2, z_dim * 2, (1, 1, 1))
+    e = prefix + "encoder"
+    conv(e + ".conv1", dims[0], 12, (3, 3, 3))
+    n_stage = len(dims) - 1
+    for i, (ci, co) in enumerate(zip(dims[:-1], dims[1:])):
+        q = f"{e}.downsamples.{i}.downsamples"
+        res(f"{q}.0", ci, co)
+        res(f"{q}.1", co, co)
+        if i != n_stage - 1:
+            conv(f"{q}.2.resample.1", co, co, (3, 3))
+            if i < len(temporal_down) and temporal_down[i]:
+                conv(f"{q}.2.time_conv", co, co, (3, 1, 1))
+    res(e + ".middle.0", dims[-1], dims[-1])
+    s[e + ".middle.1.norm.gamma"] = (dims[-1], 1, 1)
+    conv(e + ".middle.1.to_qkv", dims[-1] * 3, dims[-1], (1, 1))
+    conv(e + ".middle.1.proj", dims[-1], dims[-1], (1, 1))
+    res(e + ".middle.2", dims[-1], dims[-1])
+    s[e + ".head.0.gamma"] = (dims[-1], 1, 1, 1)
+    conv(e + ".head.2", z_dim * 2, dims[-1], (3, 3, 3))
+    return s

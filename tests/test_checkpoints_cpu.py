@@ -63,13 +63,13 @@ def test_dit_patch_embedding_pad_and_mismatch_skip(tmp_path):
 def test_vae_from_pretrained_prefixes_model(tmp_path):
     from flexam_amd import AutoencoderKLWan3_8
     raw = C.vae_weights(C.VAE_SMALL, seed=5, prefix="")                                 # Wan2.2_VAE.pth style keys
-    raw["encoder.conv1.weight"] = torch.zeros(3)                                        # encoder keys exist in the real file: ignored
+    raw.update(C.vae_enc_weights(C.VAE_ENC_SMALL, seed=6, prefix=""))                   # encoder + conv1 keys of the same file
     path = str(tmp_path / "Wan2.2_VAE.pth")
     torch.save(raw, path)
     vae = AutoencoderKLWan3_8.from_pretrained(path, additional_kwargs=dict(
-        latent_channels=48, dec_dim=16, temporal_compression_ratio=4, spatial_compression_ratio=16, vae_type="AutoencoderKLWan3_8"))
+        latent_channels=48, c_dim=16, dec_dim=16, temporal_compression_ratio=4, spatial_compression_ratio=16, vae_type="AutoencoderKLWan3_8"))
     got = vae.state_dict()
+    assert set(got) == {"model." + k for k in raw}                                       # the full reference inventory, nothing else
     for k, v in raw.items():
-        if not k.startswith("encoder."):
-            torch.testing.assert_close(got["model." + k], v, rtol=0, atol=0)
+        torch.testing.assert_close(got["model." + k], v, rtol=0, atol=0)
     assert vae.config.latent_channels == 48 and vae.spatial_compression_ratio == 16 and vae.temporal_compression_ratio == 4

@@ -123,3 +123,40 @@ def test_vae_prep_modes_upsample_dupup_scatter_softmax_unpatchify():
     want_v = v.view(3, 2, 2, t, h, w).permute(0, 3, 4, 2, 5, 1).reshape(3, t, 2 * h, 2 * w).clamp(-1, 1)      # (c r q) -> (h q) (w r)
     torch.testing.assert_close(video[:, 3:5].cpu(), want_v, rtol=0, atol=0)
     assert float(video[:, :3].abs().max()) == 0
+
+
+def test_patchify_s2d_avgdown_match_torch():
+    """Encoder helpers: patchify -> image, space-to-depth -> image, AvgDown3D add (incl. the front zero pad)."""
+    import sys
+    from flexam_amd import hip as H
+    from oracle import vae as OV
+    g = torch.Generator().manual_seed(5)
+    # patchify: video [3, 5, 8, 12] frames 1..4 -> image frames 2..4 of [5, 6, 8, 64]
+    vid = torch.randn(3, 5, 8, 12, generator=g)
+    img = torch.zeros(5, 6, 8, 64, dtype=BF, device=dev())
+    H.vae_patchify_cl(vid.to(dev()), 1, 3, img, t0=2)
+    want = OV.patchify2(vid[None])[0][:, 1:4]                                   # [12, 3, 4, 6]
+    bf16_close(img[2:, 1:-1, 1:-1, :12].permute(3, 0, 1, 2), want)
+    assert float(img[:2].abs().max()) == 0 and float(img[..., 12:].abs().max()) == 0
+    # space-to-depth
+    c, t, h, w, cs = 24, 2, 4, 6, 64
+    x = torch.randn(c, t, h, w, generator=g)
+    rows = padded_rows(x).to(dev())
+    s2d = torch.zeros(t, h // 2 + 2, w // 2 + 2, 4 * cs, dtype=BF, device=dev())
+    H.space_to_depth_cl(rows, c, t, h, w, s2d, cs)
+    for a in range(2):
+        for b in range(2):
+            grp = s2d[:, 1:-1, 1:-1, (a * 2 + b) * cs:(a * 2 + b) * cs + c].permute(3, 0, 1, 2)
+            bf16_close(grp, x[:, :, a::2, b::2])
+    assert float(s2d[:, -1].abs().max()) == 0 and float(s2d[:, :, -1].abs().max()) == 0
+    # AvgDown3D add: (ft, fs, Ti) incl. odd frame count (front pad) and the identity case
+    for ci, co, ti, ft, fs in ((8, 16, 4, 2, 2), (8, 16, 1, 2, 2), (8, 8, 3, 1, 2), (8, 8, 2, 1, 1)):
+        hi, wi = 4, 8
+        xin = torch.randn(ci, ti, hi, wi, generator=g)
+        want = OV.avg_down3d(xin[None], co, ft, fs)[0]                          # [co, to, ho, wo]
+        to, ho, wo = want.shape[1:]
+        base = torch.randn(co, to, ho, wo, generator=g)
+        xm = padded_rows(base).to(dev())
+        H.avgdown_add_cl(xm, co, to, ho, wo, padded_rows(xin).to(dev()), ci, ti, ft, fs)
+        got = xm.view(to, ho + 2, wo + 2, co)[:, 1:-1, 1:-1].permute(3, 0, 1, 2).cpu()
+        torch.testing.assert_close(got, base + want, rtol=1e-5, atol=1e-5)

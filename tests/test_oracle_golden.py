@@ -144,3 +144,14 @@ def test_g6_teacache(golden):
         assert float(tc["should_calc"]) == float(fx["should_calc"][i]) or tc["cnt"] == 0
         torch.testing.assert_close(out, fx["outs"][i], **TOL)
     assert tc["cnt"] == 0                                     # reset after num_steps calls (FX.py:1121-1122)
+
+
+def test_g8_vae_encode(golden):
+    fx = golden("g8_vae_encode")
+    esd = C.vae_enc_weights(C.VAE_ENC_SMALL, prefix="")
+    xv, xi = C.vae_enc_case(), C.vae_enc_case(seed=43, frames=1, h=32, w=32)
+    assert torch.equal(C.checksum(esd), fx["w_sum"]) and torch.equal(C.checksum(dict(v=xv, i=xi)), fx["in_sum"])
+    for x, key in ((xv, "mu_video"), (xi, "mu_image")):
+        mu = OV.vae_encode(esd, x, C.VAE_ENC_SMALL["temporal_down"], OV.LATENT_MEAN, OV.LATENT_STD, prefix="")
+        assert mu.shape == fx[key].shape
+        assert (mu - fx[key]).abs().max().item() < 2e-5 * max(1.0, fx[key].abs().max().item())

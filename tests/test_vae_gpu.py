@@ -48,3 +48,49 @@ def test_vae_decode_four_chunks_other_shape_and_repeatable():
     check(out1, want, "vae decode 4 chunks")
     out2 = vae.decode(z.cuda()).sample                      # history must be reset between calls
     torch.testing.assert_close(out1, out2, rtol=0, atol=0)
+
+
+# ----------------------------------------------------------------------------- encode
+def build_encoder(seed=41):
+    from flexam_amd.wan_vae3_8 import AutoencoderKLWan3_8
+    v = C.VAE_ENC_SMALL
+    vae = AutoencoderKLWan3_8(latent_channels=v["z_dim"], c_dim=v["dim"], dec_dim=16, dim_mult=list(v["dim_mult"]),
+                              temperal_downsample=list(v["temporal_down"]), spatial_compression_ratio=16)
+    sd = C.vae_enc_weights(v, seed=seed, prefix="model.")
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("model.decoder.", "model.conv2.")) for k in missing)
+    return vae.to("cuda:0"), sd
+
+
+def check_latent(got, want, what):
+    got, want = got.float().cpu(), want.float()
+    rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    p = C.psnr(got, want)
+    print(f"{what}: rel-rms {rel:.3e}, psnr {p:.1f} dB")
+    assert p >= 40.0 and rel <= 2e-2, f"{what}: rel-rms {rel:.3e}, psnr {p:.1f} dB"
+
+
+def test_vae_encode_matches_reference_golden(golden):
+    """G8: REFERENCE AutoencoderKLWan2_2_.encode outputs (normalised mu) on a 9-frame clip (chunks 1+4+4:
+    first-chunk temporal-conv skip, cached strided temporal conv, AvgDown3D front pad) and a single image."""
+    fx = golden("g8_vae_encode")
+    vae, sd = build_encoder()
+    xv, xi = C.vae_enc_case(), C.vae_enc_case(seed=43, frames=1, h=32, w=32)
+    mu_v = vae.encode(xv.cuda()).latent_dist.mode()
+    assert mu_v.shape == (1, 48, 3, 2, 4)
+    check_latent(mu_v, fx["mu_video"], "vae encode g8 video")
+    mu_i = vae.encode(xi.cuda())[0].mode()
+    assert mu_i.shape == (1, 48, 1, 2, 2)
+    check_latent(mu_i, fx["mu_image"], "vae encode g8 image")
+
+
+def test_vae_encode_five_chunks_other_shape_repeatable_and_logvar():
+    vae, sd = build_encoder(seed=91)
+    x = C.vae_enc_case(seed=92, frames=17, h=48, w=32)
+    want_mu = OV.vae_encode(sd, x, C.VAE_ENC_SMALL["temporal_down"], OV.LATENT_MEAN, OV.LATENT_STD)
+    post = vae.encode(x.cuda(), return_dict=False)[0]
+    assert post.parameters.shape == (1, 96, 5, 3, 2)
+    check_latent(post.mode(), want_mu, "vae encode 5 chunks")
+    again = vae.encode(x.cuda()).latent_dist.parameters        # caches must be reset between calls
+    torch.testing.assert_close(post.parameters, again, rtol=0, atol=0)
+    assert torch.isfinite(post.sample(generator=torch.Generator("cuda").manual_seed(0))).all()
