@@ -9,8 +9,9 @@ one DiT engine run + ONE fused kernel for CFG + Euler + masked blend on fp32 lat
 one-off mask/latent preparation.
 
 Two ways in:
-  * `__call__(prompt=..., video=..., ...)`: pixel-space inputs like demo.py; needs `vae.encode` and a
-    text encoder (the encode path is the next scope row, SURVEY 8f1/f4 -- it raises if absent);
+  * `__call__(prompt_embeds=..., video=..., control_video=..., ...)`: pixel-space inputs like demo.py; the
+    conditioning streams go through `vae.encode` (HIP) in `encode_conditioning`; a `prompt=` string needs a
+    text encoder attached (umT5 is outside this path, SURVEY 8f4 -- it raises if absent);
   * `__call__(..., conditioning=LatentConditioning(...))`: latent-space conditioning (what bench.py,
     the tests and a caller that has already VAE-encoded its streams use).
 """
@@ -287,19 +288,47 @@ class Wan2_2FunControlPipeline_FlexAM:
         self.maybe_free_model_hooks()
         return WanPipelineOutput(videos=video_out)
 
+    @staticmethod
+    def _preprocess(v: torch.Tensor, height: int, width: int, mask: bool = False) -> torch.Tensor:
+        """VaeImageProcessor.preprocess on a [B,C,F,H,W] tensor as PIPE.py:625-627, 657-659 use it: resize
+        (torch nearest) when the size differs; pixels in [0,1] -> [-1,1] unless already signed; masks are
+        reduced to one channel and binarised at 0.5 (0/255 masks binarise to 0/1)."""
+        v = v.to(F32)
+        b, c, f, h, w = v.shape
+        if (h, w) != (height, width):
+            v = F.interpolate(v.transpose(1, 2).reshape(b * f, c, h, w), size=(height, width)).view(b, f, c, height, width).transpose(1, 2)
+        if mask:
+            return (v[:, :1] >= 0.5).to(F32)
+        return v * 2 - 1 if float(v.min()) >= 0 else v
+
     def encode_conditioning(self, video, mask_video, control_video, depth_video, cos_control_videos, ref_image, height, width, shape):
-        """PIPE.py:623-822: VAE-encode the conditioning streams.  Needs the VAE *encode* path, which is
-        the next scope row; until then pass `conditioning=LatentConditioning(...)`."""
+        """PIPE.py:623-822: pixel-space streams -> LatentConditioning through AutoencoderKLWan3_8.encode
+        (posterior mode, PIPE.py:345-403).  video / control / depth / cos / ref: [1,3,F,H,W] in [0,1];
+        mask_video [1,1,F,H,W] with 255 (or 1) = regenerate.  An all-255 mask gives zero mask latents,
+        zero known latents and mask = 1 (PIPE.py:648-654)."""
         if self.vae is None or not getattr(self.vae, "supports_encode", False):
-            raise NotImplementedError("pixel-space conditioning needs AutoencoderKLWan3_8.encode (next scope row); "
+            raise NotImplementedError("pixel-space conditioning needs a VAE with an encode path; "
                                       "pass conditioning=LatentConditioning(...) with pre-encoded latents")
+        if video is None or mask_video is None or control_video is None:
+            raise ValueError("video, mask_video and control_video are required (predict_v2v.py:1181 always passes them)")
         if cos_control_videos is None or len(cos_control_videos) == 0:
             raise ValueError("cos_control_videos is mandatory for FlexAM (PIPE.py:744-773, 865-866)")
-        enc = lambda v: self.vae.encode(v * 2 - 1 if v.min() >= 0 else v)[0].mode()
-        mask_cond = (mask_video > 0.5).float() if mask_video.max() <= 1 else (mask_video > 127).float()
-        masked = video * (mask_cond < 0.5)
-        cos = [enc(cos_control_videos[k]) for k in sorted(cos_control_videos)]
-        depth = enc(depth_video) if depth_video is not None else torch.zeros(shape)
+        dev = self.vae.device
+        enc = lambda v: self.vae.encode(self._preprocess(v, height, width).to(dev))[0].mode().float()
+        zeros = torch.zeros(shape, device=dev, dtype=F32)
+        if bool((mask_video == 255).all()):
+            masked, mask_pixels = zeros, None
+            mask_latents, mask = zeros[:, :1].repeat(1, 4, 1, 1, 1), torch.ones_like(zeros[:, :1])
+        else:
+            mask_pixels = self._preprocess(mask_video, height, width, mask=True)
+            init = self._preprocess(video, height, width)
+            masked = self.vae.encode((init * (mask_pixels < 0.5)).to(dev))[0].mode().float()
+            mask_latents = mask = None
+        cos = [enc(cos_control_videos[k]) if cos_control_videos[k] is not None else zeros for k in sorted(cos_control_videos)]
+        depth = enc(depth_video) if depth_video is not None else zeros
+        if ref_image is not None:
+            ref = enc(ref_image)[:, :, 0]
+        else:
+            ref = zeros[:, :, 0] if getattr(self.transformer, "ref_conv", None) is not None else None
         return LatentConditioning(control_latents=enc(control_video), additional_control=torch.cat([depth] + cos, dim=1),
-                                  masked_video_latents=enc(masked), ref_latents=enc(ref_image)[:, :, 0] if ref_image is not None else None,
-                                  mask_pixels=mask_cond)
+                                  masked_video_latents=masked, ref_latents=ref, mask_pixels=mask_pixels, mask_latents=mask_latents, mask=mask)

@@ -336,18 +336,18 @@ class _EngineBase:
         """AttentionBlock (VAE.py:243-282): per frame, one head with head_dim = C."""
         c, dev = a["c"], self.device
         n = h * w
-        kp = _round_up(n, 64)
+        n4, kp = _round_up(n, 4), _round_up(n, 64)                                         # GEMM N granularity / K granularity
         rows = (h + 2) * (w + 2)
         for f in range(t):
             xf = x[f * rows:(f + 1) * rows]
-            xn = torch.empty(n, c, device=dev, dtype=BF16)
+            xn = torch.zeros(n4, c, device=dev, dtype=BF16)
             hip.vae_prep_cl(xf, c, 1, h, w, xn, mode=1, gamma=a["gamma"], compact=True)
-            qk = hip.gemm(xn, a["wqkv"][:2 * c], a["bqkv"][:2 * c])                       # [n, 2c]
-            s = hip.gemm(qk[:, :c], qk[:, c:], out_dtype=F32)                              # q k^T  [n, n]
+            qk = hip.gemm(xn, a["wqkv"][:2 * c], a["bqkv"][:2 * c])                       # [n4, 2c]
+            s = hip.gemm(qk[:n, :c], qk[:, c:], out_dtype=F32)                             # q k^T  [n, n4]; softmax over the first n
             p = torch.empty(n, kp, device=dev, dtype=BF16)
             hip.softmax_rows(s, c ** -0.5, p, n)
             vt = torch.zeros(c, kp, device=dev, dtype=BF16)
-            hip.gemm(a["wv"], xn, out=vt[:, :n])                                           # V^T (bias folded below: rows of P sum to 1)
+            hip.gemm(a["wv"], xn, out=vt[:, :n4])                                          # V^T (bias folded below: rows of P sum to 1)
             o = hip.gemm(p, vt, a["bv"])                                                   # [n, c]
             y = hip.gemm(o, a["wproj"], a["bproj"])
             hip.scatter_add_cl(xf, y, c, 1, h, w)
