@@ -141,8 +141,9 @@ def cpu_baseline(L, cfg):
                        f"took {sec:.1f} s; value = 1/(60 x that), extrapolated", block_seconds=sec)
 
 
-def time_vae_decode(device, frames, height, width):
-    """Wan2.2 3D-VAE decode of one clip (random-init weights, PIPE.py:951-955) -> seconds."""
+def time_vae(device, frames, height, width):
+    """Wan2.2 3D-VAE (random-init weights): decode of one clip (PIPE.py:951-955) and encode of one conditioning
+    video stream + the reference image (PIPE.py:655-822) -> (decode s, encode-stream s, encode-image s, finite)."""
     from flexam_amd import AutoencoderKLWan3_8
     torch.manual_seed(1)
     with torch.device(device):
@@ -162,7 +163,18 @@ def time_vae_decode(device, frames, height, width):
     out = vae.decode(z).sample
     torch.cuda.synchronize()
     sec = time.perf_counter() - t0
-    return sec, bool(torch.isfinite(out.float()).all())
+    finite = bool(torch.isfinite(out.float()).all())
+    enc = []
+    for nf in (frames, 1):
+        x = torch.rand(1, 3, nf, height, width, device=device) * 2 - 1
+        vae.encode(x)                               # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mu = vae.encode(x).latent_dist.mode()
+        torch.cuda.synchronize()
+        enc.append(time.perf_counter() - t0)
+        finite = finite and bool(torch.isfinite(mu.float()).all())
+    return sec, enc[0], enc[1], finite
 
 
 def main():
@@ -236,11 +248,12 @@ def main():
         base = cpu_baseline(L, cfg)
 
     eng_cfg, eng_sp = eng.cfg_size, eng.sp_size
-    vae_sec = None
+    vae_sec = enc_sec = enc_stream_sec = None
     if rank == 0 and world == 1 and not args.no_vae:
         del pipe, model, eng
         torch.cuda.empty_cache()
-        vae_sec, vae_finite = time_vae_decode(device, args.frames, args.height, args.width)
+        vae_sec, enc_stream_sec, enc_image_sec, vae_finite = time_vae(device, args.frames, args.height, args.width)
+        enc_sec = 7 * enc_stream_sec + enc_image_sec     # control, depth, 4 cos levels, masked video + the reference image
         finite = finite and vae_finite
 
     if rank == 0:
@@ -258,8 +271,8 @@ def main():
                                        f"parallel with one RCCL K/V all-gather per block") if world > 1 else "single GPU",
                        "layers": cfg["num_layers"]},
             "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
-            "vae_decode_sec": vae_sec,
-            "sec_per_clip": (total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
+            "vae_decode_sec": vae_sec, "vae_encode_sec_per_stream": enc_stream_sec, "conditioning_encode_sec_8_streams": enc_sec,
+            "sec_per_clip": (enc_sec + total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
             "dit_block_tflops": step_block_flops * steps_per_sec / 1e12,
             "dit_block_mfma_frac": step_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
             "finite": finite,

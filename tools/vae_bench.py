@@ -26,3 +26,39 @@ for it in range(2):
           f"absmax={float(out.float().abs().max()):.3f}, mem={torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 tflop = 33.7 * (frames - 1) + 33.7 / 4
 print(f"~{tflop:.0f} TFLOP -> {tflop / dt:.0f} TFLOP/s")
+
+# ---- encode: [1,3,1+4(frames-1),512,896] -> [1,96,frames,32,56]
+pix = 1 + 4 * (frames - 1)
+x = torch.rand(1, 3, pix, 512, 896, device="cuda:0") * 2 - 1
+torch.cuda.reset_peak_memory_stats()
+for it in range(2):
+    t0 = time.perf_counter()
+    post = vae.encode(x).latent_dist
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p = post.parameters.float()
+    print(f"encode {tuple(x.shape)} -> {tuple(p.shape)}: {dt:.3f} s, finite={bool(torch.isfinite(p).all())}, "
+          f"absmax={float(p.abs().max()):.3f}, mem={torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
+
+
+def enc_flops(frames_pix, h=256, w=448, dim=160):
+    """2*M*N*K of every conv GEMM of Encoder3d on a clip (interior positions only)."""
+    dims = [dim, dim, 2 * dim, 4 * dim, 4 * dim]
+    fl, t, hh, ww = 2.0 * frames_pix * h * w * 27 * 12 * dim, float(frames_pix), h, w
+    for i in range(4):
+        ci, co = dims[i], dims[i + 1]
+        px = t * hh * ww
+        fl += 2 * px * 27 * (ci * co + 3 * co * co) + (2 * px * ci * co if ci != co else 0)
+        if i < 3:
+            hh, ww = hh // 2, ww // 2
+            fl += 2 * t * hh * ww * 9 * co * co
+            if i > 0:
+                t = 1 + (t - 1) / 2
+                fl += 2 * t * hh * ww * 3 * co * co
+    px = t * hh * ww
+    fl += 2 * px * 27 * 4 * dims[-1] ** 2 + 2 * px * 27 * dims[-1] * 96 + px * (4 * 2 * dims[-1] ** 2 + 4 * hh * ww * dims[-1])
+    return fl
+
+
+tf = enc_flops(pix) / 1e12
+print(f"encode ~{tf:.0f} TFLOP -> {tf / dt:.0f} TFLOP/s")
