@@ -21,6 +21,8 @@
 //    share A row-panels and W column-panels in L2.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "flexam_hip.h"
 
@@ -49,24 +51,14 @@ struct GemmParams {
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 
-template <int PASSES>
-__device__ __forceinline__ void stage_tile(const bf16* __restrict__ base, const int64_t (&row_off)[PASSES], int64_t kcol,
-                                           char* lds_tile, int wave) {
-#pragma unroll
-  for (int i = 0; i < PASSES; ++i) {
-    const bf16* src = base + row_off[i] + kcol;
-    char* dst = lds_tile + i * (32768 / PASSES) + wave * 1024;   // wave-uniform; hardware adds lane*16
-    __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(dst), 16, 0, 0);
-  }
-}
-
-// WN = waves along N (4: 8 waves of 128x64 outputs, two per SIMD; 2: 4 waves of 128x128 outputs, one per SIMD with
-// the 512-register budget -- a third fewer LDS fragment reads per MFMA)
+// WN = waves along N: 8 waves = 2(M) x 4(N) of 128x64 outputs, two per SIMD.  (A 4-wave / 128x128-per-wave variant was
+// measured slower through hipcc -- profiles/r1b notes -- and removed.)
 template <int EPI, typename OutT, int WN>
-__global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
-  constexpr int NTHR = 128 * WN;          // 2 x WN waves
-  constexpr int NTW = 16 / WN;            // 16-wide n-tiles per wave (4 or 8)
-  constexpr int PASSES = 2048 / NTHR;     // 16-byte pieces per thread per operand tile (4 or 8)
+__global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
+  static_assert(WN == 4, "8-wave layout only");
+  constexpr int NTHR = 128 * WN;          // 512
+  constexpr int NTW = 16 / WN;            // 16-wide n-tiles per wave: 4
+  constexpr int PASSES = 2048 / NTHR;     // 16-byte pieces per thread per operand tile: 4
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
   const int tid = threadIdx.x;
@@ -91,17 +83,21 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void gemm_bf16_kernel(Ge
   const int tn = in_group / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- staging addresses: thread -> (row = i*64 + tid/8, LDS slot = tid%8), source chunk = slot ^ swz(row)
-  int64_t a_off[PASSES], w_off[PASSES];
+  // ---- staging addresses: thread -> (row = i*64 + tid/8, LDS slot = tid%8), source chunk = slot ^ swz(row).
+  // Byte offsets from the tile's first row fit 32 bits (256 rows x row stride), so a piece's source is
+  // (uniform 64-bit tile base + K offset) + one VGPR: the scalar-base form of global_load_lds.
+  uint32_t a_off[PASSES], w_off[PASSES];
 #pragma unroll
   for (int i = 0; i < PASSES; ++i) {
     const int row = i * (NTHR / 8) + (tid >> 3);
     const int chunk = (tid & 7) ^ ((row >> 1) & 7);
-    const int gm = min(m0 + row, p.M - 1);
-    const int gn = min(n0 + row, p.N - 1);
-    a_off[i] = (int64_t)gm * p.lda + chunk * 8;
-    w_off[i] = (int64_t)gn * p.ldw + chunk * 8;
+    const int rm = min(row, p.M - 1 - m0);                    // edge tiles re-read their last valid row
+    const int rn = min(row, p.N - 1 - n0);
+    a_off[i] = (uint32_t)(((int64_t)rm * p.lda + chunk * 8) * 2);
+    w_off[i] = (uint32_t)(((int64_t)rn * p.ldw + chunk * 8) * 2);
   }
+  const char* a_tile = (const char*)(p.A + (int64_t)m0 * p.lda);
+  const char* w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
 
   // ---- fragment read offsets (bytes inside a tile): row = base16 + (lane&15), chunk = (lane>>4) + 4*ks
   const int sw = (lane & 15) >> 1;
@@ -117,37 +113,93 @@ __global__ __launch_bounds__(128 * WN, WN == 4 ? 2 : 1) void gemm_bf16_kernel(Ge
   const int nk = p.K / BK;
   auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
 
-  stage_tile<PASSES>(p.A, a_off, kcol_a(0), smem, wave);
-  stage_tile<PASSES>(p.W, w_off, 0, smem + TILE_BYTES, wave);
-  int64_t kcol_next = kcol_a(1);          // offset of tile kb+1, fetched one iteration ahead
-  __syncthreads();
-
-  for (int kb = 0; kb < nk; ++kb) {
-    char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
-    if (kb + 1 < nk) {
-      char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
-      stage_tile<PASSES>(p.A, a_off, kcol_next, nxt, wave);
-      stage_tile<PASSES>(p.W, w_off, (int64_t)(kb + 1) * BK, nxt + TILE_BYTES, wave);
-    }
-    kcol_next = kcol_a(kb + 2);
-    const char* at = cur + wm * (128 * 128);
-    const char* wt = cur + TILE_BYTES + wn * (16 * NTW * 128);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int fo = ks ? frag_off1 : frag_off0;
-      bf16x8 wf[NTW], af[8];
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) wf[nt] = *(const bf16x8*)(wt + nt * 2048 + fo);
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) af[mt] = *(const bf16x8*)(at + mt * 2048 + fo);
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
-    }
+  // piece i (0..3: A rows i*64.., 4..7: W rows (i-4)*64..) of the tile at A K-offset ka / W K-offset kw -> LDS buffer `buf`.
+  // Inline asm: the scalar-base form (uniform 64-bit base + one 32-bit VGPR offset) keeps the 8 per-thread
+  // offsets in 8 VGPRs; completion is tracked by hand (s_waitcnt vmcnt(0) in front of each barrier).
+  auto dma = [&](int i, int64_t ka, int64_t kw, char* buf) {
+    const char* sbase = i < PASSES ? a_tile + ka * 2 : w_tile + kw * 2;
+    const uint32_t voff = i < PASSES ? a_off[i] : w_off[i - PASSES];
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PASSES ? 0 : TILE_BYTES) + (i & (PASSES - 1)) * (32768 / PASSES) + wave * 1024;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(dst)
+                 : "memory");
+  };
+  auto dma_wait_barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  };
+  // fragment j of a set: j < 4 -> W n-tile j, else A m-tile j-4 .. (12 per 32-deep K half)
+  auto frag = [&](const char* buf, int fo, int j) -> bf16x8 {
+    return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
+                   : *(const bf16x8*)(buf + wm * (128 * 128) + (j - NTW) * 2048 + fo);
+  };
+
+  // ---- main loop: two LDS buffers, two fragment sets (F0: k 0..31, F1: k 32..63 of a K block).  Per K block:
+  //   phase A: MFMAs on F0 while F1 is read from `cur`
+  //   barrier : every wave holds its F1 (cur is free) and tile kb+1 has landed in `nxt` for everyone
+  //   phase B: LDS-DMA of tile kb+2 into `cur`; MFMAs on F1 while F0 of block kb+1 is read from `nxt`
+  // so no wave crosses the barrier without MFMA work already in registers, and the 8 DMA pieces and 12 fragment
+  // reads of a phase are spread one group (4 MFMAs) apart instead of stalling the wave up front.
+  bf16x8 wf0[NTW], af0[8], wf1[NTW], af1[8];
+#pragma unroll
+  for (int i = 0; i < 2 * PASSES; ++i) dma(i, kcol_a(0), 0, smem);
+  int64_t kcol_next = kcol_a(1);          // A offset of the tile staged next, fetched one step ahead
+  dma_wait_barrier();
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 2 * PASSES; ++i) dma(i, kcol_next, BK, smem + 2 * TILE_BYTES);
   }
+  kcol_next = kcol_a(2);
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) wf0[j] = frag(smem, frag_off0, j);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) af0[j] = frag(smem, frag_off0, NTW + j);
+
+  // fragments 2g, 2g+1 of a set (order: W n-tiles 0..3, then A m-tiles 0..7)
+  auto ld2 = [&](const char* buf, int fo, int g, bf16x8 (&wf)[NTW], bf16x8 (&af)[8]) {
+#pragma unroll
+    for (int j = 2 * g; j < 2 * g + 2; ++j) {
+      if (j < NTW) wf[j] = frag(buf, fo, j);
+      else af[j - NTW] = frag(buf, fo, j);
+    }
+  };
+  auto block = [&](int kb, auto dma_c, auto rd_c) {
+    constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
+    char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
+    char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
+    const int64_t kw = (int64_t)(kb + 2) * BK;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {                       // phase A
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], af0[g], acc[g][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                // MFMAs first: the wait for F0 must not cover reads issued after it
+      if (g < 6) ld2(cur, frag_off1, g, wf1, af1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dma_wait_barrier();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {                       // phase B
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[g], acc[g][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DMA) dma(g, kcol_next, kw, cur);
+      if constexpr (RD) {
+        if (g < 6) ld2(nxt, frag_off0, g, wf0, af0);    // last read 8 MFMAs before the next block needs F0
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    kcol_next = kcol_a(kb + 3);
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  int kb = 0;
+  for (; kb + 2 < nk; ++kb) block(kb, T_{}, T_{});
+  if (kb + 1 < nk) { block(kb, F_{}, T_{}); ++kb; }
+  block(kb, F_{}, F_{});
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
   const int mrow = m0 + wm * 128 + (lane & 15);
@@ -214,8 +266,7 @@ int launch_w(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
 
 template <int EPI, typename OutT>
 int launch(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
-  static const int four_wave = [] { const char* e = getenv("FLEXAM_GEMM_4WAVE"); return e ? atoi(e) : 0; }();
-  return four_wave ? launch_w<EPI, OutT, 2>(p, a_koff, s) : launch_w<EPI, OutT, 4>(p, a_koff, s);
+  return launch_w<EPI, OutT, 4>(p, a_koff, s);
 }
 
 }  // namespace
