@@ -9,11 +9,16 @@
 //
 // MI355X mapping (MI355X_MICROARCH.md / cdna_hip_programming.md section 5):
 //  * 256x256x64 tile per 512-thread workgroup (8 waves = 2(M) x 4(N), 128x64 outputs per wave),
-//    one workgroup per CU, accumulators in 128 VGPRs/AGPRs per lane.
+//    one workgroup per CU, accumulators in 128 VGPRs per lane; shorter tiles (224..128 rows) are picked
+//    when they fill the last round of 256 CUs (pick_mt).
 //  * both operands staged HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round trip), two
 //    LDS buffers (2 x 64 KiB); tile rows are 128 B so the 16-B chunk index is XOR-swizzled with
 //    (row>>1)&7 on the *source* address (the LDS image must stay lane-linear for LDS-DMA) and
 //    again on the ds_read_b128 fragment reads: conflict-free per tools/lds_sim.py.
+//  * software pipeline: two fragment register sets and ONE barrier per 64-deep K block placed between
+//    the two 32-deep halves, so MFMA work is always in registers on both sides of the barrier; the
+//    LDS-DMA pieces and ds_reads of a phase are issued one per 4 MFMAs (an LDS-DMA piece costs ~40
+//    issue cycles next to MFMAs, tools/probes/issue_probe.hip).
 //  * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment in the A slot) so each lane
 //    ends up with 4 consecutive N columns of one output row -> 8-byte bf16 / 16-byte f32 stores.
 //  * workgroup -> tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
@@ -28,9 +33,8 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int NT = 512;
-constexpr int TILE_BYTES = BM * BK * 2;   // 32 KiB per operand tile
+constexpr int BN = 256, BK = 64;
+constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB per operand tile (A: up to 256 rows)
 
 struct GemmParams {
   const bf16* A;
@@ -47,24 +51,29 @@ struct GemmParams {
   int64_t gate_ld;
   const int32_t* gate_row; // [M] row index per output row, or null
   int64_t rows_per_batch;  // used when gate_row is null: row = m / rows_per_batch
+  int debug;               // FLEXAM_GEMM_DEBUG bit mask, TIMING ABLATIONS ONLY (wrong results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA
 };
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 
-// WN = waves along N: 8 waves = 2(M) x 4(N) of 128x64 outputs, two per SIMD.  (A 4-wave / 128x128-per-wave variant was
-// measured slower through hipcc -- profiles/r1b notes -- and removed.)
-template <int EPI, typename OutT, int WN>
-__global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
-  static_assert(WN == 4, "8-wave layout only");
-  constexpr int NTHR = 128 * WN;          // 512
-  constexpr int NTW = 16 / WN;            // 16-wide n-tiles per wave: 4
-  constexpr int PASSES = 2048 / NTHR;     // 16-byte pieces per thread per operand tile: 4
+// MT = 16-row m-tiles per wave: the workgroup tile is (32*MT) x 256 outputs, 8 waves = 2(M) x 4(N), two per SIMD.
+// MT = 8 (256 x 256) is the throughput shape; 7..4 exist so that a launch whose tile count is a little over a
+// multiple of the 256 CUs (N = 3072 projections: 91 x 12 tiles = 4.27 rounds) can trade tile height for a
+// full last round (launch() picks MT).  (A 4-wave / 128x128-per-wave variant was measured slower through
+// hipcc -- profiles/r1b notes -- and removed.)
+template <int EPI, typename OutT, int MT>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
+  constexpr int NTW = 4;                    // 16-wide n-tiles per wave
+  constexpr int BM_ = 32 * MT;              // rows of this tile shape
+  constexpr int PA = (BM_ + 63) / 64;       // 64-row staging pieces per thread for A (W always 4)
+  constexpr int NP = PA + 4;                // LDS-DMA pieces per thread per K block
+  constexpr int NF = NTW + MT;              // fragments per 32-deep K half
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave >> 2, wn = wave & 3;
 
   // ---- XCD-aware, grouped tile order
   const int nwg = p.tiles_m * p.tiles_n;
@@ -81,20 +90,18 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_kernel(GemmParams p, co
   const int in_group = bid - group * per_group;
   const int tm = first_m + in_group % gsz;
   const int tn = in_group / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM_, n0 = tn * BN;
 
   // ---- staging addresses: thread -> (row = i*64 + tid/8, LDS slot = tid%8), source chunk = slot ^ swz(row).
   // Byte offsets from the tile's first row fit 32 bits (256 rows x row stride), so a piece's source is
   // (uniform 64-bit tile base + K offset) + one VGPR: the scalar-base form of global_load_lds.
-  uint32_t a_off[PASSES], w_off[PASSES];
+  uint32_t a_off[PA], w_off[4];
 #pragma unroll
-  for (int i = 0; i < PASSES; ++i) {
-    const int row = i * (NTHR / 8) + (tid >> 3);
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 64 + (tid >> 3);
     const int chunk = (tid & 7) ^ ((row >> 1) & 7);
-    const int rm = min(row, p.M - 1 - m0);                    // edge tiles re-read their last valid row
-    const int rn = min(row, p.N - 1 - n0);
-    a_off[i] = (uint32_t)(((int64_t)rm * p.lda + chunk * 8) * 2);
-    w_off[i] = (uint32_t)(((int64_t)rn * p.ldw + chunk * 8) * 2);
+    if (i < PA) a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);   // edge tiles re-read their last row
+    w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
   }
   const char* a_tile = (const char*)(p.A + (int64_t)m0 * p.lda);
   const char* w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
@@ -104,92 +111,92 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_kernel(GemmParams p, co
   const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
   const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
 
-  f32x4 acc[8][NTW];
+  f32x4 acc[MT][NTW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
   auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
 
-  // piece i (0..3: A rows i*64.., 4..7: W rows (i-4)*64..) of the tile at A K-offset ka / W K-offset kw -> LDS buffer `buf`.
-  // Inline asm: the scalar-base form (uniform 64-bit base + one 32-bit VGPR offset) keeps the 8 per-thread
-  // offsets in 8 VGPRs; completion is tracked by hand (s_waitcnt vmcnt(0) in front of each barrier).
+  // piece i (i < PA: A rows i*64.., else W rows (i-PA)*64..) of the tile at A K-offset ka / W K-offset kw -> LDS buffer `buf`.
+  // Inline asm: the scalar-base form (uniform 64-bit base + one 32-bit VGPR offset) keeps the per-thread
+  // offsets in PA + 4 VGPRs; completion is tracked by hand (s_waitcnt vmcnt(0) in front of each barrier).
   auto dma = [&](int i, int64_t ka, int64_t kw, char* buf) {
-    const char* sbase = i < PASSES ? a_tile + ka * 2 : w_tile + kw * 2;
-    const uint32_t voff = i < PASSES ? a_off[i] : w_off[i - PASSES];
-    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PASSES ? 0 : TILE_BYTES) + (i & (PASSES - 1)) * (32768 / PASSES) + wave * 1024;
+    const char* sbase = i < PA ? a_tile + ka * 2 : w_tile + kw * 2;
+    const uint32_t voff = i < PA ? a_off[i] : w_off[i - PA];
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * 8192 : TILE_BYTES + (i - PA) * 8192) + wave * 1024;
     uint32_t keep;
+    if (p.debug & 4) return;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(dst)
                  : "memory");
   };
   auto dma_wait_barrier = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(p.debug & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.debug & 2)) __syncthreads();
   };
-  // fragment j of a set: j < 4 -> W n-tile j, else A m-tile j-4 .. (12 per 32-deep K half)
+  // fragment j of a set: j < 4 -> W n-tile j, else A m-tile j-4
   auto frag = [&](const char* buf, int fo, int j) -> bf16x8 {
     return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
-                   : *(const bf16x8*)(buf + wm * (128 * 128) + (j - NTW) * 2048 + fo);
+                   : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
+  };
+  // fragments 2g, 2g+1 of a set
+  auto ld2 = [&](const char* buf, int fo, int g, bf16x8 (&wf)[NTW], bf16x8 (&af)[MT]) {
+#pragma unroll
+    for (int j = 2 * g; j < 2 * g + 2; ++j) {
+      if (j < NTW) wf[j] = frag(buf, fo, j);
+      else if (j < NF) af[j - NTW] = frag(buf, fo, j);
+    }
   };
 
   // ---- main loop: two LDS buffers, two fragment sets (F0: k 0..31, F1: k 32..63 of a K block).  Per K block:
   //   phase A: MFMAs on F0 while F1 is read from `cur`
   //   barrier : every wave holds its F1 (cur is free) and tile kb+1 has landed in `nxt` for everyone
   //   phase B: LDS-DMA of tile kb+2 into `cur`; MFMAs on F1 while F0 of block kb+1 is read from `nxt`
-  // so no wave crosses the barrier without MFMA work already in registers, and the 8 DMA pieces and 12 fragment
+  // so no wave crosses the barrier without MFMA work already in registers, and the DMA pieces and fragment
   // reads of a phase are spread one group (4 MFMAs) apart instead of stalling the wave up front.
-  bf16x8 wf0[NTW], af0[8], wf1[NTW], af1[8];
+  bf16x8 wf0[NTW], af0[MT], wf1[NTW], af1[MT];
 #pragma unroll
-  for (int i = 0; i < 2 * PASSES; ++i) dma(i, kcol_a(0), 0, smem);
+  for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
   int64_t kcol_next = kcol_a(1);          // A offset of the tile staged next, fetched one step ahead
   dma_wait_barrier();
   if (nk > 1) {
 #pragma unroll
-    for (int i = 0; i < 2 * PASSES; ++i) dma(i, kcol_next, BK, smem + 2 * TILE_BYTES);
+    for (int i = 0; i < NP; ++i) dma(i, kcol_next, BK, smem + 2 * TILE_BYTES);
   }
   kcol_next = kcol_a(2);
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) wf0[j] = frag(smem, frag_off0, j);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) af0[j] = frag(smem, frag_off0, NTW + j);
+  for (int g = 0; g < (NF + 1) / 2; ++g) ld2(smem, frag_off0, g, wf0, af0);
 
-  // fragments 2g, 2g+1 of a set (order: W n-tiles 0..3, then A m-tiles 0..7)
-  auto ld2 = [&](const char* buf, int fo, int g, bf16x8 (&wf)[NTW], bf16x8 (&af)[8]) {
-#pragma unroll
-    for (int j = 2 * g; j < 2 * g + 2; ++j) {
-      if (j < NTW) wf[j] = frag(buf, fo, j);
-      else af[j - NTW] = frag(buf, fo, j);
-    }
-  };
   auto block = [&](int kb, auto dma_c, auto rd_c) {
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
     char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
     char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
     const int64_t kw = (int64_t)(kb + 2) * BK;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {                       // phase A
+    for (int g = 0; g < MT; ++g) {                      // phase A
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], af0[g], acc[g][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                // MFMAs first: the wait for F0 must not cover reads issued after it
-      if (g < 6) ld2(cur, frag_off1, g, wf1, af1);
+      ld2(cur, frag_off1, g, wf1, af1);
     }
     __builtin_amdgcn_sched_barrier(0);
     dma_wait_barrier();
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {                       // phase B
+    for (int g = 0; g < MT; ++g) {                      // phase B
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[g], acc[g][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DMA) dma(g, kcol_next, kw, cur);
-      if constexpr (RD) {
-        if (g < 6) ld2(nxt, frag_off0, g, wf0, af0);    // last read 8 MFMAs before the next block needs F0
+      if constexpr (DMA) {
+        dma(g, kcol_next, kw, cur);
+        if (g + MT < NP) dma(g + MT, kcol_next, kw, cur);
       }
+      if constexpr (RD) ld2(nxt, frag_off0, g, wf0, af0);
     }
     __builtin_amdgcn_sched_barrier(0);
     kcol_next = kcol_a(kb + 3);
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_kernel(GemmParams p, co
   block(kb, F_{}, F_{});
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
-  const int mrow = m0 + wm * 128 + (lane & 15);
+  const int mrow = m0 + wm * (16 * MT) + (lane & 15);
   const int ncol = n0 + wn * (16 * NTW) + (lane >> 4) * 4;
   f32x4 bias[NTW];
 #pragma unroll
@@ -211,7 +218,7 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_kernel(GemmParams p, co
     bias[nt] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int m = mrow + mt * 16;
     if (m >= p.M) continue;
     const float* grow = nullptr;
@@ -250,9 +257,203 @@ __global__ __launch_bounds__(128 * WN, 2) void gemm_bf16_kernel(GemmParams p, co
   }
 }
 
-template <int EPI, typename OutT, int WN>
-int launch_w(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
-  auto kern = gemm_bf16_kernel<EPI, OutT, WN>;
+// ------------------------------------------------------------------------------------------------
+// 4-wave variant: 256 threads, waves 2(M) x 2(N), 128 x 128 outputs per wave, one wave per SIMD with the
+// 512-register budget (256 accumulators in AGPRs).  Same LDS image, staging and two-phase pipeline as above,
+// but a third fewer LDS fragment bytes per MFMA: on a power-capped part that is clock, not just cycles.
+// The MFMAs are inline asm with "+a" accumulators: with this register budget hipcc's builtin form shuttles
+// the accumulators between AGPRs and VGPRs (~150 copies per K block).
+// ------------------------------------------------------------------------------------------------
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_w4(GemmParams p, const int64_t* __restrict__ a_koff) {
+  constexpr int MT = 8, NTW = 8, NF = 16, NP = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int group = bid / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = bid - group * per_group;
+  const int tm = first_m + in_group % gsz;
+  const int tn = in_group / gsz;
+  const int m0 = tm * 256, n0 = tn * BN;
+
+  // staging: thread -> (row = i*32 + tid/8, LDS slot = tid%8); 8 pieces per operand tile
+  uint32_t a_off[8], w_off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = i * 32 + (tid >> 3);
+    const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+    a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);
+    w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
+  }
+  const char* a_tile = (const char*)(p.A + (int64_t)m0 * p.lda);
+  const char* w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
+
+  const int sw = (lane & 15) >> 1;
+  const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
+  const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
+
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
+  auto dma = [&](int i, int64_t ka, int64_t kw, char* buf) {
+    const char* sbase = i < 8 ? a_tile + ka * 2 : w_tile + kw * 2;
+    const uint32_t voff = i < 8 ? a_off[i] : w_off[i - 8];
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < 8 ? i * 4096 : TILE_BYTES + (i - 8) * 4096) + wave * 1024;
+    uint32_t keep;
+    if (p.debug & 4) return;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(dst)
+                 : "memory");
+  };
+  auto dma_wait_barrier = [&]() {
+    if (!(p.debug & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(p.debug & 2)) __syncthreads();
+  };
+  auto frag = [&](const char* buf, int fo, int j) -> bf16x8 {
+    return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
+                   : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
+  };
+  auto ld2 = [&](const char* buf, int fo, int g, bf16x8 (&wf)[NTW], bf16x8 (&af)[MT]) {
+#pragma unroll
+    for (int j = 2 * g; j < 2 * g + 2; ++j) {
+      if (j < NTW) wf[j] = frag(buf, fo, j);
+      else if (j < NF) af[j - NTW] = frag(buf, fo, j);
+    }
+  };
+  auto mfma8 = [&](int g, const bf16x8 (&wf)[NTW], const bf16x8 (&af)[MT]) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[g][nt]) : "v"(wf[nt]), "v"(af[g]));
+  };
+
+  bf16x8 wf0[NTW], af0[MT], wf1[NTW], af1[MT];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
+  int64_t kcol_next = kcol_a(1);
+  dma_wait_barrier();
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dma(i, kcol_next, BK, smem + 2 * TILE_BYTES);
+  }
+  kcol_next = kcol_a(2);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) ld2(smem, frag_off0, g, wf0, af0);
+
+  auto block = [&](int kb, auto dma_c, auto rd_c) {
+    constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
+    char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
+    char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
+    const int64_t kw = (int64_t)(kb + 2) * BK;
+#pragma unroll
+    for (int g = 0; g < MT; ++g) {                      // phase A
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(g, wf0, af0);
+      __builtin_amdgcn_sched_barrier(0);
+      ld2(cur, frag_off1, g, wf1, af1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dma_wait_barrier();
+#pragma unroll
+    for (int g = 0; g < MT; ++g) {                      // phase B
+      __builtin_amdgcn_sched_barrier(0);
+      mfma8(g, wf1, af1);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DMA) {
+        dma(2 * g, kcol_next, kw, cur);
+        dma(2 * g + 1, kcol_next, kw, cur);
+      }
+      if constexpr (RD) ld2(nxt, frag_off0, g, wf0, af0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    kcol_next = kcol_a(kb + 3);
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  int kb = 0;
+  for (; kb + 2 < nk; ++kb) block(kb, T_{}, T_{});
+  if (kb + 1 < nk) { block(kb, F_{}, T_{}); ++kb; }
+  block(kb, F_{}, F_{});
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the compiler does not know the asm above were MFMAs: cover the AGPR read hazard
+
+  const int mrow = m0 + wm * (16 * MT) + (lane & 15);
+  const int ncol = n0 + wn * (16 * NTW) + (lane >> 4) * 4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mrow + mt * 16;
+    if (m >= p.M) continue;
+    const float* grow = nullptr;
+    if constexpr (EPI == EPI_GATE_RESIDUAL) {
+      if (p.gate) {
+        const int64_t r = p.gate_row ? (int64_t)p.gate_row[m] : (int64_t)m / p.rows_per_batch;
+        grow = p.gate + r * p.gate_ld;
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int n = ncol + nt * 16;
+      if (n >= p.N) continue;
+      f32x4 v = acc[mt][nt];
+      if (p.bias) v += *(const f32x4*)(p.bias + n);
+      if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
+      }
+      if constexpr (EPI == EPI_GATE_RESIDUAL) {
+        float* xp = p.X + (int64_t)m * p.ldx + n;
+        f32x4 x = *(const f32x4*)xp;
+        f32x4 g = grow ? *(const f32x4*)(grow + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(v[j])) * g[j];
+        *(f32x4*)xp = x;
+      } else if constexpr (sizeof(OutT) == 2) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+        *(bf16x4*)((bf16*)p.C + (int64_t)m * p.ldc + n) = o;
+      } else {
+        *(f32x4*)((float*)p.C + (int64_t)m * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
+template <int EPI, typename OutT>
+int launch_w4(GemmParams p, const int64_t* a_koff, hipStream_t s) {
+  auto kern = gemm_bf16_kernel_w4<EPI, OutT>;
+  static bool attr_set = false;
+  const int smem = 4 * TILE_BYTES;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
+    attr_set = true;
+  }
+  p.tiles_m = (p.M + 255) / 256;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p, a_koff);
+  return flexam_check_launch("flexam_gemm_bf16");
+}
+
+template <int EPI, typename OutT, int MT>
+int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
+  auto kern = gemm_bf16_kernel<EPI, OutT, MT>;
   static bool attr_set = false;
   const int smem = 4 * TILE_BYTES;   // 128 KiB
   if (!attr_set) {
@@ -260,13 +461,41 @@ int launch_w(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
       return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(128 * WN), smem, s, p, a_koff);
+  p.tiles_m = (p.M + 32 * MT - 1) / (32 * MT);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p, a_koff);
   return flexam_check_launch("flexam_gemm_bf16");
 }
 
+// Tile height: rounds of 256 concurrently resident workgroups x relative cost of one tile (MT m-tiles of MFMA work
+// plus a fixed part for the W side, barriers and the epilogue); FLEXAM_GEMM_MT=8..4 forces a shape (tuning only).
+int pick_mt(int M, int tiles_n) {
+  const char* e = getenv("FLEXAM_GEMM_MT");
+  const int forced = e ? atoi(e) : 0;
+  if (forced >= 4 && forced <= 8) return forced;
+  int best = 8;
+  double best_cost = 1e30;
+  for (int mt = 8; mt >= 4; --mt) {
+    const long tiles = (long)((M + 32 * mt - 1) / (32 * mt)) * tiles_n;
+    const double cost = (double)((tiles + 255) / 256) * (mt + 1.25);
+    if (cost < best_cost * 0.97) { best_cost = cost; best = mt; }      // a smaller tile must win by > 3 %
+  }
+  return best;
+}
+
 template <int EPI, typename OutT>
-int launch(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
-  return launch_w<EPI, OutT, 4>(p, a_koff, s);
+int launch(const GemmParams& p_, const int64_t* a_koff, hipStream_t s) {
+  GemmParams p = p_;
+  const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
+  p.debug = dbg ? atoi(dbg) : 0;
+  const char* e = getenv("FLEXAM_GEMM_W4");
+  if (e && atoi(e) == 1) return launch_w4<EPI, OutT>(p, a_koff, s);
+  switch (pick_mt(p.M, p.tiles_n)) {
+    case 7: return launch_mt<EPI, OutT, 7>(p, a_koff, s);
+    case 6: return launch_mt<EPI, OutT, 6>(p, a_koff, s);
+    case 5: return launch_mt<EPI, OutT, 5>(p, a_koff, s);
+    case 4: return launch_mt<EPI, OutT, 4>(p, a_koff, s);
+    default: return launch_mt<EPI, OutT, 8>(p, a_koff, s);
+  }
 }
 
 }  // namespace
@@ -284,7 +513,7 @@ extern "C" int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64
   GemmParams p{};
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+  p.tiles_n = (int)((N + BN - 1) / BN);   // tiles_m depends on the tile height launch() picks
   hipStream_t s = (hipStream_t)stream;
   if (out_f32) {
     FX_REQUIRE(epilogue == EPI_NONE, FLEXAM_E_ARG, "gemm: f32 output supports no activation epilogue");
@@ -305,7 +534,7 @@ extern "C" int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const 
   GemmParams p{};
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = nullptr; p.bias = bias;
   p.lda = lda; p.ldw = ldw; p.ldc = 0; p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+  p.tiles_n = (int)((N + BN - 1) / BN);   // tiles_m depends on the tile height launch() picks
   p.X = X; p.ldx = ldx; p.gate = gate; p.gate_ld = gate_ld; p.gate_row = gate_row;
   p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
   return launch<EPI_GATE_RESIDUAL, bf16>(p, a_koff, (hipStream_t)stream);

@@ -61,6 +61,34 @@ def test_gemm_exact_integers(H, m, n, k):
     torch.testing.assert_close(out.cpu(), a @ w.t() + b, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("mt", [4, 5, 6, 7, 8, "w4"])
+def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
+    """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on
+    ragged sizes, for the plain, fp32-out and gated-residual epilogues."""
+    if mt == "w4":
+        monkeypatch.setenv("FLEXAM_GEMM_W4", "1")       # the 4-wave, 128x128-per-wave kernel
+        mt = 9
+    else:
+        monkeypatch.setenv("FLEXAM_GEMM_W4", "0")
+        monkeypatch.setenv("FLEXAM_GEMM_MT", str(mt))
+    g = torch.Generator().manual_seed(100 + mt)
+    m, n, k = 1000, 772, 192
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    w = torch.randint(-3, 4, (n, k), generator=g).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    want = a @ w.t() + b
+    out = H.gemm(bf(a).to(dev()), bf(w).to(dev()), b.to(dev()), out_dtype=torch.float32)
+    torch.testing.assert_close(out.cpu(), want, rtol=0, atol=0)
+    out16 = H.gemm(bf(a).to(dev()), bf(w).to(dev()), b.to(dev()))
+    torch.testing.assert_close(out16.float().cpu(), want.to(BF).float(), rtol=0, atol=0)
+    x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+    gate = torch.randint(-2, 3, (3, n), generator=g).float()
+    rows = torch.randint(0, 3, (m,), generator=g, dtype=torch.int32)
+    x = x0.clone().to(dev())
+    H.gemm_gate_residual(bf(a).to(dev()), bf(w).to(dev()), b.to(dev()), x, gate.to(dev()), rows.to(dev()))
+    torch.testing.assert_close(x.cpu(), x0 + want.to(BF).float() * gate[rows.long()], rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("epi", ["none", "gelu"])
 def test_gemm_random_bf16_out_strided(H, epi):
     g = torch.Generator().manual_seed(5)

@@ -79,11 +79,73 @@ void run_(const char* name, const char* src, uint64_t* out, float* sink) {
   printf("%-44s x%d per 8 MFMA: %7.1f cyc/iter  (+%6.1f over bare 128; %5.1f per extra)\n", name, CNT, cyc, cyc - 128.0, (cyc - 128.0) / CNT);
 }
 
+
+// GEMM-like mix per iteration (8 MFMA): NREAD ds_read_b128 + staging of STG KiB by (KIND 0) LDS-DMA or (KIND 1)
+// global_load_dwordx4 -> VGPR -> ds_write_b128 (written one iteration later).  NW waves per workgroup (4 or 8).
+template <int KIND, int STG, int NREAD, int NW>
+__global__ __launch_bounds__(NW * 64) void mix(const char* __restrict__ src, uint64_t* __restrict__ out, float* sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.01f * ((lane * 7 + i) % 13)); b[i] = (__bf16)(0.02f * ((lane * 5 + i) % 11)); }
+  f32x4 acc[8];
+  for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const char* g = src + (size_t)blockIdx.x * 262144 + threadIdx.x * 16;
+  const uint32_t lds_lane = wave * 1024 + lane * 16;
+  i32x4 st[2] = {{1, 2, 3, 4}, {5, 6, 7, 8}};
+  i32x4 rd = {0, 0, 0, 0};
+  __syncthreads();
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    const char* gp = g + (it & 15) * 8192;
+    const uint32_t lp = (it & 3) * 8192 * (NW / 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+      if (j < NREAD) asm volatile("ds_read_b128 %0, %1" : "+v"(rd) : "v"(lds_lane + 32768 + j * 1024 * NW / 4) : "memory");
+      if (STG > 0 && j >= 8 - STG) {
+        const int e = j - (8 - STG);
+        if constexpr (KIND == 0) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + e * 65536),
+                                           (__attribute__((address_space(3))) void*)(smem + lp + wave * 1024 + e * 1024 * NW), 16, 0, 0);
+        } else {
+          asm volatile("ds_write_b128 %0, %1" ::"v"(lds_lane + lp + e * 1024 * NW), "v"(st[e & 1]) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(st[e & 1]) : "v"(gp + e * 65536) : "memory");
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  s += (float)(rd[0] ^ rd[1] ^ st[0][0] ^ st[1][1]) * 1e-30f;
+  if (s == 123.456f) sink[0] = s + smem[lane];
+  if (lane == 0) out[blockIdx.x * NW + wave] = t1 - t0;
+}
+
+template <int KIND, int STG, int NREAD, int NW>
+void run_mix(const char* name, const char* src, uint64_t* out, float* sink) {
+  const int iters = 4000, nb = 256;
+  static uint64_t h[256 * 8];
+  auto k = mix<KIND, STG, NREAD, NW>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k, dim3(nb), dim3(NW * 64), 131072, 0, src, out, sink, iters);
+  hipDeviceSynchronize();
+  hipMemcpy(h, out, sizeof(uint64_t) * nb * NW, hipMemcpyDeviceToHost);
+  double sum = 0;
+  for (int i = 0; i < nb * NW; ++i) sum += (double)h[i];
+  const double cyc = sum / (nb * NW) / iters;
+  printf("%d waves/WG  %-36s stage %d KiB + %d ds_read per 8 MFMA: %7.1f cyc/iter/wave -> MFMA pipe use %4.1f %%\n", NW, name, STG, NREAD, cyc,
+         100.0 * 128.0 * (NW / 4) / cyc);
+  fflush(stdout);
+}
+
 int main() {
   char* src; uint64_t* out; float* sink;
   hipMalloc(&src, (size_t)256 * 262144 + 1048576);
   hipMemset(src, 1, (size_t)256 * 262144 + 1048576);
-  hipMalloc(&out, 256 * 4 * 8);
+  hipMalloc(&out, 256 * 8 * 8);
   hipMalloc(&sink, 64);
   run<0, 1>("bare MFMA loop", src, out, sink);
   run<1, 1>("global_load_lds_dwordx4 (LDS-DMA)", src, out, sink);
@@ -101,5 +163,18 @@ int main() {
   run<4, 8>("ds_read_b128", src, out, sink);
   run<6, 2>("global_load_dwordx4 + ds_write_b128", src, out, sink);
   run<6, 4>("global_load_dwordx4 + ds_write_b128", src, out, sink);
+  printf("---- GEMM-like mixes (W4 density: 1 KiB staged + 2 reads per 8 MFMA per wave; 8-wave density: 1 KiB + 3 reads)\n");
+  run_mix<0, 0, 0, 4>("MFMA only", src, out, sink);
+  run_mix<0, 0, 2, 4>("reads only", src, out, sink);
+  run_mix<0, 1, 2, 4>("LDS-DMA", src, out, sink);
+  run_mix<1, 1, 2, 4>("global_load + ds_write_b128", src, out, sink);
+  run_mix<0, 2, 2, 4>("LDS-DMA", src, out, sink);
+  run_mix<1, 2, 2, 4>("global_load + ds_write_b128", src, out, sink);
+  run_mix<0, 0, 0, 8>("MFMA only", src, out, sink);
+  run_mix<0, 0, 3, 8>("reads only", src, out, sink);
+  run_mix<0, 1, 3, 8>("LDS-DMA", src, out, sink);
+  run_mix<1, 1, 3, 8>("global_load + ds_write_b128", src, out, sink);
+  run_mix<0, 2, 3, 8>("LDS-DMA", src, out, sink);
+  run_mix<1, 2, 3, 8>("global_load + ds_write_b128", src, out, sink);
   return 0;
 }
