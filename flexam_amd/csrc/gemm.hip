@@ -51,16 +51,23 @@ struct GemmParams {
   int64_t gate_ld;
   const int32_t* gate_row; // [M] row index per output row, or null
   int64_t rows_per_batch;  // used when gate_row is null: row = m / rows_per_batch
-  int debug;               // FLEXAM_GEMM_DEBUG bit mask, TIMING ABLATIONS ONLY (wrong results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA
+  int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA
 };
+
+#ifdef FLEXAM_GEMM_ABLATE
+#define ABLATE(p, bit) ((p).debug & (bit))
+#else
+#define ABLATE(p, bit) 0
+#endif
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 
 // MT = 16-row m-tiles per wave: the workgroup tile is (32*MT) x 256 outputs, 8 waves = 2(M) x 4(N), two per SIMD.
 // MT = 8 (256 x 256) is the throughput shape; 7..4 exist so that a launch whose tile count is a little over a
 // multiple of the 256 CUs (N = 3072 projections: 91 x 12 tiles = 4.27 rounds) can trade tile height for a
-// full last round (launch() picks MT).  (A 4-wave / 128x128-per-wave variant was measured slower through
-// hipcc -- profiles/r1b notes -- and removed.)
+// full last round (launch() picks MT).  (A 4-wave variant with 128x128 outputs per wave, one wave per SIMD and
+// AGPR accumulators ran at a higher clock -- a third fewer LDS bytes per MFMA -- but lower MFMA occupancy, 5-8 %
+// slower overall: profiles/r1e_gemm_notes.txt; it is in the history, not in the tree.)
 template <int EPI, typename OutT, int MT>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
   constexpr int NTW = 4;                    // 16-wide n-tiles per wave
@@ -128,15 +135,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     const uint32_t voff = i < PA ? a_off[i] : w_off[i - PA];
     const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * 8192 : TILE_BYTES + (i - PA) * 8192) + wave * 1024;
     uint32_t keep;
-    if (p.debug & 4) return;
+    if (ABLATE(p, 4)) return;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(dst)
                  : "memory");
   };
   auto dma_wait_barrier = [&]() {
-    if (!(p.debug & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(p.debug & 2)) __syncthreads();
+    if (!ABLATE(p, 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!ABLATE(p, 2)) __syncthreads();
   };
   // fragment j of a set: j < 4 -> W n-tile j, else A m-tile j-4
   auto frag = [&](const char* buf, int fo, int j) -> bf16x8 {
@@ -257,200 +264,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// 4-wave variant: 256 threads, waves 2(M) x 2(N), 128 x 128 outputs per wave, one wave per SIMD with the
-// 512-register budget (256 accumulators in AGPRs).  Same LDS image, staging and two-phase pipeline as above,
-// but a third fewer LDS fragment bytes per MFMA: on a power-capped part that is clock, not just cycles.
-// The MFMAs are inline asm with "+a" accumulators: with this register budget hipcc's builtin form shuttles
-// the accumulators between AGPRs and VGPRs (~150 copies per K block).
-// ------------------------------------------------------------------------------------------------
-template <int EPI, typename OutT>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_kernel_w4(GemmParams p, const int64_t* __restrict__ a_koff) {
-  constexpr int MT = 8, NTW = 8, NF = 16, NP = 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
-  constexpr int GM = 8;
-  const int per_group = GM * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(p.tiles_m - first_m, GM);
-  const int in_group = bid - group * per_group;
-  const int tm = first_m + in_group % gsz;
-  const int tn = in_group / gsz;
-  const int m0 = tm * 256, n0 = tn * BN;
-
-  // staging: thread -> (row = i*32 + tid/8, LDS slot = tid%8); 8 pieces per operand tile
-  uint32_t a_off[8], w_off[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = i * 32 + (tid >> 3);
-    const int chunk = (tid & 7) ^ ((row >> 1) & 7);
-    a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);
-    w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
-  }
-  const char* a_tile = (const char*)(p.A + (int64_t)m0 * p.lda);
-  const char* w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
-
-  const int sw = (lane & 15) >> 1;
-  const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
-  const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
-
-  f32x4 acc[MT][NTW];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
-  auto dma = [&](int i, int64_t ka, int64_t kw, char* buf) {
-    const char* sbase = i < 8 ? a_tile + ka * 2 : w_tile + kw * 2;
-    const uint32_t voff = i < 8 ? a_off[i] : w_off[i - 8];
-    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < 8 ? i * 4096 : TILE_BYTES + (i - 8) * 4096) + wave * 1024;
-    uint32_t keep;
-    if (p.debug & 4) return;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(dst)
-                 : "memory");
-  };
-  auto dma_wait_barrier = [&]() {
-    if (!(p.debug & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!(p.debug & 2)) __syncthreads();
-  };
-  auto frag = [&](const char* buf, int fo, int j) -> bf16x8 {
-    return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
-                   : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
-  };
-  auto ld2 = [&](const char* buf, int fo, int g, bf16x8 (&wf)[NTW], bf16x8 (&af)[MT]) {
-#pragma unroll
-    for (int j = 2 * g; j < 2 * g + 2; ++j) {
-      if (j < NTW) wf[j] = frag(buf, fo, j);
-      else if (j < NF) af[j - NTW] = frag(buf, fo, j);
-    }
-  };
-  auto mfma8 = [&](int g, const bf16x8 (&wf)[NTW], const bf16x8 (&af)[MT]) {
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[g][nt]) : "v"(wf[nt]), "v"(af[g]));
-  };
-
-  bf16x8 wf0[NTW], af0[MT], wf1[NTW], af1[MT];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
-  int64_t kcol_next = kcol_a(1);
-  dma_wait_barrier();
-  if (nk > 1) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) dma(i, kcol_next, BK, smem + 2 * TILE_BYTES);
-  }
-  kcol_next = kcol_a(2);
-#pragma unroll
-  for (int g = 0; g < 8; ++g) ld2(smem, frag_off0, g, wf0, af0);
-
-  auto block = [&](int kb, auto dma_c, auto rd_c) {
-    constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
-    char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
-    char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
-    const int64_t kw = (int64_t)(kb + 2) * BK;
-#pragma unroll
-    for (int g = 0; g < MT; ++g) {                      // phase A
-      __builtin_amdgcn_sched_barrier(0);
-      mfma8(g, wf0, af0);
-      __builtin_amdgcn_sched_barrier(0);
-      ld2(cur, frag_off1, g, wf1, af1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    dma_wait_barrier();
-#pragma unroll
-    for (int g = 0; g < MT; ++g) {                      // phase B
-      __builtin_amdgcn_sched_barrier(0);
-      mfma8(g, wf1, af1);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DMA) {
-        dma(2 * g, kcol_next, kw, cur);
-        dma(2 * g + 1, kcol_next, kw, cur);
-      }
-      if constexpr (RD) ld2(nxt, frag_off0, g, wf0, af0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    kcol_next = kcol_a(kb + 3);
-  };
-  using T_ = std::integral_constant<bool, true>;
-  using F_ = std::integral_constant<bool, false>;
-  int kb = 0;
-  for (; kb + 2 < nk; ++kb) block(kb, T_{}, T_{});
-  if (kb + 1 < nk) { block(kb, F_{}, T_{}); ++kb; }
-  block(kb, F_{}, F_{});
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // the compiler does not know the asm above were MFMAs: cover the AGPR read hazard
-
-  const int mrow = m0 + wm * (16 * MT) + (lane & 15);
-  const int ncol = n0 + wn * (16 * NTW) + (lane >> 4) * 4;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = mrow + mt * 16;
-    if (m >= p.M) continue;
-    const float* grow = nullptr;
-    if constexpr (EPI == EPI_GATE_RESIDUAL) {
-      if (p.gate) {
-        const int64_t r = p.gate_row ? (int64_t)p.gate_row[m] : (int64_t)m / p.rows_per_batch;
-        grow = p.gate + r * p.gate_ld;
-      }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int n = ncol + nt * 16;
-      if (n >= p.N) continue;
-      f32x4 v = acc[mt][nt];
-      if (p.bias) v += *(const f32x4*)(p.bias + n);
-      if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
-      }
-      if constexpr (EPI == EPI_GATE_RESIDUAL) {
-        float* xp = p.X + (int64_t)m * p.ldx + n;
-        f32x4 x = *(const f32x4*)xp;
-        f32x4 g = grow ? *(const f32x4*)(grow + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(v[j])) * g[j];
-        *(f32x4*)xp = x;
-      } else if constexpr (sizeof(OutT) == 2) {
-        bf16x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-        *(bf16x4*)((bf16*)p.C + (int64_t)m * p.ldc + n) = o;
-      } else {
-        *(f32x4*)((float*)p.C + (int64_t)m * p.ldc + n) = v;
-      }
-    }
-  }
-}
-
-template <int EPI, typename OutT>
-int launch_w4(GemmParams p, const int64_t* a_koff, hipStream_t s) {
-  auto kern = gemm_bf16_kernel_w4<EPI, OutT>;
-  static bool attr_set = false;
-  const int smem = 4 * TILE_BYTES;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-      return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
-    attr_set = true;
-  }
-  p.tiles_m = (p.M + 255) / 256;
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p, a_koff);
-  return flexam_check_launch("flexam_gemm_bf16");
-}
-
 template <int EPI, typename OutT, int MT>
 int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
   auto kern = gemm_bf16_kernel<EPI, OutT, MT>;
@@ -485,10 +298,10 @@ int pick_mt(int M, int tiles_n) {
 template <int EPI, typename OutT>
 int launch(const GemmParams& p_, const int64_t* a_koff, hipStream_t s) {
   GemmParams p = p_;
+#ifdef FLEXAM_GEMM_ABLATE
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
   p.debug = dbg ? atoi(dbg) : 0;
-  const char* e = getenv("FLEXAM_GEMM_W4");
-  if (e && atoi(e) == 1) return launch_w4<EPI, OutT>(p, a_koff, s);
+#endif
   switch (pick_mt(p.M, p.tiles_n)) {
     case 7: return launch_mt<EPI, OutT, 7>(p, a_koff, s);
     case 6: return launch_mt<EPI, OutT, 6>(p, a_koff, s);

@@ -61,16 +61,11 @@ def test_gemm_exact_integers(H, m, n, k):
     torch.testing.assert_close(out.cpu(), a @ w.t() + b, rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("mt", [4, 5, 6, 7, 8, "w4"])
+@pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
 def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
     """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on
     ragged sizes, for the plain, fp32-out and gated-residual epilogues."""
-    if mt == "w4":
-        monkeypatch.setenv("FLEXAM_GEMM_W4", "1")       # the 4-wave, 128x128-per-wave kernel
-        mt = 9
-    else:
-        monkeypatch.setenv("FLEXAM_GEMM_W4", "0")
-        monkeypatch.setenv("FLEXAM_GEMM_MT", str(mt))
+    monkeypatch.setenv("FLEXAM_GEMM_MT", str(mt))
     g = torch.Generator().manual_seed(100 + mt)
     m, n, k = 1000, 772, 192
     a = torch.randint(-3, 4, (m, k), generator=g).float()
