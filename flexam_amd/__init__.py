@@ -8,7 +8,8 @@ Arithmetic runs in libflexam_hip.so (hand-written gfx950 HIP kernels, C ABI in
 include/flexam_hip.h); this package is the host-side mirror of the reference interface.
 """
 __all__ = ["Wan2_2Transformer3DModel_FlexAM", "WanTransformer3DModel_FlexAM", "AutoencoderKLWan3_8",
-           "Wan2_2FunControlPipeline_FlexAM", "FlowMatchEulerDiscreteScheduler", "attention"]
+           "Wan2_2FunControlPipeline_FlexAM", "FlowMatchEulerDiscreteScheduler", "FlowUniPCMultistepScheduler",
+           "FlowDPMSolverMultistepScheduler", "attention"]
 
 
 def __getattr__(name):
@@ -25,6 +26,12 @@ def __getattr__(name):
     if name == "FlowMatchEulerDiscreteScheduler":
         from .scheduler import FlowMatchEulerDiscreteScheduler
         return FlowMatchEulerDiscreteScheduler
+    if name == "FlowUniPCMultistepScheduler":
+        from .fm_solvers_unipc import FlowUniPCMultistepScheduler
+        return FlowUniPCMultistepScheduler
+    if name == "FlowDPMSolverMultistepScheduler":
+        from .fm_solvers import FlowDPMSolverMultistepScheduler
+        return FlowDPMSolverMultistepScheduler
     if name == "attention":
         from .attention_utils import attention
         return attention

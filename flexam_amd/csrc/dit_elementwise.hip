@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void cfg_euler_blend_kernel(const float* __restrict__ tok_u, const float* __restrict__ tok_c,
                                                               int64_t ldt, int64_t tok0, float guidance, float dt,
                                                               float* __restrict__ latents, const float* __restrict__ known,
-                                                              const float* __restrict__ mask, int C, int F, int H, int W) {
+                                                              const float* __restrict__ mask, int C, int F, int H, int W,
+                                                              float* __restrict__ v_out) {
   const int64_t total = (int64_t)C * F * H * W;
   const int hw2 = (H / 2) * (W / 2);
   const int64_t fhw = (int64_t)F * H * W;
@@ -330,6 +331,10 @@ __global__ __launch_bounds__(256) void cfg_euler_blend_kernel(const float* __res
     const int col = (((h & 1) << 1) | (w & 1)) * C + c;
     float v = tok_u[token * ldt + col];
     if (tok_c) v = v + guidance * (tok_c[token * ldt + col] - v);
+    if (v_out) {                       // multistep samplers: hand the guided velocity to scheduler.step
+      v_out[i] = v;
+      continue;
+    }
     float x = latents[i] + dt * v;
     if (mask) {
       const float mk = mask[i % fhw];
@@ -345,6 +350,31 @@ __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, float
     const f32x4 xv = ((const f32x4*)x)[i];
     f32x4 yv = ((f32x4*)y)[i];
     ((f32x4*)y)[i] = xv * a + yv * b;
+  }
+}
+
+// out = sum_i c[i] * x[i] over n fp32 elements; `out` may be one of the x[i] (purely elementwise).  The multistep
+// samplers' updates (fm_solvers_unipc.py:349-615, fm_solvers.py:415-677) are such combinations of the sample and
+// the stored x0 predictions.
+constexpr int LINCOMB_MAX = 8;
+struct LincombArgs {
+  const float* x[LINCOMB_MAX];
+  float c[LINCOMB_MAX];
+};
+__global__ __launch_bounds__(256) void lincomb_kernel(float* out, LincombArgs a, int n_terms, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 acc = ((const f32x4*)a.x[0])[i] * a.c[0];
+    for (int t = 1; t < n_terms; ++t) acc += ((const f32x4*)a.x[t])[i] * a.c[t];
+    ((f32x4*)out)[i] = acc;
+  }
+}
+
+// x = (1 - mask) known + mask x, mask [fhw] broadcast over channels (PIPE.py:933-934 for non-Euler samplers)
+__global__ __launch_bounds__(256) void mask_blend_kernel(float* __restrict__ x, const float* __restrict__ known,
+                                                         const float* __restrict__ mask, int64_t total, int64_t fhw) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float mk = mask[i % fhw];
+    x[i] = (1.0f - mk) * known[i] + mk * x[i];
   }
 }
 
@@ -474,8 +504,38 @@ extern "C" int flexam_cfg_euler_blend(const float* tok_uncond, const float* tok_
   FX_REQUIRE((mask == nullptr) == (known == nullptr), FLEXAM_E_ARG, "cfg_euler_blend: mask and known go together");
   FX_REQUIRE(H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "cfg_euler_blend: H, W must be even");
   hipLaunchKernelGGL(cfg_euler_blend_kernel, dim3(grid_for((int64_t)C * F * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
-                     tok_uncond, tok_cond, ldt, tok0, guidance, dt, latents, known, mask, C, F, H, W);
+                     tok_uncond, tok_cond, ldt, tok0, guidance, dt, latents, known, mask, C, F, H, W, (float*)nullptr);
   return flexam_check_launch("flexam_cfg_euler_blend");
+}
+
+extern "C" int flexam_cfg_velocity(const float* tok_uncond, const float* tok_cond, int64_t ldt, int64_t tok0, float guidance, float* v,
+                                   int C, int F, int H, int W, void* stream) {
+  FX_REQUIRE(tok_uncond && v, FLEXAM_E_ARG, "cfg_velocity: null pointer");
+  FX_REQUIRE(H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "cfg_velocity: H, W must be even");
+  hipLaunchKernelGGL(cfg_euler_blend_kernel, dim3(grid_for((int64_t)C * F * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
+                     tok_uncond, tok_cond, ldt, tok0, guidance, 0.f, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, C, F,
+                     H, W, v);
+  return flexam_check_launch("flexam_cfg_velocity");
+}
+
+extern "C" int flexam_lincomb_f32(float* out, int64_t n, int n_terms, const float* const* terms, const float* coefs, void* stream) {
+  FX_REQUIRE(out && terms && coefs && n > 0 && n % 4 == 0, FLEXAM_E_ARG, "lincomb_f32: null pointer or n %% 4 != 0");
+  FX_REQUIRE(n_terms >= 1 && n_terms <= LINCOMB_MAX, FLEXAM_E_ARG, "lincomb_f32: %d terms (1..%d supported)", n_terms, LINCOMB_MAX);
+  LincombArgs a{};
+  for (int i = 0; i < n_terms; ++i) {
+    FX_REQUIRE(terms[i], FLEXAM_E_ARG, "lincomb_f32: term %d is null", i);
+    a.x[i] = terms[i];
+    a.c[i] = coefs[i];
+  }
+  hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, out, a, n_terms, n / 4);
+  return flexam_check_launch("flexam_lincomb_f32");
+}
+
+extern "C" int flexam_mask_blend_f32(float* x, const float* known, const float* mask, int C, int64_t fhw, void* stream) {
+  FX_REQUIRE(x && known && mask && C > 0 && fhw > 0, FLEXAM_E_ARG, "mask_blend_f32: bad arguments");
+  hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for((int64_t)C * fhw, 256)), dim3(256), 0, (hipStream_t)stream, x, known, mask,
+                     (int64_t)C * fhw, fhw);
+  return flexam_check_launch("flexam_mask_blend_f32");
 }
 
 extern "C" int flexam_axpby_f32(float* y, float a, const float* x, float b, int64_t n, void* stream) {

@@ -51,7 +51,7 @@ struct GemmParams {
   int64_t gate_ld;
   const int32_t* gate_row; // [M] row index per output row, or null
   int64_t rows_per_batch;  // used when gate_row is null: row = m / rows_per_batch
-  int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA
+  int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
 #ifdef FLEXAM_GEMM_ABLATE
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     const uint32_t voff = i < PA ? a_off[i] : w_off[i - PA];
     const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * 8192 : TILE_BYTES + (i - PA) * 8192) + wave * 1024;
     uint32_t keep;
-    if (ABLATE(p, 4)) return;
+    if (ABLATE(p, 4) || (ABLATE(p, 16) && i >= PA)) return;      // 16: no W-tile staging (half the LDS-DMA)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(dst)
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], af0[g], acc[g][nt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);                // MFMAs first: the wait for F0 must not cover reads issued after it
-      ld2(cur, frag_off1, g, wf1, af1);
+      if (!ABLATE(p, 8)) ld2(cur, frag_off1, g, wf1, af1);   // 8: no phase-A fragment reads (half the ds_reads)
     }
     __builtin_amdgcn_sched_barrier(0);
     dma_wait_barrier();

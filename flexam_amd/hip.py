@@ -35,6 +35,9 @@ _SIGNATURES = {
     "flexam_unpatchify": ([_P, _L, _L, _I, _I, _I, _I, _P, _I, _P], c_int),
     "flexam_cfg_euler_blend": ([_P, _P, _L, _L, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P], c_int),
     "flexam_axpby_f32": ([_P, _F, _P, _F, _L, _P], c_int),
+    "flexam_cfg_velocity": ([_P, _P, _L, _L, _F, _P, _I, _I, _I, _I, _P], c_int),
+    "flexam_lincomb_f32": ([_P, _L, _I, _P, _P, _P], c_int),
+    "flexam_mask_blend_f32": ([_P, _P, _P, _I, _L, _P], c_int),
     "flexam_pack_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_unpack_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _P], c_int),
     "flexam_groupnorm_silu_cl": ([_P, _L, _I, _I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P, _I, _P], c_int),
@@ -268,6 +271,39 @@ def axpby(y, a, x, b):
         raise RuntimeError("axpby: contiguous tensors of equal shape required")
     _check(lib().flexam_axpby_f32(_ptr(y, F32), a, _ptr(x, F32), b, y.numel(), _stream()), "flexam_axpby_f32")
     return y
+
+
+def cfg_velocity(tok_uncond, tok_cond, tok0, guidance, out):
+    """out [C,F,H,W] fp32 = unpatchify(u + g (c - u)); tok_cond None: out = unpatchify(u)."""
+    C, F, H, W = out.shape
+    _check(lib().flexam_cfg_velocity(_ptr(tok_uncond, F32), _ptr(tok_cond, F32), tok_uncond.stride(0), tok0, guidance, _ptr(out, F32),
+                                     C, F, H, W, _stream()), "flexam_cfg_velocity")
+    return out
+
+
+def lincomb(out, terms):
+    """out = sum(c * t for c, t in terms): fp32 contiguous tensors of out's shape; out may be one of them."""
+    n = len(terms)
+    for _, t in terms:
+        if t.shape != out.shape or t.dtype != F32 or not t.is_contiguous() or t.device != out.device:
+            raise RuntimeError("lincomb: fp32 contiguous tensors of equal shape on one device required")
+    if not out.is_contiguous() or out.dtype != F32:
+        raise RuntimeError("lincomb: out must be fp32 contiguous")
+    ptrs = (c_void_p * n)(*[t.data_ptr() for _, t in terms])
+    coefs = (c_float * n)(*[float(c) for c, _ in terms])
+    _check(lib().flexam_lincomb_f32(_ptr(out, F32), out.numel(), n, ctypes.cast(ptrs, c_void_p), ctypes.cast(coefs, c_void_p),
+                                    _stream()), "flexam_lincomb_f32")
+    return out
+
+
+def mask_blend(x, known, mask):
+    """x [C, ...] = (1 - mask) * known + mask * x with mask [...] broadcast over the leading channel dim."""
+    C = x.shape[0]
+    fhw = x.numel() // C
+    if mask.numel() != fhw or known.shape != x.shape:
+        raise RuntimeError("mask_blend: shape mismatch")
+    _check(lib().flexam_mask_blend_f32(_ptr(x, F32), _ptr(known, F32), _ptr(mask, F32), C, fhw, _stream()), "flexam_mask_blend_f32")
+    return x
 
 
 # ----------------------------------------------------------------------------- channels-last conv helpers

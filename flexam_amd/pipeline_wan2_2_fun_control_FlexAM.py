@@ -23,6 +23,8 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
+from .fm_solvers import FlowDPMSolverMultistepScheduler, get_sampling_sigmas, retrieve_timesteps
+from .fm_solvers_unipc import FlowUniPCMultistepScheduler
 from .scheduler import FlowMatchEulerDiscreteScheduler
 
 F32 = torch.float32
@@ -162,7 +164,7 @@ class Wan2_2FunControlPipeline_FlexAM:
     # ------------------------------------------------------------------ the hot path
     @torch.no_grad()
     def prepare(self, latents, cond: LatentConditioning, context_cond, context_uncond, density, guidance_scale, num_inference_steps,
-                timesteps=None):
+                timesteps=None, shift: float = 5):
         """Everything step-invariant (PIPE.py:598-605, 655-690, 833-842, 850-898 hoisted out of the loop)."""
         tr = self.transformer
         eng = tr.engine()
@@ -195,7 +197,15 @@ class Wan2_2FunControlPipeline_FlexAM:
         uniq, inv = torch.unique(seq, return_inverse=True)
         U = uniq.numel()
         row_index = torch.cat([inv + r * U for r in range(nrow)]).to(torch.int32).contiguous()
-        self.scheduler.set_timesteps(num_inference_steps, device=None) if timesteps is None else self.scheduler.set_timesteps(timesteps=timesteps)
+        # PIPE.py:603-616: each scheduler family builds its schedule its own way
+        if isinstance(self.scheduler, FlowMatchEulerDiscreteScheduler):
+            self.scheduler.set_timesteps(num_inference_steps, device=None) if timesteps is None else self.scheduler.set_timesteps(timesteps=timesteps)
+        elif isinstance(self.scheduler, FlowUniPCMultistepScheduler):
+            self.scheduler.set_timesteps(num_inference_steps, device=None, shift=shift)
+        elif isinstance(self.scheduler, FlowDPMSolverMultistepScheduler):
+            retrieve_timesteps(self.scheduler, device=None, sigmas=get_sampling_sigmas(num_inference_steps, shift))
+        else:
+            self.scheduler.set_timesteps(num_inference_steps)
         self._num_timesteps = len(self.scheduler.timesteps)
         tr.num_inference_steps = num_inference_steps
         self._state = dict(latents=latents[0].contiguous(), known=known[0].contiguous() if pinned else None,
@@ -220,8 +230,7 @@ class Wan2_2FunControlPipeline_FlexAM:
             U = st["U"]
             head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows[:U], st["row_index"][: st["row_index"].numel() // st["nrow"]],
                                              U, only_row=st["nrow"] - 1))
-            hip.cfg_euler_blend(head[0], None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i), st["latents"], st["known"], st["mask"])
-            return st["latents"]
+            return self._sampler_update(i, head[0], None)
         tc = tr.teacache
         head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"], teacache=tc))
         if tc is not None:
@@ -230,10 +239,25 @@ class Wan2_2FunControlPipeline_FlexAM:
                 tc.reset()
         # head: [rows, L, 192] with rows = (uncond, cond) after the gather, whatever the parallel layout
         if skip_uncond:                                  # CFG-parallel ranks: both rows were computed anyway, take cond
-            hip.cfg_euler_blend(head[1], None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i), st["latents"], st["known"], st["mask"])
-        else:
-            hip.cfg_euler_blend(head[0], head[1] if st["cfg"] else None, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i),
-                                st["latents"], st["known"], st["mask"])
+            return self._sampler_update(i, head[1], None)
+        return self._sampler_update(i, head[0], head[1] if st["cfg"] else None)
+
+    def _sampler_update(self, i: int, tok_uncond, tok_cond):
+        """PIPE.py:926-934: CFG combine, scheduler.step, masked blend with the known latents.  Flow-match Euler: ONE
+        fused kernel.  Multistep samplers (UniPC, DPM-Solver++): guided velocity -> scheduler.step (its updates are
+        single `flexam_lincomb_f32` launches) -> `flexam_mask_blend_f32`."""
+        st = self._state
+        if isinstance(self.scheduler, FlowMatchEulerDiscreteScheduler):
+            hip.cfg_euler_blend(tok_uncond, tok_cond, st["ref_len"], st["guidance"], self.scheduler.sigma_step(i), st["latents"],
+                                st["known"], st["mask"])
+            return st["latents"]
+        if "velocity" not in st:
+            st["velocity"] = torch.empty_like(st["latents"])
+        v = hip.cfg_velocity(tok_uncond, tok_cond, st["ref_len"], st["guidance"], st["velocity"])
+        new = self.scheduler.step(v.unsqueeze(0), self.scheduler.timesteps[i], st["latents"].unsqueeze(0), return_dict=False)[0]
+        st["latents"].copy_(new[0])
+        if st["mask"] is not None:
+            hip.mask_blend(st["latents"], st["known"], st["mask"])
         return st["latents"]
 
     def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
@@ -271,7 +295,7 @@ class Wan2_2FunControlPipeline_FlexAM:
         if conditioning is None:
             conditioning = self.encode_conditioning(video, mask_video, control_video, depth_video, cos_control_videos, ref_image,
                                                     height, width, shape)
-        self.prepare(latents, conditioning, ctx_c, ctx_u, density, guidance_scale, num_inference_steps, timesteps)
+        self.prepare(latents, conditioning, ctx_c, ctx_u, density, guidance_scale, num_inference_steps, timesteps, shift)
         for i in range(self._num_timesteps):
             if self._interrupt:
                 continue

@@ -121,6 +121,16 @@ int flexam_unpatchify(const float* tok, int64_t ldt, int64_t tok0, int C, int F,
 int flexam_cfg_euler_blend(const float* tok_uncond, const float* tok_cond, int64_t ldt, int64_t tok0, float guidance, float dt,
                            float* latents, const float* known, const float* mask, int C, int F, int H, int W, void* stream);
 
+/* Multistep samplers (FlexAM/utils/fm_solvers_unipc.py:640-724, fm_solvers.py:706-798; PIPE.py:926-934 around them):
+ * cfg_velocity: v[C,F,H,W] = unpatchify(u + g (c - u)) -- the noise_pred handed to scheduler.step;
+ * lincomb_f32:  out = sum_i coefs[i] * terms[i] (n_terms <= 8; `terms` / `coefs` are HOST arrays, terms[i] device
+ *               pointers; out may alias a term) -- every UniPC / DPM-Solver++ update is one such combination;
+ * mask_blend_f32: x = (1 - mask) known + mask x, mask [fhw] broadcast over C channels. */
+int flexam_cfg_velocity(const float* tok_uncond, const float* tok_cond, int64_t ldt, int64_t tok0, float guidance, float* v, int C,
+                        int F, int H, int W, void* stream);
+int flexam_lincomb_f32(float* out, int64_t n, int n_terms, const float* const* terms, const float* coefs, void* stream);
+int flexam_mask_blend_f32(float* x, const float* known, const float* mask, int C, int64_t fhw, void* stream);
+
 /* y[i] = a*x[i] + b*y[i], fp32, n % 4 == 0.  TeaCache bookkeeping: residual = x_after_blocks - x_before and
  * x += cached residual on skipped steps (wan_transformer3d_FlexAM.py:1003-1051). */
 int flexam_axpby_f32(float* y, float a, const float* x, float b, int64_t n, void* stream);

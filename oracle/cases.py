@@ -128,6 +128,25 @@ def vae_enc_case(seed: int = 42, frames: int = 9, h: int = 32, w: int = 64) -> T
     return torch.rand(1, 3, frames, h, w, generator=g, dtype=torch.float32) * 2 - 1
 
 
+# ----------------------------------------------------------------------------- multistep sampler cases (G10)
+SOLVER_CASES = {                                    # name -> (kind, steps, shift, constructor kwargs)
+    "unipc_o2": ("unipc", 8, 5.0, {}),
+    "unipc_o3": ("unipc", 20, 3.0, dict(solver_order=3)),
+    "dpmpp_o2": ("dpm", 8, 5.0, {}),
+    "dpmpp_o3": ("dpm", 12, 5.0, dict(solver_order=3)),
+    "dpmpp_heun": ("dpm", 6, 5.0, dict(solver_type="heun")),
+}
+
+
+def solver_case(name: str, shape=(1, 48, 3, 4, 6)):
+    """Seeded start sample and per-step model outputs (velocity predictions) for a scheduler trace."""
+    kind, steps, shift, kw = SOLVER_CASES[name]
+    g = torch.Generator().manual_seed(1000 + sorted(SOLVER_CASES).index(name))
+    x = randn(g, *shape)
+    vs = [randn(g, *shape) for _ in range(steps)]
+    return kind, steps, shift, kw, x, vs
+
+
 def psnr(a: Tensor, b: Tensor, peak: float = None) -> float:
     """PSNR of a vs reference b; peak defaults to the reference's max-abs range."""
     a, b = a.double(), b.double()

@@ -14,6 +14,7 @@ Fixtures:
   g5_dit_scalart     same, 1-D t branch                                                         FX.py:941-944
   g6_teacache        6 forwards with TeaCache on (identity rescale, threshold 2.0): computed and skipped steps  FX.py:977-1051
   g8_vae_encode      small AutoencoderKLWan2_2_ encode [1,3,9,32,64] / [1,3,1,32,32] -> normalised mu          VAE.py:788-818
+  g10_solver_*       FlowUniPCMultistepScheduler / FlowDPMSolverMultistepScheduler step() traces             fm_solvers_unipc.py:640-724, fm_solvers.py:706-798
   g7_vae_decode      small AutoencoderKLWan2_2_ decode [1,48,3,4,6] -> [1,3,9,64,96] + taps    VAE.py:820-849
   g9_sampler         4-step CFG/Euler/blend trace at latent [1,48,3,16,16] driving the
                      reference DiT module through oracle.sampler.denoise_loop                  PIPE.py:840-949
@@ -164,6 +165,22 @@ def main():
         mu_v = VE.encode(xv, [mean, 1.0 / std])[:, :48]
         mu_i = VE.encode(xi, [mean, 1.0 / std])[:, :48]
     _save("g8_vae_encode", dict(mu_video=mu_v, mu_image=mu_i, in_sum=C.checksum(dict(v=xv, i=xi)), w_sum=C.checksum(esd)))
+
+    # ---- G10: vendored multistep samplers (UniPC, DPM-Solver++): sigma schedule + trace of step() outputs
+    for name in sorted(C.SOLVER_CASES):
+        kind, steps, shift, kw, x, vs = C.solver_case(name)
+        if kind == "unipc":
+            sch = ref.unipc.FlowUniPCMultistepScheduler(num_train_timesteps=1000, shift=1, **kw)
+            sch.set_timesteps(steps, device="cpu", shift=shift)                          # PIPE.py:606-608
+        else:
+            sch = ref.dpm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, **kw)
+            ref.dpm.retrieve_timesteps(sch, device="cpu", sigmas=ref.dpm.get_sampling_sigmas(steps, shift))   # PIPE.py:609-614
+        trace, cur = [], x.clone()
+        for i, t in enumerate(sch.timesteps):
+            cur = sch.step(vs[i], t, cur, return_dict=False)[0]
+            trace.append(cur.clone())
+        _save("g10_solver_" + name, dict(sigmas=sch.sigmas.clone(), timesteps=sch.timesteps.clone(), trace=torch.stack(trace),
+                                         in_sum=C.checksum(dict(x=x, **{f"v{i}": v for i, v in enumerate(vs)}))))
     print("golden fixtures written to", OUT)
 
 

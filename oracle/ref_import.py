@@ -91,7 +91,25 @@ def _install_stubs():
     _module("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=_register_to_config)
     _module("diffusers.loaders.single_file_model", FromOriginalModelMixin=FromOriginalModelMixin)
     _module("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
-    _module("diffusers.utils", is_torch_version=lambda *a: True, logging=_Logging())
+    _module("diffusers.utils", is_torch_version=lambda *a: True, logging=_Logging(), deprecate=lambda *a, **k: None,
+            is_scipy_available=lambda: False)
+    _module("diffusers.schedulers")
+
+    class SchedulerMixin:
+        pass
+
+    class SchedulerOutput:
+        def __init__(self, prev_sample):
+            self.prev_sample = prev_sample
+
+    _module("diffusers.schedulers.scheduling_utils", KarrasDiffusionSchedulers=[], SchedulerMixin=SchedulerMixin,
+            SchedulerOutput=SchedulerOutput)
+
+    def _randn_tensor(shape, generator=None, device=None, dtype=None):
+        import torch
+        return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+    _module("diffusers.utils.torch_utils", randn_tensor=_randn_tensor)
     _module("diffusers.models.autoencoders.vae", DecoderOutput=DecoderOutput,
             DiagonalGaussianDistribution=DiagonalGaussianDistribution)
     _module("diffusers.models.modeling_outputs", AutoencoderKLOutput=AutoencoderKLOutput)
@@ -119,7 +137,7 @@ _CACHE = {}
 
 
 def load_reference():
-    """Returns a namespace with the reference modules: .dit .vae .att .cache .cfg"""
+    """Returns a namespace with the reference modules: .dit .vae .att .cache .cfg .unipc .dpm"""
     if "ns" in _CACHE:
         return _CACHE["ns"]
     if not reference_available():
@@ -132,6 +150,8 @@ def load_reference():
     _load("FlexAM.models.wan_camera_adapter", "FlexAM/models/wan_camera_adapter.py")
     dit = _load("FlexAM.models.wan_transformer3d_FlexAM", "FlexAM/models/wan_transformer3d_FlexAM.py")
     vae = _load("FlexAM.models.wan_vae3_8", "FlexAM/models/wan_vae3_8.py")
-    ns = types.SimpleNamespace(dit=dit, vae=vae, att=att, cache=cache, cfg=cfg)
+    unipc = _load("FlexAM.utils.fm_solvers_unipc", "FlexAM/utils/fm_solvers_unipc.py")
+    dpm = _load("FlexAM.utils.fm_solvers", "FlexAM/utils/fm_solvers.py")
+    ns = types.SimpleNamespace(dit=dit, vae=vae, att=att, cache=cache, cfg=cfg, unipc=unipc, dpm=dpm)
     _CACHE["ns"] = ns
     return ns

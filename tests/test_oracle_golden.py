@@ -1,5 +1,6 @@
 """CPU: the oracle (oracle/*.py) against golden vectors produced by the reference modules
 (oracle/make_golden.py).  This is what pins the oracle; fp32 vs fp32, tight tolerances."""
+import pytest
 import torch
 
 from oracle import cases as C
@@ -155,3 +156,23 @@ def test_g8_vae_encode(golden):
         mu = OV.vae_encode(esd, x, C.VAE_ENC_SMALL["temporal_down"], OV.LATENT_MEAN, OV.LATENT_STD, prefix="")
         assert mu.shape == fx[key].shape
         assert (mu - fx[key]).abs().max().item() < 2e-5 * max(1.0, fx[key].abs().max().item())
+
+
+@pytest.mark.parametrize("name", sorted(C.SOLVER_CASES))
+def test_g10_multistep_solvers(golden, name):
+    from oracle import solvers as SV
+    fx = golden("g10_solver_" + name)
+    kind, steps, shift, kw, x, vs = C.solver_case(name)
+    assert torch.equal(C.checksum(dict(x=x, **{f"v{i}": v for i, v in enumerate(vs)})), fx["in_sum"])
+    if kind == "unipc":
+        sig, ts = SV.flow_sigmas(steps, shift)
+        sol = SV.UniPC(sig, **kw)
+    else:
+        sig, ts = SV.flow_sigmas(steps, 1.0, sigmas=SV.sampling_sigmas(steps, shift))
+        sol = SV.DPMSolverPP(sig, **kw)
+    assert torch.equal(sig, fx["sigmas"]) and torch.equal(ts, fx["timesteps"])
+    cur = x.clone()
+    for i in range(steps):
+        cur = sol.step(vs[i], cur)
+        want = fx["trace"][i]
+        assert (cur - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (name, i)
