@@ -15,6 +15,7 @@ Fixtures:
   g6_teacache        6 forwards with TeaCache on (identity rescale, threshold 2.0): computed and skipped steps  FX.py:977-1051
   g8_vae_encode      small AutoencoderKLWan2_2_ encode [1,3,9,32,64] / [1,3,1,32,32] -> normalised mu          VAE.py:788-818
   g10_solver_*       FlowUniPCMultistepScheduler / FlowDPMSolverMultistepScheduler step() traces             fm_solvers_unipc.py:640-724, fm_solvers.py:706-798
+  g11_riflex         WanTransformer3DModel_FlexAM.enable_riflex() rope table (cos / sin of the complex freqs)              FX.py:57-113,774-788
   g7_vae_decode      small AutoencoderKLWan2_2_ decode [1,48,3,4,6] -> [1,3,9,64,96] + taps    VAE.py:820-849
   g9_sampler         4-step CFG/Euler/blend trace at latent [1,48,3,16,16] driving the
                      reference DiT module through oracle.sampler.denoise_loop                  PIPE.py:840-949
@@ -181,6 +182,15 @@ def main():
             trace.append(cur.clone())
         _save("g10_solver_" + name, dict(sigmas=sch.sigmas.clone(), timesteps=sch.timesteps.clone(), trace=torch.stack(trace),
                                          in_sum=C.checksum(dict(x=x, **{f"v{i}": v for i, v in enumerate(vs)}))))
+
+    # ---- G11: RIFLEx rope table (enable_riflex defaults k=6, L_test=66, L_test_scale=4.886; FX.py:57-113, 774-788)
+    tiny = _ref_dit(ref, dict(O.DIT_TINY), C.dit_weights(dict(O.DIT_TINY), 1))
+    tiny.enable_riflex()
+    riflex = torch.angle(tiny.freqs.to(torch.complex128)) if tiny.freqs.is_complex() else tiny.freqs.double()
+    tiny.disable_riflex()
+    base = torch.angle(tiny.freqs.to(torch.complex128))
+    _save("g11_riflex", dict(cis_real=tiny.freqs.real.float()[:64].contiguous(), riflex_cos=torch.cos(riflex).float().contiguous(),
+                             riflex_sin=torch.sin(riflex).float().contiguous(), base_cos=torch.cos(base).float().contiguous()))
     print("golden fixtures written to", OUT)
 
 

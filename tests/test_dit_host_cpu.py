@@ -96,3 +96,15 @@ def test_forward_fails_loudly_on_cpu():
     case = C.dit_case(cfg, 41)
     with pytest.raises(RuntimeError, match="GPU|cuda|libflexam"):
         m(**case)
+
+
+def test_riflex_table_matches_reference_golden(golden):
+    """G11: cos/sin of the REFERENCE model's complex rope table after enable_riflex() (defaults k=6, L_test=66,
+    L_test_scale=4.886) and after disable_riflex(); the product stores the angles (FX.py:57-113, 774-795)."""
+    fx = golden("g11_riflex")
+    m, _ = tiny_model()
+    m.enable_riflex()
+    torch.testing.assert_close(torch.cos(m.freqs).float(), fx["riflex_cos"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(torch.sin(m.freqs).float(), fx["riflex_sin"], rtol=0, atol=2e-6)
+    m.disable_riflex()
+    torch.testing.assert_close(torch.cos(m.freqs).float(), fx["base_cos"], rtol=0, atol=2e-6)
