@@ -70,6 +70,33 @@ def shard_rows(full: torch.Tensor, batch: int, seq_len: int, rank: int, world: i
     return full.view(batch, seq_len)[:, s:e].contiguous().view(-1)
 
 
+def shard_streams(jobs, encode, group=None):
+    """Independent objects shard across ranks with no data-path collective: the conditioning streams
+    of one clip (PIPE.py:655-822: control, depth, cos levels, masked video, reference image) are VAE-encoded
+    round-robin -- stream j on rank j % N -- and every result is then broadcast from its owner (a few MB of
+    latents per stream).  `jobs`: list of (key, tensor_or_None); `encode(tensor) -> latent`.  Returns {key: latent};
+    None inputs stay None.  Every rank must call this with the same job list."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    live = [(k, v) for k, v in jobs if v is not None]
+    out = {k: None for k, _ in jobs}
+    mine = {k: encode(v) for j, (k, v) in enumerate(live) if j % world == rank}
+    if world == 1:
+        out.update(mine)
+        return out
+    ref = next(iter(mine.values())) if mine else None
+    shapes = [None] * world
+    dist.all_gather_object(shapes, {k: (tuple(t.shape), str(t.dtype).replace("torch.", "")) for k, t in mine.items()}, group=group)
+    device = ref.device if ref is not None else torch.device("cuda", torch.cuda.current_device())
+    for j, (k, _) in enumerate(live):
+        owner = j % world
+        shape, dt = shapes[owner][k]
+        t = mine[k].contiguous() if owner == rank else torch.empty(shape, device=device, dtype=getattr(torch, dt))
+        dist.broadcast(t, src=dist.get_global_rank(group, owner) if group is not None else owner, group=group)
+        out[k] = t
+    return out
+
+
 def get_sequence_parallel_world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_initialized() else 1
 

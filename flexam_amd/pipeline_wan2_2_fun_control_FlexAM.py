@@ -338,21 +338,26 @@ class Wan2_2FunControlPipeline_FlexAM:
         if cos_control_videos is None or len(cos_control_videos) == 0:
             raise ValueError("cos_control_videos is mandatory for FlexAM (PIPE.py:744-773, 865-866)")
         dev = self.vae.device
-        enc = lambda v: self.vae.encode(self._preprocess(v, height, width).to(dev))[0].mode().float()
+        enc = lambda v: self.vae.encode(v.to(dev))[0].mode().float()
+        pre = lambda v: None if v is None else self._preprocess(v, height, width)
         zeros = torch.zeros(shape, device=dev, dtype=F32)
+        jobs = [("control", pre(control_video)), ("depth", pre(depth_video)), ("ref", pre(ref_image))]
+        jobs += [(("cos", k), pre(cos_control_videos[k])) for k in sorted(cos_control_videos)]
         if bool((mask_video == 255).all()):
-            masked, mask_pixels = zeros, None
+            mask_pixels = None
             mask_latents, mask = zeros[:, :1].repeat(1, 4, 1, 1, 1), torch.ones_like(zeros[:, :1])
         else:
             mask_pixels = self._preprocess(mask_video, height, width, mask=True)
-            init = self._preprocess(video, height, width)
-            masked = self.vae.encode((init * (mask_pixels < 0.5)).to(dev))[0].mode().float()
+            jobs.append(("masked", self._preprocess(video, height, width) * (mask_pixels < 0.5)))
             mask_latents = mask = None
-        cos = [enc(cos_control_videos[k]) if cos_control_videos[k] is not None else zeros for k in sorted(cos_control_videos)]
-        depth = enc(depth_video) if depth_video is not None else zeros
-        if ref_image is not None:
-            ref = enc(ref_image)[:, :, 0]
+        from .dist import shard_streams
+        lat = shard_streams(jobs, enc)                # one process: plain loop; N ranks: stream j on rank j % N, then broadcast
+        masked = lat.get("masked", zeros) if mask_pixels is not None else zeros
+        cos = [lat[("cos", k)] if lat[("cos", k)] is not None else zeros for k in sorted(cos_control_videos)]
+        depth = lat["depth"] if lat["depth"] is not None else zeros
+        if lat["ref"] is not None:
+            ref = lat["ref"][:, :, 0]
         else:
             ref = zeros[:, :, 0] if getattr(self.transformer, "ref_conv", None) is not None else None
-        return LatentConditioning(control_latents=enc(control_video), additional_control=torch.cat([depth] + cos, dim=1),
+        return LatentConditioning(control_latents=lat["control"], additional_control=torch.cat([depth] + cos, dim=1),
                                   masked_video_latents=masked, ref_latents=ref, mask_pixels=mask_pixels, mask_latents=mask_latents, mask=mask)

@@ -131,3 +131,26 @@ def _async_gather(rank, world):
 
 def test_async_seq_gather_both_layouts():
     assert all(run_world(_async_gather))
+
+
+def _shard_streams(rank, world):
+    from flexam_amd.dist import shard_streams
+    g = torch.Generator().manual_seed(4)
+    jobs = [("control", torch.randn(1, 3, 5, 4, 4, generator=g)), ("depth", None), ("ref", torch.randn(1, 3, 1, 4, 4, generator=g))]
+    jobs += [(("cos", k), torch.randn(1, 3, 5, 4, 4, generator=g)) for k in range(3)]
+    calls = []
+
+    def encode(v):                                       # stand-in for vae.encode: any deterministic map
+        calls.append(tuple(v.shape))
+        return v.mean(dim=1, keepdim=True) * 2 + 1
+    out = shard_streams(jobs, encode)
+    want = {k: (None if v is None else v.mean(dim=1, keepdim=True) * 2 + 1) for k, v in jobs}
+    same = all((out[k] is None and want[k] is None) or torch.equal(out[k], want[k]) for k in want)
+    return same, len(calls), sorted(str(k) for k in out)
+
+
+def test_conditioning_streams_shard_round_robin_and_broadcast():
+    res = run_world(_shard_streams, 2)
+    assert all(r[0] for r in res)                       # every rank ends with every latent, bit-identical to a local encode
+    assert [r[1] for r in res] == [3, 2]                # 5 live streams: 3 on rank 0, 2 on rank 1 -- each encoded exactly once
+    assert res[0][2] == res[1][2] and len(res[0][2]) == 6
