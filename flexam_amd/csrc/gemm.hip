@@ -22,8 +22,8 @@
 //  * v_mfma_f32_16x16x32_bf16 with the operands swapped (W fragment in the A slot) so each lane
 //    ends up with 4 consecutive N columns of one output row -> 8-byte bf16 / 16-byte f32 stores.
 //  * workgroup -> tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
-//    chunks of the tile list, walked in groups of 8 tile-rows so concurrently resident tiles
-//    share A row-panels and W column-panels in L2.
+//    chunks of the tile list, walked in groups of 4 tile-rows so concurrently resident tiles
+//    share A row-panels and W column-panels in L2 (FLEXAM_GEMM_GM overrides the group height).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -51,6 +51,7 @@ struct GemmParams {
   int64_t gate_ld;
   const int32_t* gate_row; // [M] row index per output row, or null
   int64_t rows_per_batch;  // used when gate_row is null: row = m / rows_per_batch
+  int gm;                  // tile-rows per L2 group (XCD-aware order)
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  constexpr int GM = 8;
+  const int GM = p.gm;
   const int per_group = GM * p.tiles_n;
   const int group = bid / per_group;
   const int first_m = group * GM;
@@ -298,6 +299,11 @@ int pick_mt(int M, int tiles_n) {
 template <int EPI, typename OutT>
 int launch(const GemmParams& p_, const int64_t* a_koff, hipStream_t s) {
   GemmParams p = p_;
+  {
+    const char* g = getenv("FLEXAM_GEMM_GM");
+    p.gm = g ? atoi(g) : 4;                  // 4 tile-rows x (32 / 4) tile-columns resident per XCD measured best (profiles/r1e notes)
+    if (p.gm < 1) p.gm = 4;
+  }
 #ifdef FLEXAM_GEMM_ABLATE
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
   p.debug = dbg ? atoi(dbg) : 0;
