@@ -9,7 +9,7 @@ include/flexam_hip.h); this package is the host-side mirror of the reference int
 """
 __all__ = ["Wan2_2Transformer3DModel_FlexAM", "WanTransformer3DModel_FlexAM", "AutoencoderKLWan3_8",
            "Wan2_2FunControlPipeline_FlexAM", "FlowMatchEulerDiscreteScheduler", "FlowUniPCMultistepScheduler",
-           "FlowDPMSolverMultistepScheduler", "attention"]
+           "FlowDPMSolverMultistepScheduler", "WanT5EncoderModel", "attention"]
 
 
 def __getattr__(name):
@@ -32,6 +32,9 @@ def __getattr__(name):
     if name == "FlowDPMSolverMultistepScheduler":
         from .fm_solvers import FlowDPMSolverMultistepScheduler
         return FlowDPMSolverMultistepScheduler
+    if name == "WanT5EncoderModel":
+        from .wan_text_encoder import WanT5EncoderModel
+        return WanT5EncoderModel
     if name == "attention":
         from .attention_utils import attention
         return attention

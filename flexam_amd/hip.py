@@ -48,6 +48,9 @@ _SIGNATURES = {
     "flexam_scatter_add_cl": ([_P, _L, _P, _L, _I, _I, _I, _I, _P], c_int),
     "flexam_vae_unpatchify_clamp": ([_P, _L, _I, _I, _I, _P, _I, _I, _F, _F, _P], c_int),
     "flexam_pack_affine_cl": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
+    "flexam_t5_norm": ([_P, _L, _L, _I, _F, _P, _P, _L, _I, _P], c_int),
+    "flexam_softmax_bias_rows": ([_P, _L, _L, _I, _F, _P, _L, _P, _P, _L, _I, _P], c_int),
+    "flexam_mul_bf16": ([_P, _P, _P, _L, _P], c_int),
     "flexam_vae_patchify_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_space_to_depth_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_avgdown_add_cl": ([_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P], c_int),
@@ -401,3 +404,30 @@ def avgdown_add_cl(x_main, Co, To, Ho, Wo, x_in, Ci, Ti, ft, fs):
     _check(lib().flexam_avgdown_add_cl(_ptr(x_main, F32), x_main.stride(0), Co, To, Ho, Wo, _ptr(x_in, F32), x_in.stride(0), Ci, Ti, ft, fs,
                                        _stream()), "flexam_avgdown_add_cl")
     return x_main
+
+
+# ----------------------------------------------------------------------------- umT5 text encoder helpers
+def t5_norm(x, w, out, eps=1e-6):
+    """x [M, C] fp32 rows -> out [M, C] (bf16 or fp32) = w * x * rsqrt(mean(x^2) + eps)."""
+    M, C, ldx = _rows(x)
+    _check(lib().flexam_t5_norm(_ptr(x, F32), ldx, M, C, eps, _ptr(w, F32), _ptr(out), out.stride(0), 1 if out.dtype == F32 else 0,
+                                _stream()), "flexam_t5_norm")
+    return out
+
+
+def softmax_bias_rows(s, out, n_valid, scale=1.0, bias=None, key_mask=None):
+    """out [M, Npad] bf16 = softmax(scale * s[:, :n_valid] + bias) over keys with key_mask != 0."""
+    M = s.shape[0]
+    _check(lib().flexam_softmax_bias_rows(_ptr(s, F32), s.stride(0), M, n_valid, scale, _ptr(bias, F32), bias.stride(0) if bias is not None else 0,
+                                          _ptr(key_mask, F32), _ptr(out, BF16), out.stride(0), out.shape[1], _stream()),
+           "flexam_softmax_bias_rows")
+    return out
+
+
+def mul_bf16(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    if a.shape != b.shape or not (a.is_contiguous() and b.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("mul_bf16: contiguous bf16 tensors of equal shape required")
+    _check(lib().flexam_mul_bf16(_ptr(a, BF16), _ptr(b, BF16), _ptr(out, BF16), a.numel(), _stream()), "flexam_mul_bf16")
+    return out

@@ -10,8 +10,8 @@ one-off mask/latent preparation.
 
 Two ways in:
   * `__call__(prompt_embeds=..., video=..., control_video=..., ...)`: pixel-space inputs like demo.py; the
-    conditioning streams go through `vae.encode` (HIP) in `encode_conditioning`; a `prompt=` string needs a
-    text encoder attached (umT5 is outside this path, SURVEY 8f4 -- it raises if absent);
+    conditioning streams go through `vae.encode` (HIP) in `encode_conditioning`; a `prompt=` string goes through
+    the attached tokenizer + `WanT5EncoderModel` (HIP), `prompt_embeds=` skips them;
   * `__call__(..., conditioning=LatentConditioning(...))`: latent-space conditioning (what bench.py,
     the tests and a caller that has already VAE-encoded its streams use).
 """
@@ -139,14 +139,14 @@ class Wan2_2FunControlPipeline_FlexAM:
 
     def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance=True, prompt_embeds=None,
                       negative_prompt_embeds=None, max_sequence_length=512, device=None):
-        """PIPE.py:234-313: lists of per-prompt [len_i, text_dim] embeddings (T5 output trimmed to the
-        true token count).  The umT5 encoder itself is outside this round's scope."""
+        """PIPE.py:234-313: lists of per-prompt [len_i, text_dim] embeddings (T5 output trimmed to the true token
+        count).  `text_encoder` is `flexam_amd.WanT5EncoderModel` (HIP) or any module with the reference's call."""
         def as_list(e):
             return list(e) if e is not None else None
         if prompt_embeds is None:
             if self.text_encoder is None or self.tokenizer is None:
-                raise NotImplementedError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds "
-                                          "(umT5-xxl is SURVEY row f4, not part of this round)")
+                raise NotImplementedError("no tokenizer / text encoder attached: pass prompt_embeds / negative_prompt_embeds, or "
+                                          "construct the pipeline with tokenizer= and text_encoder=WanT5EncoderModel")
             prompt = [prompt] if isinstance(prompt, str) else prompt
             prompt_embeds = self._t5(prompt, max_sequence_length, device)
             if do_classifier_free_guidance and negative_prompt_embeds is None:

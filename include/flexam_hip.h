@@ -185,6 +185,18 @@ int flexam_space_to_depth_cl(const void* src, int src_is_bf16, int64_t ld_src, i
 int flexam_avgdown_add_cl(float* x_main, int64_t ld_main, int Co, int To, int Ho, int Wo, const float* x_in, int64_t ld_in, int Ci,
                           int Ti, int ft, int fs, void* stream);
 
+
+/* umT5 text encoder helpers (FlexAM/models/wan_text_encoder.py; projections are flexam_gemm_bf16).
+ * t5_norm: out = w * x * rsqrt(mean(x^2) + eps) per row (T5LayerNorm :44-56), bf16 or fp32 out.
+ * softmax_bias_rows: P = softmax(scale * s + bias) over the keys with key_mask != 0 (T5Attention :91-103:
+ *   relative-position bias [M, N], padding mask [N]; bias / key_mask may be NULL), bf16, zero padded to Npad.
+ * mul_bf16: out = a * b elementwise (fc1(x) * gate(x), :125-126). */
+int flexam_t5_norm(const float* x, int64_t ldx, int64_t M, int C, float eps, const float* w, void* out, int64_t ld_out, int out_f32,
+                   void* stream);
+int flexam_softmax_bias_rows(const float* s, int64_t ld_s, int64_t M, int N, float scale, const float* bias, int64_t ld_bias,
+                             const float* key_mask, void* out, int64_t ld_out, int Npad, void* stream);
+int flexam_mul_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

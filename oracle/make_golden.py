@@ -16,6 +16,7 @@ Fixtures:
   g8_vae_encode      small AutoencoderKLWan2_2_ encode [1,3,9,32,64] / [1,3,1,32,32] -> normalised mu          VAE.py:788-818
   g10_solver_*       FlowUniPCMultistepScheduler / FlowDPMSolverMultistepScheduler step() traces             fm_solvers_unipc.py:640-724, fm_solvers.py:706-798
   g11_riflex         WanTransformer3DModel_FlexAM.enable_riflex() rope table (cos / sin of the complex freqs)              FX.py:57-113,774-788
+  g12_t5             WanT5EncoderModel.forward (tiny umT5 config, per-layer relative position bias, key mask)            wan_text_encoder.py:256-305
   g7_vae_decode      small AutoencoderKLWan2_2_ decode [1,48,3,4,6] -> [1,3,9,64,96] + taps    VAE.py:820-849
   g9_sampler         4-step CFG/Euler/blend trace at latent [1,48,3,16,16] driving the
                      reference DiT module through oracle.sampler.denoise_loop                  PIPE.py:840-949
@@ -191,6 +192,17 @@ def main():
     base = torch.angle(tiny.freqs.to(torch.complex128))
     _save("g11_riflex", dict(cis_real=tiny.freqs.real.float()[:64].contiguous(), riflex_cos=torch.cos(riflex).float().contiguous(),
                              riflex_sin=torch.sin(riflex).float().contiguous(), base_cos=torch.cos(base).float().contiguous()))
+
+    # ---- G12: umT5 text encoder (WanT5EncoderModel.forward) on a tiny config, right-padded prompts of 24 and 9 tokens
+    from . import t5 as OT
+    tcfg = dict(OT.T5_TINY)
+    T5 = ref.t5.WanT5EncoderModel(**tcfg).eval()
+    tsd = OT.seeded_t5_weights(tcfg, 5)
+    T5.load_state_dict(tsd)
+    ids, amask = OT.t5_case(tcfg)
+    with torch.no_grad():
+        emb = T5(ids, amask)[0]
+    _save("g12_t5", dict(out=emb, ids=ids.float(), mask=amask.float(), w_sum=C.checksum(tsd)))
     print("golden fixtures written to", OUT)
 
 

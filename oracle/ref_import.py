@@ -137,7 +137,7 @@ _CACHE = {}
 
 
 def load_reference():
-    """Returns a namespace with the reference modules: .dit .vae .att .cache .cfg .unipc .dpm"""
+    """Returns a namespace with the reference modules: .dit .vae .att .cache .cfg .unipc .dpm .t5"""
     if "ns" in _CACHE:
         return _CACHE["ns"]
     if not reference_available():
@@ -150,8 +150,9 @@ def load_reference():
     _load("FlexAM.models.wan_camera_adapter", "FlexAM/models/wan_camera_adapter.py")
     dit = _load("FlexAM.models.wan_transformer3d_FlexAM", "FlexAM/models/wan_transformer3d_FlexAM.py")
     vae = _load("FlexAM.models.wan_vae3_8", "FlexAM/models/wan_vae3_8.py")
+    t5 = _load("FlexAM.models.wan_text_encoder", "FlexAM/models/wan_text_encoder.py")
     unipc = _load("FlexAM.utils.fm_solvers_unipc", "FlexAM/utils/fm_solvers_unipc.py")
     dpm = _load("FlexAM.utils.fm_solvers", "FlexAM/utils/fm_solvers.py")
-    ns = types.SimpleNamespace(dit=dit, vae=vae, att=att, cache=cache, cfg=cfg, unipc=unipc, dpm=dpm)
+    ns = types.SimpleNamespace(dit=dit, vae=vae, att=att, cache=cache, cfg=cfg, unipc=unipc, dpm=dpm, t5=t5)
     _CACHE["ns"] = ns
     return ns

@@ -176,3 +176,15 @@ def test_g10_multistep_solvers(golden, name):
         cur = sol.step(vs[i], cur)
         want = fx["trace"][i]
         assert (cur - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item()), (name, i)
+
+
+def test_g12_t5_encoder(golden):
+    from oracle import t5 as OT
+    fx = golden("g12_t5")
+    cfg = dict(OT.T5_TINY)
+    sd = OT.seeded_t5_weights(cfg, 5)
+    assert torch.equal(C.checksum(sd), fx["w_sum"])
+    ids, mask = OT.t5_case(cfg)
+    assert torch.equal(ids.float(), fx["ids"]) and torch.equal(mask.float(), fx["mask"])
+    out = OT.t5_encode(sd, cfg, ids, mask)
+    torch.testing.assert_close(out, fx["out"], rtol=1e-5, atol=1e-5)
