@@ -395,8 +395,10 @@ class _DecoderEngine(_EngineBase):
                 out.append(st["time_conv"])
         return out
 
-    def _chunk(self, src_rows, h, w, first, video, f0):
-        """Decoder3d.forward on one latent frame (VAE.py:677-728); writes 1 or 4 frames into `video`."""
+    def _chunk(self, src_rows, h, w, first, video, f0, stripe=None):
+        """Decoder3d.forward on one latent frame (VAE.py:677-728); writes 1 or 4 frames into `video`.
+        stripe = (cut, a, b): stages < cut run on full frames, then rows [a, b) of the activation entering stage
+        `cut` are kept and everything after works on that row band (`video` is then the band's buffer)."""
         t = 1
         c1 = self.conv1
         hip.vae_prep_cl(src_rows, c1.ci, t, h, w, c1.image(h, w), mode=0, t0=c1.hist)
@@ -404,7 +406,12 @@ class _DecoderEngine(_EngineBase):
         x = self._res(self.mid[0], x, t, h, w)
         x = self._attention(self.attn, x, t, h, w)
         x = self._res(self.mid[2], x, t, h, w)
-        for st in self.stages:
+        for si, st in enumerate(self.stages):
+            if stripe is not None and si == stripe[0]:
+                _, a, b = stripe
+                band = torch.zeros(t, b - a + 2, w + 2, x.shape[1], device=self.device, dtype=F32)
+                band[:, 1:-1] = x.view(t, h + 2, w + 2, -1)[:, a + 1:b + 1]
+                x, h = band.view(-1, x.shape[1]), b - a
             x_in, cin = x, x.shape[1]
             main = x.clone() if st["up"] else x
             for r in st["res"]:
@@ -433,9 +440,36 @@ class _DecoderEngine(_EngineBase):
         hip.vae_unpatchify_clamp(y, t, h, w, video, f0)
         return t
 
+    def stripe_plan(self, h: int, rank: int, world: int):
+        """Row band of the high-resolution stages for `rank` of `world`.  The low-resolution part of
+        the decoder (conv1, the middle block with its global attention, stages 0-1: about a quarter of the FLOPs) is
+        computed on full frames by every rank; from stage 2 on each rank keeps H/world rows plus a halo equal to the
+        receptive field of the remaining 3x3 convolutions, so the band's interior is EXACT (no seams, no exchange).
+        Returns (cut, a, b, keep_lo, keep_hi, scale): band rows [a, b) at the cut resolution, of which
+        [keep_lo, keep_hi) (in output pixel rows, relative to the band's output) are this rank's."""
+        cut = 2
+        n_st = len(self.stages)
+        if n_st <= cut:
+            raise RuntimeError("parallel decode needs at least 3 decoder stages")
+        hc = h * 2 ** sum(1 for st in self.stages[:cut] if st["up"])
+        if hc % world:
+            raise ValueError(f"{hc} rows at the striping resolution do not divide over {world} ranks")
+        halo, res = 0.0, 1.0                                   # rows of context, in units of the cut resolution
+        for st in self.stages[cut:]:
+            halo += 2 * len(st["res"]) / res                   # two 3x3(x3) convs per residual block
+            if st["up"]:
+                res *= 2
+                halo += 1 / res                                # the resample conv runs after the 2x upsample
+        halo = int(math.ceil(halo + 1 / res))                  # + the head conv
+        r0, r1 = rank * hc // world, (rank + 1) * hc // world
+        a, b = max(0, r0 - halo), min(hc, r1 + halo)
+        scale = int(res) * 2                                   # remaining upsamples x unpatchify
+        return cut, a, b, (r0 - a) * scale, (r1 - a) * scale, scale
+
     @torch.no_grad()
-    def decode(self, z: torch.Tensor) -> torch.Tensor:
-        """z [zc, T, H, W] -> video [3, 1 + 4(T-1), 16H, 16W] fp32 in [-1, 1]."""
+    def decode(self, z: torch.Tensor, stripe=None) -> torch.Tensor:
+        """z [zc, T, H, W] -> video [3, 1 + 4(T-1), 16H, 16W] fp32 in [-1, 1].
+        stripe = (rank, world): only this rank's band of output rows, [3, F, 16H/world, 16W]."""
         zc, tz, h, w = z.shape
         for c in self._all_convs():
             c.reset()
@@ -446,11 +480,18 @@ class _DecoderEngine(_EngineBase):
         scale = 2 ** (len(self.stages) - 1)
         tfac = 2 ** sum(self.temporal_up)
         frames = 1 + tfac * (tz - 1)
-        video = torch.empty(3, frames, h * scale * 2, w * scale * 2, device=self.device, dtype=F32)
+        if stripe is None or stripe[1] == 1:
+            video = torch.empty(3, frames, h * scale * 2, w * scale * 2, device=self.device, dtype=F32)
+            f0 = 0
+            for i in range(tz):
+                f0 += self._chunk(x0[i * rows:(i + 1) * rows], h, w, i == 0, video, f0)
+            return video
+        cut, a, b, lo, hi, sc = self.stripe_plan(h, *stripe)
+        band = torch.empty(3, frames, (b - a) * sc, w * scale * 2, device=self.device, dtype=F32)
         f0 = 0
         for i in range(tz):
-            f0 += self._chunk(x0[i * rows:(i + 1) * rows], h, w, i == 0, video, f0)
-        return video
+            f0 += self._chunk(x0[i * rows:(i + 1) * rows], h, w, i == 0, band, f0, stripe=(cut, a, b))
+        return band[:, :, lo:hi].contiguous()
 
 
 class _EncoderEngine(_EngineBase):
@@ -583,6 +624,7 @@ class AutoencoderKLWan3_8(nn.Module):
         self.supports_encode = True
         self._engine: Optional[_DecoderEngine] = None
         self._enc_engine: Optional[_EncoderEngine] = None
+        self._parallel_group, self._parallel = None, False
 
     def _apply(self, fn, *a, **k):
         self._engine = self._enc_engine = None
@@ -605,11 +647,30 @@ class AutoencoderKLWan3_8(nn.Module):
             self._engine = _DecoderEngine(self)
         return self._engine
 
+    def enable_parallel_decode(self, group=None):
+        """Row-band decode over the ranks of `group` (replaces the reference's missing `parallel_magvit_vae`,
+        FlexAM/models/__init__.py:36-38): every rank decodes 1/N of the output rows (exactly, see
+        _DecoderEngine.stripe_plan) and one all-gather assembles the clip."""
+        self._parallel_group, self._parallel = group, True
+
+    def disable_parallel_decode(self):
+        self._parallel_group, self._parallel = None, False
+
+    def _decode_one(self, eng, u):
+        import torch.distributed as dist
+        world = dist.get_world_size(self._parallel_group) if (self._parallel and dist.is_initialized()) else 1
+        if world == 1:
+            return eng.decode(u)
+        band = eng.decode(u, stripe=(dist.get_rank(self._parallel_group), world))
+        bands = [torch.empty_like(band) for _ in range(world)]
+        dist.all_gather(bands, band, group=self._parallel_group)
+        return torch.cat(bands, dim=2)
+
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         """VAE.py:1041-1056: per sample chunked decode, clamp(-1, 1)."""
         eng = self.engine()
-        out = torch.stack([eng.decode(u) for u in z])
+        out = torch.stack([self._decode_one(eng, u) for u in z])
         if z.dtype == BF16:
             out = out.to(BF16)
         return DecoderOutput(out) if return_dict else (out,)

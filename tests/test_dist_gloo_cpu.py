@@ -154,3 +154,21 @@ def test_conditioning_streams_shard_round_robin_and_broadcast():
     assert all(r[0] for r in res)                       # every rank ends with every latent, bit-identical to a local encode
     assert [r[1] for r in res] == [3, 2]                # 5 live streams: 3 on rank 0, 2 on rank 1 -- each encoded exactly once
     assert res[0][2] == res[1][2] and len(res[0][2]) == 6
+
+
+def _parallel_decode_gather(rank, world):
+    from flexam_amd.wan_vae3_8 import AutoencoderKLWan3_8
+    full = torch.arange(3 * 5 * 8 * 6, dtype=torch.float32).view(3, 5, 8, 6)
+
+    class FakeEngine:                                     # stands in for the HIP decoder: returns this rank's row band
+        def decode(self, u, stripe=None):
+            r, n = stripe
+            return full[:, :, r * 8 // n:(r + 1) * 8 // n].contiguous()
+    vae = AutoencoderKLWan3_8(c_dim=16, dec_dim=16)
+    vae.enable_parallel_decode()
+    out = vae._decode_one(FakeEngine(), None)
+    return bool(torch.equal(out, full))
+
+
+def test_parallel_vae_decode_assembles_row_bands():
+    assert all(run_world(_parallel_decode_gather, 2))

@@ -95,3 +95,18 @@ def test_vae_encode_five_chunks_other_shape_repeatable_and_logvar():
     again = vae.encode(x.cuda()).latent_dist.parameters        # caches must be reset between calls
     torch.testing.assert_close(post.parameters, again, rtol=0, atol=0)
     assert torch.isfinite(post.sample(generator=torch.Generator("cuda").manual_seed(0))).all()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_vae_row_band_decode_is_exact(world):
+    """Parallel decode: each rank decodes a band of output rows with a receptive-field halo; the
+    bands of all ranks, computed here one after another on one GPU, must tile the full decode BIT-EXACTLY."""
+    vae, sd = build(seed=55)
+    z = C.vae_case(seed=56, frames=3, h=8, w=4)
+    full = vae.decode(z.cuda()).sample[0]
+    eng = vae.engine()
+    bands = [eng.decode(z[0].cuda(), stripe=(r, world)) for r in range(world)]
+    assert all(bd.shape == (3, 9, 128 // world, 64) for bd in bands)
+    torch.testing.assert_close(torch.cat(bands, dim=2), full, rtol=0, atol=0)
+    cut, a, b, lo, hi, sc = eng.stripe_plan(8, 1, world)
+    assert (cut, sc) == (2, 4) and b - a < 32 or world == 2          # bands are narrower than the frame once world > 2

@@ -62,3 +62,14 @@ def enc_flops(frames_pix, h=256, w=448, dim=160):
 
 tf = enc_flops(pix) / 1e12
 print(f"encode ~{tf:.0f} TFLOP -> {tf / dt:.0f} TFLOP/s")
+
+# ---- row-band (parallel) decode: time of ONE rank's band for world = 2, 4, 8 (all ranks do the same amount of work)
+eng = vae.engine()
+for world in (2, 4, 8):
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        band = eng.decode(z[0], stripe=(world // 2, world))
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+    print(f"band decode world={world}: {tuple(band.shape)} {dtb:.3f} s per rank")
