@@ -41,6 +41,11 @@ struct AttnParams {
   int B, H, Lq, Lk;
   float scale_log2e;    // softmax_scale * log2(e)
   int q_blocks;
+  // split-KV (kv_splits > 1): workgroup (q block, head, split) covers key tiles [split*tiles_per_split, ..) and writes its
+  // un-normalised O (fp32) and (running max, row sum) to the workspace; attn_merge_kernel combines the splits
+  int kv_splits, tiles_per_split;
+  float* ws_o;          // [S][B][Lq][H][128]
+  float* ws_ml;         // [S][B][Lq][H][2]
 };
 
 // byte offset of 16-byte chunk `ch` (0..15) of key row `row` in a [64][128] bf16 tile, image (b)
@@ -107,14 +112,16 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
-  const int nwg = p.B * p.H * p.q_blocks;
+  const int nwg = p.B * p.H * p.q_blocks * p.kv_splits;
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, local = bid >> 3;
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
   }
-  const int qb = bid % p.q_blocks;
-  const int bh = bid / p.q_blocks;
+  const int qb = bid % p.q_blocks;                 // consecutive workgroups: q blocks of one (head, split) -> same K/V range in L2
+  const int rest = bid / p.q_blocks;
+  const int split = rest % p.kv_splits;
+  const int bh = rest / p.kv_splits;
   const int head = bh % p.H, b = bh / p.H;
 
   const bf16* qbase = p.q + (int64_t)b * p.q_bs + head * HD;
@@ -147,7 +154,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 
   // ---- LDS-DMA staging: piece id = tid + 512*i (i < 2) lands at LDS byte id*16 of the tile, i.e. row id/16,
   //      slot id%16; it must carry chunk (slot ^ swizzle(row)) of that key row
-  const int ntiles = (p.Lk + KVBLK - 1) / KVBLK;
+  const int tiles_all = (p.Lk + KVBLK - 1) / KVBLK;
+  const int t0 = split * p.tiles_per_split;                        // first key tile of this split (0 without split-KV)
+  const int ntiles = min(p.tiles_per_split, tiles_all - t0);       // tiles are indexed locally below; t0 + t is the global tile
   const unsigned k_step = (unsigned)(KVBLK * p.k_rs * 2), v_step = (unsigned)(KVBLK * p.v_rs * 2);
   unsigned k_go[2], v_go[2];
 #pragma unroll
@@ -160,18 +169,19 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
   auto issue_tile = [&](int t) {
     const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * (2 * KV_TILE_BYTES) + wave * 1024);   // wave-uniform
-    if ((t + 1) * KVBLK <= p.Lk) {
+    const int tg = t0 + t;
+    if ((tg + 1) * KVBLK <= p.Lk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        lds_dma16(kbase + (k_go[i] + (unsigned)t * k_step), slot + i * 8192);
-        lds_dma16(vbase + (v_go[i] + (unsigned)t * v_step), slot + KV_TILE_BYTES + i * 8192);
+        lds_dma16(kbase + (k_go[i] + (unsigned)tg * k_step), slot + i * 8192);
+        lds_dma16(vbase + (v_go[i] + (unsigned)tg * v_step), slot + KV_TILE_BYTES + i * 8192);
       }
     } else {                                 // last, partial tile: rows past Lk re-read the last key (masked later)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = (tid + NT * i) >> 4;
         const int col = ((tid & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 16;
-        const int key = min(t * KVBLK + row, p.Lk - 1);
+        const int key = min(tg * KVBLK + row, p.Lk - 1);
         lds_dma16(kbase + ((int64_t)key * p.k_rs * 2 + col), slot + i * 8192);
         lds_dma16(vbase + ((int64_t)key * p.v_rs * 2 + col), slot + KV_TILE_BYTES + i * 8192);
       }
@@ -211,12 +221,13 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       }
     }
   };
-  auto mask_half = [&](int g, f32x16& sacc) {
-    if ((g + 1) * 32 > p.Lk) {
+  auto mask_half = [&](int g, f32x16& sacc) {      // g: local half index; keys are global
+    const int gg = 2 * t0 + g;
+    if ((gg + 1) * 32 > p.Lk || g >= 2 * ntiles) {   // past the end of the keys, or of this split's range
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int key = g * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (key >= p.Lk) sacc[e] = -INFINITY;
+        const int key = gg * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key >= p.Lk || g >= 2 * ntiles) sacc[e] = -INFINITY;
       }
     }
   };
@@ -358,8 +369,26 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: O[q][32dt + 8i + 4h + (0..3)] = o_acc[dt][4i + (0..3)] / l
-  const float inv_l = 1.0f / pair_sum(l_run);
+  const float l_tot = pair_sum(l_run);
   const int qi = q0 + r;
+  if (p.kv_splits > 1) {                   // partial result of this key range; attn_merge_kernel finishes the softmax
+    if (qi < p.Lq) {
+      const int64_t row = (((int64_t)split * p.B + b) * p.Lq + qi) * p.H + head;
+      float* orow = p.ws_o + row * HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 ov;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ov[e] = o_acc[dt][4 * i + e];
+          *(f32x4*)(orow + 32 * dt + 8 * i + 4 * h) = ov;
+        }
+      if (h == 0) *(f32x2*)(p.ws_ml + row * 2) = (f32x2){m_run, l_tot};
+    }
+    return;
+  }
+  const float inv_l = 1.0f / l_tot;
   if (qi < p.Lq) {
     bf16* orow = p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.o_rs + head * HD;
 #pragma unroll
@@ -374,11 +403,37 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-}  // namespace
+// out[b][q][head][:] = sum_s w_s O_s / sum_s w_s l_s with w_s = exp2((m_s - max_s m_s) * scale_log2e); one wave per
+// (b, q, head) row, two columns per lane
+__global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
+  const int64_t rows = (int64_t)p.B * p.Lq * p.H;
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    float m = -INFINITY;
+    for (int s = 0; s < p.kv_splits; ++s) m = fmaxf(m, p.ws_ml[(s * rows + row) * 2]);
+    float l = 0.f;
+    f32x2 acc = {0.f, 0.f};
+    for (int s = 0; s < p.kv_splits; ++s) {
+      const f32x2 ml = *(const f32x2*)(p.ws_ml + (s * rows + row) * 2);
+      const float w = __builtin_amdgcn_exp2f((ml[0] - m) * p.scale_log2e);
+      l += w * ml[1];
+      const f32x2 o = *(const f32x2*)(p.ws_o + (s * rows + row) * HD + 2 * lane);
+      acc += o * w;
+    }
+    const int head = (int)(row % p.H);
+    const int64_t bq = row / p.H;
+    const int q = (int)(bq % p.Lq), b = (int)(bq / p.Lq);
+    const float inv = 1.0f / l;
+    bf16x2 ov;
+    ov[0] = f2bf(acc[0] * inv);
+    ov[1] = f2bf(acc[1] * inv);
+    *(bf16x2*)(p.o + (int64_t)b * p.o_bs + (int64_t)q * p.o_rs + head * HD + 2 * lane) = ov;
+  }
+}
 
-extern "C" int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
-                               const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
-                               int Lq, int Lk, int head_dim, float softmax_scale, void* stream) {
+int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
+             int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk, int head_dim, float softmax_scale,
+             int kv_splits, float* ws_o, float* ws_ml, void* stream) {
   FX_REQUIRE(q && k && v && o, FLEXAM_E_ARG, "attn_fwd: null pointer");
   FX_REQUIRE(head_dim == HD, FLEXAM_E_SHAPE, "attn_fwd: head_dim %d unsupported (128 only)", head_dim);
   FX_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, FLEXAM_E_SHAPE, "attn_fwd: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
@@ -386,12 +441,18 @@ extern "C" int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const 
                  o_bs % 4 == 0,
              FLEXAM_E_SHAPE, "attn_fwd: strides must keep 16-byte alignment of head rows");
   FX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, FLEXAM_E_ARG, "attn_fwd: misaligned pointer");
+  const int tiles_all = (Lk + KVBLK - 1) / KVBLK;
+  FX_REQUIRE(kv_splits >= 1 && kv_splits <= tiles_all, FLEXAM_E_ARG, "attn_fwd: %d key splits for %d key tiles", kv_splits, tiles_all);
+  FX_REQUIRE(kv_splits == 1 || (ws_o && ws_ml), FLEXAM_E_ARG, "attn_fwd: split-KV needs both workspaces");
   AttnParams p;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o;
   p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
   p.scale_log2e = softmax_scale * 1.4426950408889634f;
   p.q_blocks = (Lq + QBLK - 1) / QBLK;
+  p.tiles_per_split = (tiles_all + kv_splits - 1) / kv_splits;
+  p.kv_splits = (tiles_all + p.tiles_per_split - 1) / p.tiles_per_split;     // drop empty trailing splits
+  p.ws_o = ws_o; p.ws_ml = ws_ml;
   FX_REQUIRE((int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 x (K tile | V tile): 128 KiB
@@ -403,6 +464,28 @@ extern "C" int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const 
       return flexam_fail(FLEXAM_E_LAUNCH, "attn_fwd: cannot raise dynamic LDS to %d bytes", smem);
     attr_set[cross] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B * H * p.q_blocks), dim3(NT), smem, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(kern, dim3(B * H * p.q_blocks * p.kv_splits), dim3(NT), smem, (hipStream_t)stream, p);
+  if (p.kv_splits > 1) {
+    const int64_t rows = (int64_t)B * Lq * H;
+    const int64_t g = (rows + 3) / 4;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, p);
+  }
   return flexam_check_launch("flexam_attn_fwd");
+}
+
+}  // namespace
+
+extern "C" int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                               const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
+                               int Lq, int Lk, int head_dim, float softmax_scale, void* stream) {
+  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, 1, nullptr, nullptr,
+                  stream);
+}
+
+extern "C" int flexam_attn_fwd_splitkv(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                                       const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
+                                       int Lq, int Lk, int head_dim, float softmax_scale, int kv_splits, float* ws_o, float* ws_ml,
+                                       void* stream) {
+  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, kv_splits, ws_o,
+                  ws_ml, stream);
 }

@@ -150,6 +150,28 @@ def test_attention_matches_oracle(H, b, h, lq, lk):
     assert_bf16_close(out, _attn_ref(q, k, v), ulps=2.0, atol=6e-3, msg="attention")
 
 
+@pytest.mark.parametrize("splits,b,h,lq,lk", [(2, 1, 2, 300, 1111), (3, 2, 1, 64, 1600), (4, 1, 2, 513, 2055), (8, 1, 1, 256, 4100), (5, 1, 1, 100, 640)])
+def test_attention_split_kv_matches_oracle(H, splits, b, h, lq, lk):
+    """Keys cut into ranges (sequence-parallel ranks hold few query rows): partial softmaxes + merge must equal the one-pass
+    result; ragged Lq / Lk, a last split shorter than the others, a partial last key tile."""
+    g = torch.Generator().manual_seed(splits * 1000 + lk)
+    q = bf(torch.randn(b, lq, h, 128, generator=g))
+    k = bf(torch.randn(b, lk, h, 128, generator=g))
+    v = bf(torch.randn(b, lk, h, 128, generator=g))
+    out = H.attn_fwd(q.to(dev()), k.to(dev()), v.to(dev()), kv_splits=splits)
+    assert_bf16_close(out, _attn_ref(q, k, v), ulps=2.0, atol=6e-3, msg=f"split-KV attention S={splits}")
+    one = H.attn_fwd(q.to(dev()), k.to(dev()), v.to(dev()), kv_splits=1)
+    assert_bf16_close(out, one.float().cpu(), ulps=2.0, atol=4e-3, msg="split vs single pass")
+
+
+def test_attention_split_heuristic():
+    f = __import__("flexam_amd.hip", fromlist=["attn_kv_splits"]).attn_kv_splits
+    assert f(48, 11648, 11648) == 1            # one GPU: 2208 workgroups, 8.6 rounds
+    assert f(24, 11648, 11648) == 2            # CFG-parallel pair: 1104 workgroups
+    assert f(24, 2912, 11648) >= 4             # 8 GPUs: 288 workgroups for 256 CUs
+    assert f(48, 11648, 512) == 1              # text cross-attention: 8 key tiles, never split
+
+
 def test_attention_strided_qkv_and_scale(H):
     """q, k, v as column slices of one fused [B, L, 3*H*128] projection buffer (the DiT layout)."""
     g = torch.Generator().manual_seed(3)
