@@ -61,6 +61,22 @@ def test_gemm_exact_integers(H, m, n, k):
     torch.testing.assert_close(out.cpu(), a @ w.t() + b, rtol=0, atol=0)
 
 
+def test_gemm_full_size_one_hot_rows_select_weight_columns(H):
+    """Size-independent property at the BASELINE shape (M = 23296 tokens, N = K = 3072): with one-hot rows of A the
+    product is a gather of W's columns -- exact in bf16, every tile of the 91 x 12 grid and every K block is exercised."""
+    g = torch.Generator().manual_seed(17)
+    m, n, k = 23296, 3072, 3072
+    idx = torch.randint(0, k, (m,), generator=g)
+    a = torch.zeros(m, k, dtype=BF)
+    a[torch.arange(m), idx] = 1.0
+    w = bf(torch.randn(n, k, generator=g))
+    out = H.gemm(a.to(dev()), w.to(dev()))
+    assert torch.equal(out.cpu(), w[:, idx].t().contiguous())
+    x = torch.zeros(m, n, device=dev())
+    H.gemm_gate_residual(a.to(dev()), w.to(dev()), None, x)
+    assert torch.equal(x.cpu(), w[:, idx].t().float())
+
+
 @pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
 def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
     """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on
