@@ -196,12 +196,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # FLEXAM_BENCH_ONE_DEVICE=1 + FLEXAM_BENCH_BACKEND=gloo: validation of the multi-rank code path on a box with ONE GPU
+    # (all ranks share cuda:0, collectives go through the host); such a line is marked invalid below.
+    one_device = os.environ.get("FLEXAM_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("FLEXAM_BENCH_BACKEND", "nccl")
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from flexam_amd import Wan2_2FunControlPipeline_FlexAM
     from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
@@ -277,6 +286,8 @@ def main():
             "dit_block_mfma_frac": step_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
             "finite": finite,
         }
+        if one_device or backend != "nccl":
+            result["invalid"] = f"code-path validation only: {world} ranks on one device / backend {backend}"
         if kern is not None:
             a = kern["attn_self"]
             traffic = None                       # HBM bytes per launch from the committed PMC passes (not collected live)
