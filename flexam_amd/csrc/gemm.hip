@@ -225,6 +225,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     const int n = ncol + nt * 16;
     bias[nt] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  if constexpr (EPI == EPI_GATE_RESIDUAL) {
+    // Interior tiles (all but the last tile row / column): the fp32 read-modify-write of X is latency-bound unless many
+    // loads are in flight, and the general path below waits for every 16-byte load on its own (bounds branches keep the
+    // compiler from batching them).  Here the X and gate loads of two m-tiles (16 x 16 B per lane) are issued together.
+    if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
+#pragma unroll
+      for (int mt0 = 0; mt0 < MT; mt0 += 2) {
+        constexpr int NB = 2;
+        f32x4 xv[NB][NTW], gv[NB][NTW];
+        float* xp[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          if (mt0 + u >= MT) continue;                         // compile-time after unrolling (odd MT)
+          const int m = mrow + (mt0 + u) * 16;
+          xp[u] = p.X + (int64_t)m * p.ldx + ncol;
+          const float* grow = nullptr;
+          if (p.gate) {
+            const int64_t r = p.gate_row ? (int64_t)p.gate_row[m] : (int64_t)m / p.rows_per_batch;
+            grow = p.gate + r * p.gate_ld + ncol;
+          }
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            xv[u][nt] = *(const f32x4*)(xp[u] + nt * 16);
+            gv[u][nt] = grow ? *(const f32x4*)(grow + nt * 16) : (f32x4){1.f, 1.f, 1.f, 1.f};
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          if (mt0 + u >= MT) continue;
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            const f32x4 v = acc[mt0 + u][nt] + bias[nt];
+            f32x4 x = xv[u][nt];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(v[j])) * gv[u][nt][j];     // y rounded to bf16 first (FX.py:456,461,468)
+            *(f32x4*)(xp[u] + nt * 16) = x;
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mrow + mt * 16;
