@@ -83,41 +83,52 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  // ---- XCD-aware, grouped tile order
+  // ---- persistent workgroups over an XCD-aware, grouped tile order: workgroup w lives on XCD w & 7 (round-robin
+  // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
+  // stride gridDim/8, so the tiles resident on an XCD at any time are neighbours in the list (shared A / W panels in
+  // its L2) and a workgroup pays its launch latency once, not once per tile.
   const int nwg = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
-  const int GM = p.gm;
-  const int per_group = GM * p.tiles_n;
-  const int group = bid / per_group;
-  const int first_m = group * GM;
-  const int gsz = min(p.tiles_m - first_m, GM);
-  const int in_group = bid - group * per_group;
-  const int tm = first_m + in_group % gsz;
-  const int tn = in_group / gsz;
-  const int m0 = tm * BM_, n0 = tn * BN;
-
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
+  const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+  const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  // tile index in the grouped order -> first row / column
+  auto tile_origin = [&](int bid, int& m0, int& n0) {
+    const int GM = p.gm;
+    const int per_group = GM * p.tiles_n;
+    const int group = bid / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int in_group = bid - group * per_group;
+    m0 = (first_m + in_group % gsz) * BM_;
+    n0 = (in_group / gsz) * BN;
+  };
   // ---- staging addresses: thread -> (row = i*64 + tid/8, LDS slot = tid%8), source chunk = slot ^ swz(row).
   // Byte offsets from the tile's first row fit 32 bits (256 rows x row stride), so a piece's source is
   // (uniform 64-bit tile base + K offset) + one VGPR: the scalar-base form of global_load_lds.
   uint32_t a_off[PA], w_off[4];
+  const char *a_tile, *w_tile;
+  auto stage_setup = [&](int m0, int n0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 64 + (tid >> 3);
-    const int chunk = (tid & 7) ^ ((row >> 1) & 7);
-    if (i < PA) a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);   // edge tiles re-read their last row
-    w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
-  }
-  const char* a_tile = (const char*)(p.A + (int64_t)m0 * p.lda);
-  const char* w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 64 + (tid >> 3);
+      const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+      if (i < PA) a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);   // edge tiles re-read their last row
+      w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
+    }
+    a_tile = (const char*)(p.A + (int64_t)m0 * p.lda);
+    w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
+  };
 
   // ---- fragment read offsets (bytes inside a tile): row = base16 + (lane&15), chunk = (lane>>4) + 4*ks
   const int sw = (lane & 15) >> 1;
   const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
   const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
+  bool staged = false;          // K block 0 of the coming tile is already on its way into LDS buffer 0
+
+  for (int it = blockIdx.x >> 3; it < chunk_n; it += per_xcd) {
+  int m0, n0;
+  tile_origin(chunk0 + it, m0, n0);
+  if (!staged) stage_setup(m0, n0);
 
   f32x4 acc[MT][NTW];
 #pragma unroll
@@ -167,8 +178,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // so no wave crosses the barrier without MFMA work already in registers, and the DMA pieces and fragment
   // reads of a phase are spread one group (4 MFMAs) apart instead of stalling the wave up front.
   bf16x8 wf0[NTW], af0[MT], wf1[NTW], af1[MT];
+  if (!staged) {
 #pragma unroll
-  for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
+    for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
+  }
   int64_t kcol_next = kcol_a(1);          // A offset of the tile staged next, fetched one step ahead
   dma_wait_barrier();
   if (nk > 1) {
@@ -215,6 +228,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   for (; kb + 2 < nk; ++kb) block(kb, T_{}, T_{});
   if (kb + 1 < nk) { block(kb, F_{}, T_{}); ++kb; }
   block(kb, F_{}, F_{});
+
+  // ---- the next tile's first K block goes on its way before this tile's epilogue: LDS is idle from here on (every wave
+  // passed the last barrier with its fragments in registers) and the epilogue only touches global memory
+  staged = it + per_xcd < chunk_n;
+  if (staged) {
+    int nm0, nn0;
+    tile_origin(chunk0 + it + per_xcd, nm0, nn0);
+    stage_setup(nm0, nn0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
+  }
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
   const int mrow = m0 + wm * (16 * MT) + (lane & 15);
@@ -264,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
           }
         }
       }
-      return;
+      continue;                                        // next tile of this persistent workgroup
     }
   }
 #pragma unroll
@@ -305,6 +329,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       }
     }
   }
+  }   // tile loop
+}
+
+int num_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount / 8 * 8;
+    }
+    return cus;
+  }();
+  return n;
 }
 
 template <int EPI, typename OutT, int MT>
@@ -318,7 +355,11 @@ int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
     attr_set = true;
   }
   p.tiles_m = (p.M + 32 * MT - 1) / (32 * MT);
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), smem, s, p, a_koff);
+  const int nwg = p.tiles_m * p.tiles_n;
+  int grid = (nwg + 7) / 8 * 8;                          // a multiple of 8 so that blockIdx & 7 is the XCD
+  static const int persist = [] { const char* e = getenv("FLEXAM_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
+  if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (128 KiB of LDS each)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, p, a_koff);
   return flexam_check_launch("flexam_gemm_bf16");
 }
 
