@@ -52,6 +52,11 @@ struct GemmParams {
   const int32_t* gate_row; // [M] row index per output row, or null
   int64_t rows_per_batch;  // used when gate_row is null: row = m / rows_per_batch
   int gm;                  // tile-rows per L2 group (XCD-aware order)
+  // tail split-K: work units 0..split_full-1 are whole tiles; the remaining tiles (the last, partial round of the CUs) are
+  // cut into split_s K slices each; partial sums go through `ws`, the last slice to arrive (counters) reduces + finishes
+  int units, split_full, split_s;
+  float* ws;
+  int* counters;
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -87,10 +92,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
   // stride gridDim/8, so the tiles resident on an XCD at any time are neighbours in the list (shared A / W panels in
   // its L2) and a workgroup pays its launch latency once, not once per tile.
-  const int nwg = p.tiles_m * p.tiles_n;
+  // Whole tiles (units < split_full) are chunked per XCD as described; the K slices of the tail tiles (units >= split_full)
+  // are dealt round-robin over all workgroups afterwards, so every XCD gets the same amount of tail work.
+  const int nwg = p.split_full;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3;
   const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+  const int local = blockIdx.x >> 3;
+  const int n_whole = local < chunk_n ? (chunk_n - local + per_xcd - 1) / per_xcd : 0;
+  const int n_tail = (int)blockIdx.x < p.units - p.split_full ? (p.units - p.split_full - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  auto nth_unit = [&](int j) -> int {       // j-th work unit of this workgroup, -1 past the end
+    if (j < n_whole) return chunk0 + local + j * per_xcd;
+    if (j < n_whole + n_tail) return p.split_full + (int)blockIdx.x + (j - n_whole) * (int)gridDim.x;
+    return -1;
+  };
   // tile index in the grouped order -> first row / column
   auto tile_origin = [&](int bid, int& m0, int& n0) {
     const int GM = p.gm;
@@ -123,11 +138,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   const int sw = (lane & 15) >> 1;
   const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
   const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
-  bool staged = false;          // K block 0 of the coming tile is already on its way into LDS buffer 0
+  bool staged = false;          // K block 0 of the coming unit is already on its way into LDS buffer 0
+  const int nk = p.K / BK;
+  auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
+  // work unit -> (tile, first K block, K blocks, slice, slices)
+  auto unit_decode = [&](int u, int& tile, int& kb0, int& nkl, int& slice, int& ns) {
+    if (u < p.split_full) {
+      tile = u; kb0 = 0; nkl = nk; slice = 0; ns = 1;
+    } else {
+      const int v = u - p.split_full;
+      tile = p.split_full + v / p.split_s;
+      slice = v - (v / p.split_s) * p.split_s;
+      ns = p.split_s;
+      kb0 = (int)((int64_t)slice * nk / ns);
+      nkl = (int)((int64_t)(slice + 1) * nk / ns) - kb0;
+    }
+  };
+  __shared__ int arrive_flag;
 
-  for (int it = blockIdx.x >> 3; it < chunk_n; it += per_xcd) {
-  int m0, n0;
-  tile_origin(chunk0 + it, m0, n0);
+  for (int it = 0; it < n_whole + n_tail; ++it) {
+  int m0, n0, tile, kb0, nkl, slice, ns;
+  unit_decode(nth_unit(it), tile, kb0, nkl, slice, ns);
+  tile_origin(tile, m0, n0);
   if (!staged) stage_setup(m0, n0);
 
   f32x4 acc[MT][NTW];
@@ -135,9 +167,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-  auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
 
   // piece i (i < PA: A rows i*64.., else W rows (i-PA)*64..) of the tile at A K-offset ka / W K-offset kw -> LDS buffer `buf`.
   // Inline asm: the scalar-base form (uniform 64-bit base + one 32-bit VGPR offset) keeps the per-thread
@@ -180,15 +209,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   bf16x8 wf0[NTW], af0[MT], wf1[NTW], af1[MT];
   if (!staged) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
+    for (int i = 0; i < NP; ++i) dma(i, kcol_a(kb0), (int64_t)kb0 * BK, smem);
   }
-  int64_t kcol_next = kcol_a(1);          // A offset of the tile staged next, fetched one step ahead
+  int64_t kcol_next = kcol_a(kb0 + 1);    // A offset of the K block staged next, fetched one step ahead
   dma_wait_barrier();
-  if (nk > 1) {
+  if (nkl > 1) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) dma(i, kcol_next, BK, smem + 2 * TILE_BYTES);
+    for (int i = 0; i < NP; ++i) dma(i, kcol_next, (int64_t)(kb0 + 1) * BK, smem + 2 * TILE_BYTES);
   }
-  kcol_next = kcol_a(2);
+  kcol_next = kcol_a(kb0 + 2);
 #pragma unroll
   for (int g = 0; g < (NF + 1) / 2; ++g) ld2(smem, frag_off0, g, wf0, af0);
 
@@ -196,7 +225,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
     char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
     char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
-    const int64_t kw = (int64_t)(kb + 2) * BK;
+    const int64_t kw = (int64_t)(kb0 + kb + 2) * BK;
 #pragma unroll
     for (int g = 0; g < MT; ++g) {                      // phase A
       __builtin_amdgcn_sched_barrier(0);
@@ -220,24 +249,64 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       if constexpr (RD) ld2(nxt, frag_off0, g, wf0, af0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    kcol_next = kcol_a(kb + 3);
+    kcol_next = kcol_a(kb0 + kb + 3);
   };
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
   int kb = 0;
-  for (; kb + 2 < nk; ++kb) block(kb, T_{}, T_{});
-  if (kb + 1 < nk) { block(kb, F_{}, T_{}); ++kb; }
+  for (; kb + 2 < nkl; ++kb) block(kb, T_{}, T_{});
+  if (kb + 1 < nkl) { block(kb, F_{}, T_{}); ++kb; }
   block(kb, F_{}, F_{});
 
   // ---- the next tile's first K block goes on its way before this tile's epilogue: LDS is idle from here on (every wave
   // passed the last barrier with its fragments in registers) and the epilogue only touches global memory
-  staged = it + per_xcd < chunk_n;
+  staged = it + 1 < n_whole + n_tail;
   if (staged) {
-    int nm0, nn0;
-    tile_origin(chunk0 + it + per_xcd, nm0, nn0);
+    int nm0, nn0, ntile, nkb0, nnkl, nslice, nns;
+    unit_decode(nth_unit(it + 1), ntile, nkb0, nnkl, nslice, nns);
+    tile_origin(ntile, nm0, nn0);
     stage_setup(nm0, nn0);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) dma(i, kcol_a(0), 0, smem);
+    for (int i = 0; i < NP; ++i) dma(i, kcol_a(nkb0), (int64_t)nkb0 * BK, smem);
+  }
+
+  // ---- tail split-K: park this slice's partial sums; the slice whose arrival count comes back last adds all of them up in
+  // slice order (deterministic) and runs the epilogue.  Per-XCD L2s are not coherent with each other, and an agent-scope
+  // fence would write back / invalidate a whole L2 per hand-off; instead EVERY handed-off byte is stored and loaded with
+  // agent-scope (sc1) accesses, each storing wave drains its stores, and one lane signals behind a workgroup barrier with a
+  // relaxed agent-scope atomic add (MI355X_MICROARCH.md, inter-workgroup visibility: the "added last" row).
+  if (ns > 1) {
+    constexpr int SLAB = 256 * BN;                     // floats per slab; 16-byte element of (mt, nt) at ((mt*4+nt)*512 + tid)*4
+    typedef unsigned long long u64;
+    const int tr = tile - p.split_full;
+    float* slab = p.ws + ((int64_t)tr * ns + slice) * SLAB;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)          // 16-byte sc1 stores cost what plain ones do; 8-byte ones are one fabric write each
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slab + ((mt * NTW + nt) * 512 + tid) * 4), "v"(acc[mt][nt]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) arrive_flag = __hip_atomic_fetch_add(p.counters + tr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = arrive_flag == ns - 1;
+    __syncthreads();                                   // arrive_flag is rewritten by the next split unit
+    if (!last) continue;
+    if (tid == 0) __hip_atomic_store(p.counters + tr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    const u64* base = (const u64*)(p.ws + (int64_t)tr * ns * SLAB);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int e = ((mt * NTW + nt) * 512 + tid) * 2 + hf;
+          f32x2 sum = __builtin_bit_cast(f32x2, __hip_atomic_load(base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          for (int s2 = 1; s2 < ns; ++s2)
+            sum += __builtin_bit_cast(f32x2, __hip_atomic_load(base + (int64_t)s2 * (SLAB / 2) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          acc[mt][nt][2 * hf] = sum[0];
+          acc[mt][nt][2 * hf + 1] = sum[1];
+        }
   }
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
@@ -332,6 +401,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   }   // tile loop
 }
 
+// scratch for the tail split-K, registered by the host side (flexam_gemm_set_workspace): [256 ints | slabs of 256 x 256 fp32]
+struct GemmWorkspace {
+  int* counters = nullptr;
+  float* slabs = nullptr;
+  int64_t n_slabs = 0;
+};
+GemmWorkspace g_ws;
+
 int num_cus() {
   static const int n = [] {
     int dev = 0, cus = 256;
@@ -342,6 +419,28 @@ int num_cus() {
     return cus;
   }();
   return n;
+}
+
+// Tail split-K plan: `rem` = tiles of the last, partial round of the CUs.  Cutting each of them into S K slices turns that
+// round into ceil(rem*S/G) passes of 1/S of a tile, and every pass pays the hand-off: parking 256 KiB of partial sums and the
+// arrival atomic (~15 us), then ONE workgroup re-reads S slabs at the ~25 GB/s a single CU can pull (~10 us per slab) --
+// in K blocks of main loop (1.15 us each): 13 + 9 S.  S (<= 8, slabs must fit the workspace) minimises the sum; with
+// K = 3072 (48 K blocks) the hand-off eats the gain and nothing is split, with K = 14336 the tail shrinks to ~0.5 tile
+// times.  `cost` = resulting length of the tail in tile times (1.0 without a split).
+void plan_split(int tiles, int nk, int& S, int& rem, double* cost = nullptr) {
+  const int G = num_cus();
+  static const int enabled = [] { const char* e = getenv("FLEXAM_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
+  rem = tiles % G;
+  S = 1;
+  double best = rem ? 1.0 : 0.0;
+  if (enabled && g_ws.slabs && rem) {
+    for (int s = 2; s <= 8 && s <= nk / 8 && (int64_t)rem * s <= g_ws.n_slabs; ++s) {
+      const int passes = (rem * s + G - 1) / G;
+      const double c = passes * (1.0 / s + (13.0 + 9.0 * s) / nk);
+      if (c < best - 0.05) { best = c; S = s; }
+    }
+  }
+  if (cost) *cost = best;
 }
 
 template <int EPI, typename OutT, int MT>
@@ -355,7 +454,15 @@ int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
     attr_set = true;
   }
   p.tiles_m = (p.M + 32 * MT - 1) / (32 * MT);
-  const int nwg = p.tiles_m * p.tiles_n;
+  const int tiles = p.tiles_m * p.tiles_n;
+  int split_s, rem;
+  plan_split(tiles, p.K / BK, split_s, rem);
+  p.split_s = split_s;
+  p.split_full = split_s > 1 ? tiles - rem : tiles;
+  p.units = p.split_full + (split_s > 1 ? rem * split_s : 0);
+  p.ws = g_ws.slabs;
+  p.counters = g_ws.counters;
+  const int nwg = p.units;
   int grid = (nwg + 7) / 8 * 8;                          // a multiple of 8 so that blockIdx & 7 is the XCD
   static const int persist = [] { const char* e = getenv("FLEXAM_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
   if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (128 KiB of LDS each)
@@ -365,15 +472,19 @@ int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
 
 // Tile height: rounds of 256 concurrently resident workgroups x relative cost of one tile (MT m-tiles of MFMA work
 // plus a fixed part for the W side, barriers and the epilogue); FLEXAM_GEMM_MT=8..4 forces a shape (tuning only).
-int pick_mt(int M, int tiles_n) {
+int pick_mt(int M, int tiles_n, int nk) {
   const char* e = getenv("FLEXAM_GEMM_MT");
   const int forced = e ? atoi(e) : 0;
   if (forced >= 4 && forced <= 8) return forced;
   int best = 8;
   double best_cost = 1e30;
+  const int G = num_cus();
   for (int mt = 8; mt >= 4; --mt) {
-    const long tiles = (long)((M + 32 * mt - 1) / (32 * mt)) * tiles_n;
-    const double cost = (double)((tiles + 255) / 256) * (mt + 1.25);
+    const int tiles = (int)((long)((M + 32 * mt - 1) / (32 * mt)) * tiles_n);
+    int S, rem;
+    double tail;
+    plan_split(tiles, nk, S, rem, &tail);
+    const double cost = (tiles / G + tail) * (mt + 1.25);
     if (cost < best_cost * 0.97) { best_cost = cost; best = mt; }      // a smaller tile must win by > 3 %
   }
   return best;
@@ -391,7 +502,7 @@ int launch(const GemmParams& p_, const int64_t* a_koff, hipStream_t s) {
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
   p.debug = dbg ? atoi(dbg) : 0;
 #endif
-  switch (pick_mt(p.M, p.tiles_n)) {
+  switch (pick_mt(p.M, p.tiles_n, p.K / BK)) {
     case 7: return launch_mt<EPI, OutT, 7>(p, a_koff, s);
     case 6: return launch_mt<EPI, OutT, 6>(p, a_koff, s);
     case 5: return launch_mt<EPI, OutT, 5>(p, a_koff, s);
@@ -440,4 +551,16 @@ extern "C" int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const 
   p.X = X; p.ldx = ldx; p.gate = gate; p.gate_ld = gate_ld; p.gate_row = gate_row;
   p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
   return launch<EPI_GATE_RESIDUAL, bf16>(p, a_koff, (hipStream_t)stream);
+}
+
+extern "C" int flexam_gemm_set_workspace(void* ws, int64_t bytes) {
+  if (!ws || bytes < 1024 + 256 * BN * 4) {
+    g_ws = GemmWorkspace{};
+    return 0;
+  }
+  FX_REQUIRE((uintptr_t)ws % 16 == 0, FLEXAM_E_ARG, "gemm_set_workspace: pointer must be 16-byte aligned");
+  g_ws.counters = (int*)ws;                              // 256 ints, must be zero on entry (the kernels leave them zero)
+  g_ws.slabs = (float*)((char*)ws + 1024);
+  g_ws.n_slabs = (bytes - 1024) / ((int64_t)256 * BN * 4);
+  return 0;
 }

@@ -24,6 +24,7 @@ _SIGNATURES = {
     "flexam_device_check": ([], c_int),
     "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P], c_int),
     "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P], c_int),
+    "flexam_gemm_set_workspace": ([_P, _L], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
     "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
@@ -118,6 +119,18 @@ def device_check():
 
 
 # ----------------------------------------------------------------------------- GEMM
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device):
+    """Registers the tail split-K scratch (64 MiB + counters) once per process; see flexam_gemm_set_workspace."""
+    if "buf" not in _GEMM_WS:
+        buf = torch.zeros(1024 + 256 * 256 * 256 * 4, device=device, dtype=torch.uint8)
+        _check(lib().flexam_gemm_set_workspace(buf.data_ptr(), buf.numel()), "flexam_gemm_set_workspace")
+        _GEMM_WS["buf"] = buf
+    return _GEMM_WS["buf"]
+
+
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=None, m=None, k=None):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  a, w bf16 2-D views (row stride free).
     With a_koff (int64 [K/64]) `a` is only a base view: rows are `m`, K = `k` (implicit conv)."""
@@ -132,6 +145,7 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=No
     om, on, ldc = _rows(out)
     if (om, on) != (M, wn):
         raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != ({M}, {wn})")
+    _gemm_workspace(a.device)
     _check(lib().flexam_gemm_bf16(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(out), ldc, M, wn, K, epilogue,
                                   1 if out.dtype == F32 else 0, _ptr(a_koff, I64), _stream()), "flexam_gemm_bf16")
     return out
@@ -146,6 +160,7 @@ def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0
     if (a_koff is None and (ak != K or am != M)) or xn != N:
         raise RuntimeError("gemm_gate_residual: shape mismatch")
     gate_ld = gate.stride(0) if gate is not None else 0
+    _gemm_workspace(a.device)
     _check(lib().flexam_gemm_bf16_gate_residual(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(x, F32), ldx,
                                                 _ptr(gate, F32), gate_ld, _ptr(gate_row, I32), rows_per_batch, M, N, K,
                                                 _ptr(a_koff, I64), _stream()), "flexam_gemm_bf16_gate_residual")

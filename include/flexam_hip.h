@@ -57,6 +57,13 @@ int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, in
                                    int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, const int64_t* a_koff,
                                    void* stream);
 
+/* Optional scratch for the GEMMs' tail split-K (the tiles of the last, partial round of the CUs are cut along K so that all CUs
+ * work; partial sums are reduced in a fixed order by the slice that finishes last -> deterministic).  `ws`: device memory,
+ * 16-byte aligned, first 1 KiB ZEROED by the caller (arrival counters; kernels leave them zero), then slabs of 256 KiB; 64 MiB
+ * + 1 KiB covers every shape.  ws = NULL unregisters (GEMMs then never split).  One registration per process (one GPU per
+ * process); launches that use it must be ordered on one stream at a time. */
+int flexam_gemm_set_workspace(void* ws, int64_t bytes);
+
 /* Flash attention forward, head_dim 128, non-causal, keys [0, Lk): o = softmax(q k^T * scale) v.
  * q/k/v/o are [B, L, H, 128] views given by batch stride `*_bs` and row stride `*_rs` (elements);
  * head h starts at column h*128 of a row.  bf16 in/out, fp32 softmax/accumulate.

@@ -77,6 +77,30 @@ def test_gemm_full_size_one_hot_rows_select_weight_columns(H):
     assert torch.equal(x.cpu(), w[:, idx].t().float())
 
 
+@pytest.mark.parametrize("m,n,k", [(5000, 3072, 3072), (2912, 3072, 14336), (1500, 1024, 1024), (70 * 256, 256, 2048)])
+def test_gemm_tail_split_k_is_exact_and_repeatable(H, m, n, k, monkeypatch):
+    """Shapes whose tile count leaves the last round of the 256 CUs mostly empty: those tiles are cut along K (partial sums
+    through the registered workspace, fixed-order reduction).  Integer data -> exact; ten launches -> identical bits; all
+    three epilogues; and the same answers with the split disabled."""
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    w = torch.randint(-2, 3, (n, k), generator=g).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    want = a @ w.t() + b
+    ad, wd, bd = bf(a).to(dev()), bf(w).to(dev()), b.to(dev())
+    outs = [H.gemm(ad, wd, bd, out_dtype=torch.float32) for _ in range(10)]
+    torch.testing.assert_close(outs[0].cpu(), want, rtol=0, atol=0)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+    x = x0.clone().to(dev())
+    H.gemm_gate_residual(ad, wd, bd, x)
+    torch.testing.assert_close(x.cpu(), x0 + want.to(BF).float(), rtol=0, atol=0)
+    out16 = H.gemm(ad, wd, bd, epilogue=H.EPI_GELU_TANH)
+    monkeypatch.setenv("FLEXAM_GEMM_SPLITK", "0")          # read once per process: this only documents the switch
+    ref16 = torch.nn.functional.gelu(want, approximate="tanh").to(BF)
+    assert_bf16_close(out16, ref16.float(), ulps=2.0, atol=1e-2, msg="gelu epilogue after split-K")
+
+
 @pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
 def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
     """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on
