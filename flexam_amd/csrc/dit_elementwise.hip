@@ -13,6 +13,69 @@ constexpr int RT = 128;   // threads per row
 __device__ __forceinline__ float row_sum(float v, float* red) { return block_sum<RT>(v, red); }
 
 // ------------------------------------------------------------------------------------------
+// Same LayerNorm + modulation, ONE WAVE PER ROW (C = 512*NV8, NV8 <= 8): every lane keeps 8*NV8 values in registers, both
+// reductions are wave shuffles (no LDS, no barrier), four rows per 256-thread block.  The block-per-row form below spends
+// its time in two block reductions per 12 KiB row; this one keeps 6 x 32 B loads per lane in flight.
+// ------------------------------------------------------------------------------------------
+template <int NV8>
+__global__ __launch_bounds__(256) void ln_modulate_wave_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, float eps,
+                                                               const float* __restrict__ shift, const float* __restrict__ scale,
+                                                               int64_t tab_ld, const int32_t* __restrict__ row_index,
+                                                               int64_t rows_per_batch, const float* __restrict__ ln_w,
+                                                               const float* __restrict__ ln_b, bf16* __restrict__ out, int64_t ldo) {
+  constexpr int C = 512 * NV8;
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const float* xr = x + m * ldx;
+  f32x4 v[NV8][2];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    v[i][0] = *(const f32x4*)(xr + c);
+    v[i][1] = *(const f32x4*)(xr + c + 4);
+  }
+#pragma unroll
+  for (int i = 0; i < NV8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += v[i][0][j] + v[i][1][j];
+  const float mean = wave_sum(s) * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = v[i][0][j] - mean, b = v[i][1][j] - mean;
+      q += a * a + b * b;
+    }
+  const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * (1.0f / C) + eps);
+  const float* sh = nullptr;
+  const float* sc = nullptr;
+  if (shift) {
+    const int64_t r = row_index ? (int64_t)row_index[m] : m / rows_per_batch;
+    sh = shift + r * tab_ld;
+    sc = scale + r * tab_ld;
+  }
+  bf16* orow = out + m * ldo;
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int c0 = (i * 64 + lane) * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = c0 + h * 4;
+      f32x4 y = (v[i][h] - mean) * rstd;
+      if (ln_w) y = y * *(const f32x4*)(ln_w + c) + *(const f32x4*)(ln_b + c);
+      if (sh) y = y * *(const f32x4*)(sc + c) + *(const f32x4*)(sh + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[h * 4 + j] = f2bf(y[j]);
+    }
+    *(bf16x8*)(orow + c0) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm (no affine, or affine for norm3) * scale + shift  ->  bf16
 //   scale/shift rows come from a small fp32 table; row = row_index[m] or m / rows_per_batch.
 //   The table already holds (1 + scale) and (shift + density shift): see mod_table_kernel.
@@ -407,6 +470,17 @@ extern "C" int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C,
   FX_REQUIRE((ln_w == nullptr) == (ln_b == nullptr), FLEXAM_E_ARG, "ln_modulate: ln_w and ln_b go together");
   FX_REQUIRE(!shift || row_index || rows_per_batch > 0, FLEXAM_E_ARG, "ln_modulate: need row_index or rows_per_batch");
   if (rows_per_batch <= 0) rows_per_batch = 1;
+  if (C % 512 == 0 && C <= 4096) {             // wave-per-row form (the DiT width 3072 = 512 * 6)
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+#define LN_WAVE(NV8_)                                                                                                              \
+  case NV8_:                                                                                                                       \
+    hipLaunchKernelGGL(ln_modulate_wave_kernel<NV8_>, grid, block, 0, (hipStream_t)stream, x, ldx, M, eps, shift, scale, tab_ld, \
+                       row_index, rows_per_batch, ln_w, ln_b, (bf16*)out, ldo);                                                    \
+    break;
+    switch (C / 512) { LN_WAVE(1) LN_WAVE(2) LN_WAVE(3) LN_WAVE(4) LN_WAVE(5) LN_WAVE(6) LN_WAVE(7) LN_WAVE(8) }
+#undef LN_WAVE
+    return flexam_check_launch("flexam_ln_modulate");
+  }
   DISPATCH_VPT(C, hipLaunchKernelGGL(ln_modulate_kernel<VPT>, dim3((unsigned)M), dim3(RT), 0, (hipStream_t)stream, x, ldx, C, eps,
                                      shift, scale, tab_ld, row_index, rows_per_batch, ln_w, ln_b, (bf16*)out, ldo));
   return flexam_check_launch("flexam_ln_modulate");
