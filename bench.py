@@ -297,7 +297,11 @@ def main():
             result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0> (self-attention, head_dim 128)", "achieved": a["tflops"],
                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                   "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r1d_*)",
-                                  "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"]}
+                                  "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"],
+                                  "launch_note": "one self-attention call = attn_fwd_kernel<0> over the full rounds of work units + "
+                                                 "attn_fwd_kernel<0> over the last partial round with its keys cut in 3 + attn_merge_kernel; "
+                                                 "launch_ms is the whole call, so rocprofv3 shows 2 attn_fwd_kernel<0> rows per call "
+                                                 "(launch_ms = 2 x its AverageNs + the merge)"}
             result["kernels"] = {k: {"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1),
                                      "frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} for k, v in kern.items()}
         if base is not None:

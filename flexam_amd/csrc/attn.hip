@@ -44,8 +44,9 @@ struct AttnParams {
   // split-KV (kv_splits > 1): workgroup (q block, head, split) covers key tiles [split*tiles_per_split, ..) and writes its
   // un-normalised O (fp32) and (running max, row sum) to the workspace; attn_merge_kernel combines the splits
   int kv_splits, tiles_per_split;
-  float* ws_o;          // [S][B][Lq][H][128]
-  float* ws_ml;         // [S][B][Lq][H][2]
+  int unit0, n_units;   // this launch covers work units (q block, head, batch) unit0 .. unit0 + n_units - 1
+  float* ws_o;          // [S][n_units][256 rows][128]
+  float* ws_ml;         // [S][n_units][256 rows][2]
 };
 
 // byte offset of 16-byte chunk `ch` (0..15) of key row `row` in a [64][128] bf16 tile, image (b)
@@ -112,16 +113,18 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
 
-  const int nwg = p.B * p.H * p.q_blocks * p.kv_splits;
+  const int nwg = p.n_units * p.kv_splits;
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, local = bid >> 3;
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
   }
-  const int qb = bid % p.q_blocks;                 // consecutive workgroups: q blocks of one (head, split) -> same K/V range in L2
-  const int rest = bid / p.q_blocks;
-  const int split = rest % p.kv_splits;
-  const int bh = rest / p.kv_splits;
+  // consecutive workgroups: the units of one split, i.e. q blocks of one head first -> same K/V range in L2
+  const int split = bid / p.n_units;
+  const int ul = bid - split * p.n_units;          // unit index inside this launch
+  const int unit = p.unit0 + ul;
+  const int qb = unit % p.q_blocks;
+  const int bh = unit / p.q_blocks;
   const int head = bh % p.H, b = bh / p.H;
 
   const bf16* qbase = p.q + (int64_t)b * p.q_bs + head * HD;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const int qi = q0 + r;
   if (p.kv_splits > 1) {                   // partial result of this key range; attn_merge_kernel finishes the softmax
     if (qi < p.Lq) {
-      const int64_t row = (((int64_t)split * p.B + b) * p.Lq + qi) * p.H + head;
+      const int64_t row = ((int64_t)split * p.n_units + ul) * QBLK + wave * 32 + r;
       float* orow = p.ws_o + row * HD;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -403,12 +406,17 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-// out[b][q][head][:] = sum_s w_s O_s / sum_s w_s l_s with w_s = exp2((m_s - max_s m_s) * scale_log2e); one wave per
-// (b, q, head) row, two columns per lane
+// out[b][q][head][:] = sum_s w_s O_s / sum_s w_s l_s with w_s = exp2((m_s - max_s m_s) * scale_log2e) for the rows of the
+// launch's units; one wave per row, two columns per lane
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
-  const int64_t rows = (int64_t)p.B * p.Lq * p.H;
+  const int64_t rows = (int64_t)p.n_units * QBLK;
   const int lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const int ul = (int)(row / QBLK), rr = (int)(row % QBLK);
+    const int unit = p.unit0 + ul;
+    const int qb = unit % p.q_blocks, bh = unit / p.q_blocks;
+    const int q = qb * QBLK + rr;
+    if (q >= p.Lq) continue;
     float m = -INFINITY;
     for (int s = 0; s < p.kv_splits; ++s) m = fmaxf(m, p.ws_ml[(s * rows + row) * 2]);
     float l = 0.f;
@@ -420,9 +428,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
       const f32x2 o = *(const f32x2*)(p.ws_o + (s * rows + row) * HD + 2 * lane);
       acc += o * w;
     }
-    const int head = (int)(row % p.H);
-    const int64_t bq = row / p.H;
-    const int q = (int)(bq % p.Lq), b = (int)(bq / p.Lq);
+    const int head = bh % p.H, b = bh / p.H;
     const float inv = 1.0f / l;
     bf16x2 ov;
     ov[0] = f2bf(acc[0] * inv);
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
 
 int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
              int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk, int head_dim, float softmax_scale,
-             int kv_splits, float* ws_o, float* ws_ml, void* stream) {
+             int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream) {
   FX_REQUIRE(q && k && v && o, FLEXAM_E_ARG, "attn_fwd: null pointer");
   FX_REQUIRE(head_dim == HD, FLEXAM_E_SHAPE, "attn_fwd: head_dim %d unsupported (128 only)", head_dim);
   FX_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, FLEXAM_E_SHAPE, "attn_fwd: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
@@ -464,10 +470,18 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
       return flexam_fail(FLEXAM_E_LAUNCH, "attn_fwd: cannot raise dynamic LDS to %d bytes", smem);
     attr_set[cross] = true;
   }
-  hipLaunchKernelGGL(kern, dim3(B * H * p.q_blocks * p.kv_splits), dim3(NT), smem, (hipStream_t)stream, p);
-  if (p.kv_splits > 1) {
-    const int64_t rows = (int64_t)B * Lq * H;
-    const int64_t g = (rows + 3) / 4;
+  const int units = B * H * p.q_blocks;
+  FX_REQUIRE(split_from_unit >= 0 && split_from_unit <= units, FLEXAM_E_ARG, "attn_fwd: split_from_unit %d of %d units", split_from_unit, units);
+  const int S = p.kv_splits, tps = p.tiles_per_split;
+  if (S == 1) split_from_unit = units;
+  if (split_from_unit > 0) {               // units [0, split_from_unit): one pass over all keys
+    p.unit0 = 0; p.n_units = split_from_unit; p.kv_splits = 1; p.tiles_per_split = tiles_all;
+    hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);
+  }
+  if (split_from_unit < units) {           // the rest: S key ranges each, then the merge
+    p.unit0 = split_from_unit; p.n_units = units - split_from_unit; p.kv_splits = S; p.tiles_per_split = tps;
+    hipLaunchKernelGGL(kern, dim3(p.n_units * S), dim3(NT), smem, (hipStream_t)stream, p);
+    const int64_t g = ((int64_t)p.n_units * QBLK + 3) / 4;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, p);
   }
   return flexam_check_launch("flexam_attn_fwd");
@@ -478,14 +492,14 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
 extern "C" int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                                const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
                                int Lq, int Lk, int head_dim, float softmax_scale, void* stream) {
-  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, 1, nullptr, nullptr,
-                  stream);
+  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, 1, 0, nullptr,
+                  nullptr, stream);
 }
 
 extern "C" int flexam_attn_fwd_splitkv(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
                                        const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
-                                       int Lq, int Lk, int head_dim, float softmax_scale, int kv_splits, float* ws_o, float* ws_ml,
-                                       void* stream) {
-  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, kv_splits, ws_o,
-                  ws_ml, stream);
+                                       int Lq, int Lk, int head_dim, float softmax_scale, int kv_splits, int split_from_unit,
+                                       float* ws_o, float* ws_ml, void* stream) {
+  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, kv_splits,
+                  split_from_unit, ws_o, ws_ml, stream);
 }

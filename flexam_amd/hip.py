@@ -26,7 +26,7 @@ _SIGNATURES = {
     "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P], c_int),
     "flexam_gemm_set_workspace": ([_P, _L], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
-    "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
+    "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
     "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
     "flexam_rmsnorm_rope": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
@@ -168,28 +168,38 @@ def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_kv_splits(batch_heads: int, lq: int, lk: int, n_cu: int = 256) -> int:
-    """Key splits for flexam_attn_fwd_splitkv: with W = batch_heads * ceil(lq/256) workgroups of ceil(lk/64) key tiles each, the
-    launch takes ceil(W*S/n_cu) rounds of 1/S of that work.  S = 1 unless a split saves more than 8 % (the merge pass and the
-    fp32 partial outputs are not free) and every split keeps at least 8 key tiles."""
+def attn_split_plan(batch_heads: int, lq: int, lk: int, n_cu: int = 256):
+    """(kv_splits, split_from_unit) for flexam_attn_fwd_splitkv.  W = batch_heads * ceil(lq/256) work units of ceil(lk/64) key
+    tiles; the launch takes ceil(W/n_cu) rounds.  Cutting only the units of the last, partial round into S key ranges turns
+    that round into ceil(rem*S/n_cu)/S of a round (+ 4 % per pass for the partial outputs and the merge); S is kept only if the
+    whole launch gets more than 2 % shorter and every range keeps at least 8 key tiles."""
     w = batch_heads * ((lq + 255) // 256)
     tiles = (lk + 63) // 64
-    best, best_cost = 1, float(-(-w // n_cu))
-    for s in (2, 3, 4, 6, 8):
+    full, rem = (w // n_cu) * n_cu, w % n_cu
+    if rem == 0:
+        return 1, w
+    best, best_cost = 1, float(w // n_cu + 1)
+    for s in (2, 3, 4, 5, 6, 8):
         if tiles // s < 8:
             break
-        cost = -(-w * s // n_cu) / s
-        if cost < best_cost * 0.92:
+        passes = -(-rem * s // n_cu)
+        cost = w // n_cu + passes * (1.0 / s + 0.04)
+        if cost < best_cost * 0.98:
             best, best_cost = s, cost
-    return best
+    return (best, full) if best > 1 else (1, w)
+
+
+def attn_kv_splits(batch_heads: int, lq: int, lk: int, n_cu: int = 256) -> int:
+    return attn_split_plan(batch_heads, lq, lk, n_cu)[0]
 
 
 _ATTN_WS = {}
 
 
-def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None):
+def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_unit=None):
     """q [B,Lq,H,128], k/v [B,Lk,H,128] bf16 (arbitrary batch/row strides, head dim contiguous and
-    heads packed: stride(2) == 128) -> out [B,Lq,H,128] bf16.  kv_splits None: chosen by attn_kv_splits."""
+    heads packed: stride(2) == 128) -> out [B,Lq,H,128] bf16.  kv_splits None: plan from attn_split_plan (only the last,
+    partial round of the CUs is split); an explicit kv_splits splits every unit unless split_from_unit is given too."""
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
     for t in (q, k, v):
@@ -198,20 +208,26 @@ def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None):
     if out is None:
         out = torch.empty(B, Lq, H, D, device=q.device, dtype=BF16)
     scale = softmax_scale if softmax_scale is not None else D ** -0.5
-    S = attn_kv_splits(B * H, Lq, Lk) if kv_splits is None else int(kv_splits)
+    units = B * H * ((Lq + 255) // 256)
+    if kv_splits is None:
+        S, from_unit = attn_split_plan(B * H, Lq, Lk)
+    else:
+        S, from_unit = int(kv_splits), (0 if split_from_unit is None else int(split_from_unit))
     if S <= 1:
         _check(lib().flexam_attn_fwd(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1),
                                      _ptr(v, BF16), v.stride(0), v.stride(1), _ptr(out, BF16), out.stride(0), out.stride(1),
                                      B, H, Lq, Lk, D, scale, _stream()), "flexam_attn_fwd")
         return out
-    key = (q.device, S, B, Lq, H)
+    n = units - from_unit
+    key = (q.device, S, n)
     if key not in _ATTN_WS:                     # per-shape scratch, reused across launches (stream-ordered)
         _ATTN_WS.clear()
-        _ATTN_WS[key] = (torch.empty(S, B, Lq, H, D, device=q.device, dtype=F32), torch.empty(S, B, Lq, H, 2, device=q.device, dtype=F32))
+        _ATTN_WS[key] = (torch.empty(S, n, 256, D, device=q.device, dtype=F32), torch.empty(S, n, 256, 2, device=q.device, dtype=F32))
     ws_o, ws_ml = _ATTN_WS[key]
     _check(lib().flexam_attn_fwd_splitkv(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1),
                                          _ptr(v, BF16), v.stride(0), v.stride(1), _ptr(out, BF16), out.stride(0), out.stride(1),
-                                         B, H, Lq, Lk, D, scale, S, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()), "flexam_attn_fwd_splitkv")
+                                         B, H, Lq, Lk, D, scale, S, from_unit, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()),
+           "flexam_attn_fwd_splitkv")
     return out
 
 

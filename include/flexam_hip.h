@@ -72,12 +72,15 @@ int flexam_gemm_set_workspace(void* ws, int64_t bytes);
 int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                     int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk,
                     int head_dim, float softmax_scale, void* stream);
-/* Same, with the keys cut into kv_splits ranges (flash-decoding style) so that B*H*ceil(Lq/256)*kv_splits workgroups fill the
- * 256 CUs when a rank holds few query rows (sequence-parallel runs).  ws_o: fp32 [kv_splits, B, Lq, H, 128] and
- * ws_ml: fp32 [kv_splits, B, Lq, H, 2] scratch; a second launch merges the partial softmaxes.  kv_splits = 1 == flexam_attn_fwd. */
+/* Same, with the work units u = (batch*H + head)*ceil(Lq/256) + q_block at and after `split_from_unit` cut into kv_splits key
+ * ranges each (flash-decoding style partial softmaxes + a merge launch), the units before it in one pass: with
+ * split_from_unit = floor(units/256)*256 only the last, partial round of the 256 CUs is split; 0 splits everything (ranks of a
+ * sequence-parallel run hold few query rows).  ws_o: fp32 [kv_splits, n, 256, 128], ws_ml: fp32 [kv_splits, n, 256, 2] scratch
+ * with n = units - split_from_unit.  kv_splits = 1 == flexam_attn_fwd. */
 int flexam_attn_fwd_splitkv(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                             int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk,
-                            int head_dim, float softmax_scale, int kv_splits, float* ws_o, float* ws_ml, void* stream);
+                            int head_dim, float softmax_scale, int kv_splits, int split_from_unit, float* ws_o, float* ws_ml,
+                            void* stream);
 
 /* out_bf16[m,:] = LN(x_f32[m,:]; eps) [* ln_w + ln_b] [* scale[row(m),:] + shift[row(m),:]]
  * row(m) = row_index[m] if row_index else m / rows_per_batch; scale rows already hold (1+scale),

@@ -204,12 +204,27 @@ def test_attention_split_kv_matches_oracle(H, splits, b, h, lq, lk):
     assert_bf16_close(out, one.float().cpu(), ulps=2.0, atol=4e-3, msg="split vs single pass")
 
 
-def test_attention_split_heuristic():
-    f = __import__("flexam_amd.hip", fromlist=["attn_kv_splits"]).attn_kv_splits
-    assert f(48, 11648, 11648) == 1            # one GPU: 2208 workgroups, 8.6 rounds
-    assert f(24, 11648, 11648) == 2            # CFG-parallel pair: 1104 workgroups
-    assert f(24, 2912, 11648) >= 4             # 8 GPUs: 288 workgroups for 256 CUs
-    assert f(48, 11648, 512) == 1              # text cross-attention: 8 key tiles, never split
+def test_attention_tail_split_matches_single_pass(H):
+    """Only the work units of the last, partial round are split: units before `split_from_unit` take the one-pass kernel."""
+    g = torch.Generator().manual_seed(77)
+    b, h, lq, lk = 2, 3, 700, 1300                       # 2 * 3 * 3 = 18 units
+    q = bf(torch.randn(b, lq, h, 128, generator=g))
+    k = bf(torch.randn(b, lk, h, 128, generator=g))
+    v = bf(torch.randn(b, lk, h, 128, generator=g))
+    ref = _attn_ref(q, k, v)
+    for from_unit in (0, 5, 17):
+        out = H.attn_fwd(q.to(dev()), k.to(dev()), v.to(dev()), kv_splits=2, split_from_unit=from_unit)
+        assert_bf16_close(out, ref, ulps=2.0, atol=6e-3, msg=f"tail split from unit {from_unit}")
+
+
+def test_attention_split_plan():
+    f = __import__("flexam_amd.hip", fromlist=["attn_split_plan"]).attn_split_plan
+    assert f(48, 11648, 11648) == (3, 2048)    # one GPU: 2208 units = 8 full rounds + 160 units cut in 3
+    assert f(24, 11648, 11648) == (3, 1024)    # CFG-parallel pair: 1104 units
+    s8, from8 = f(24, 2912, 11648)
+    assert s8 >= 4 and from8 == 256            # 8 GPUs: 288 units for 256 CUs
+    assert f(48, 11648, 512) == (1, 2208)      # text cross-attention: 8 key tiles, never split
+    assert f(16, 4096, 4096) == (1, 256)       # exactly one full round: nothing to split
 
 
 def test_attention_strided_qkv_and_scale(H):

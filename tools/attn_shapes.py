@@ -14,14 +14,16 @@ for n, (b, lq) in {1: (2, L), 2: (1, L), 4: (1, L // 2), 8: (1, L // 4)}.items()
     o = torch.empty(b, lq, 24, 128, dtype=BF, device=dev)
     fl = 4.0 * b * 24 * lq * L * 128
     line = f"N={n}: B={b} Lq={lq:5d}"
-    for s in sorted({1, H.attn_kv_splits(b * 24, lq, L)}):
+    plan = H.attn_split_plan(b * 24, lq, L)
+    for label, kw in (("one pass", dict(kv_splits=1)), (f"plan S={plan[0]} from unit {plan[1]}", dict()),
+                      (f"all units S={plan[0]}", dict(kv_splits=plan[0]))):
         for _ in range(2):
-            H.attn_fwd(q, k, v, out=o, kv_splits=s)
+            H.attn_fwd(q, k, v, out=o, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
-            H.attn_fwd(q, k, v, out=o, kv_splits=s)
+            H.attn_fwd(q, k, v, out=o, **kw)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
-        line += f" | S={s}: {dt * 1e3:6.3f} ms {fl / dt / 1e12:7.1f} TF/s"
+        line += f" | {label}: {dt * 1e3:6.3f} ms {fl / dt / 1e12:6.1f} TF/s"
     print(line, flush=True)
