@@ -37,14 +37,20 @@ def sinusoidal_embedding_1d(dim: int, position: Tensor) -> Tensor:
     return torch.cat([ang.cos(), ang.sin()], dim=1)
 
 
-def rope_angles(max_len: int, head_dim: int, theta: float = 10000.0) -> Tensor:
+def rope_angles(max_len: int, head_dim: int, theta: float = 10000.0, riflex=None) -> Tensor:
     """Angle table [max_len, head_dim/2] fp64.  FX.py:45-52 builds exp(i*angle) per axis and
     FX.py:655-665 concatenates the three axes with widths d-4*(d//6), 2*(d//6), 2*(d//6)
-    (in *real* dims; pairs = half of that: 22/21/21 for d=128)."""
+    (in *real* dims; pairs = half of that: 22/21/21 for d=128).  riflex = (k, L_test, L_test_scale): the temporal
+    axis' k-th frequency becomes 0.9 * 2 pi / L_test / L_test_scale (enable_riflex, FX.py:57-113, 774-788)."""
     d = head_dim
     parts = []
-    for axis_dim in (d - 4 * (d // 6), 2 * (d // 6), 2 * (d // 6)):
+    for ax, axis_dim in enumerate((d - 4 * (d // 6), 2 * (d // 6), 2 * (d // 6))):
         inv = 1.0 / torch.pow(theta, torch.arange(0, axis_dim, 2, dtype=torch.float64) / axis_dim)
+        if ax == 0 and riflex is not None:
+            k, l_test, scale = riflex
+            inv[k - 1] = 0.9 * 2 * torch.pi / l_test
+            if scale is not None:
+                inv[k - 1] = inv[k - 1] / scale
         parts.append(torch.outer(torch.arange(max_len, dtype=torch.float64), inv))
     return torch.cat(parts, dim=1)
 
@@ -219,7 +225,7 @@ def _teacache_decide(tc: dict, e0: Tensor) -> bool:
 def dit_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, context: List[Tensor], seq_len: int,
                 y: Optional[Tensor] = None, full_ref: Optional[Tensor] = None,
                 additional_control: Optional[Tensor] = None, density: Optional[Tensor] = None,
-                taps: Optional[dict] = None, teacache: Optional[dict] = None) -> Tensor:
+                taps: Optional[dict] = None, teacache: Optional[dict] = None, riflex=None) -> Tensor:
     """WanTransformer3DModel_FlexAM.forward, FX.py:817-1123 (inference, sp=1, no TeaCache, no
     camera adapter, no subject_ref, clip_fea=None -- the FlexAM 5B call contract).
 
@@ -251,7 +257,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, context:
     e, e0 = time_embed(sd, cfg, t)
     dens, dens0 = density_embed(sd, cfg, density)
     ctx = text_embed(sd, cfg, context)
-    angles = rope_angles(1024, dim // nh)
+    angles = rope_angles(1024, dim // nh, riflex=riflex)
     if taps is not None:
         taps.update(x_embed=x.clone(), e=e, e0=e0, dens0=dens0, context=ctx)
     calc = True if teacache is None else _teacache_decide(teacache, e0)

@@ -185,11 +185,17 @@ def main():
                                          in_sum=C.checksum(dict(x=x, **{f"v{i}": v for i, v in enumerate(vs)}))))
 
     # ---- G11: RIFLEx rope table (enable_riflex defaults k=6, L_test=66, L_test_scale=4.886; FX.py:57-113, 774-788)
-    tiny = _ref_dit(ref, dict(O.DIT_TINY), C.dit_weights(dict(O.DIT_TINY), 1))
+    tiny = _ref_dit(ref, dict(O.DIT_TINY), C.dit_weights(dict(O.DIT_TINY), 7))
     tiny.enable_riflex()
     riflex = torch.angle(tiny.freqs.to(torch.complex128)) if tiny.freqs.is_complex() else tiny.freqs.double()
     tiny.disable_riflex()
     base = torch.angle(tiny.freqs.to(torch.complex128))
+    tiny.enable_riflex(k=2, L_test=3, L_test_scale=1.0)           # a setting that visibly moves a 3-frame clip
+    rcase = C.dit_case(dict(O.DIT_TINY), 41)
+    with torch.no_grad():
+        rout = tiny(**rcase)
+    tiny.disable_riflex()
+    _save("g11b_dit_riflex", dict(out=rout))
     _save("g11_riflex", dict(cis_real=tiny.freqs.real.float()[:64].contiguous(), riflex_cos=torch.cos(riflex).float().contiguous(),
                              riflex_sin=torch.sin(riflex).float().contiguous(), base_cos=torch.cos(base).float().contiguous()))
 

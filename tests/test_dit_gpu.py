@@ -47,6 +47,17 @@ def test_dit_matches_reference_golden(golden, name, per_tok, h, w):
     check(out, golden(name)["out"], name)
 
 
+def test_dit_with_riflex_matches_reference_golden(golden):
+    """enable_riflex (FX.py:774-788) changes one temporal rope frequency; golden G11b is the REFERENCE model's output with it on."""
+    cfg = dict(O.DIT_TINY)
+    m, _ = build(cfg, 7)
+    case = to_dev(C.dit_case(cfg, 41))
+    m.enable_riflex(k=2, L_test=3, L_test_scale=1.0)
+    check(m(**case), golden("g11b_dit_riflex")["out"], "g11b riflex")
+    m.disable_riflex()
+    check(m(**case), golden("g4_dit_tokent")["out"], "g4 after disable_riflex")
+
+
 def test_dit_matches_oracle_other_shape_batch1_and_bf16_weights():
     cfg = dict(O.DIT_TINY, num_layers=3)
     m, sd = build(cfg, 19)

@@ -188,3 +188,12 @@ def test_g12_t5_encoder(golden):
     assert torch.equal(ids.float(), fx["ids"]) and torch.equal(mask.float(), fx["mask"])
     out = OT.t5_encode(sd, cfg, ids, mask)
     torch.testing.assert_close(out, fx["out"], rtol=1e-5, atol=1e-5)
+
+
+def test_g11b_dit_with_riflex(golden):
+    cfg = dict(O.DIT_TINY)
+    sd = C.dit_weights(cfg, 7)
+    case = C.dit_case(cfg, 41)
+    out = O.dit_forward(sd, cfg, riflex=(2, 3, 1.0), **case)
+    torch.testing.assert_close(out, golden("g11b_dit_riflex")["out"], **TOL)
+    assert not torch.allclose(out, golden("g4_dit_tokent")["out"], atol=1e-3)          # the switch does change the output
