@@ -93,14 +93,21 @@ def kernel_rooflines(eng, B, L, lc):
     M = B * lc
     q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hd))
     out = {}
-    if eng.sp_size == 1:
-        k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hd))
-        v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hd))
+    if eng.sp_size > 1 and eng.sp_mode == "ulysses":
+        # this rank's attention: all L tokens of nh / sp heads (the q|k|v it received in the last block's all-to-all)
+        hg = nh // eng.sp_size
+        full = ws["a2a_recv"].view(1, L, 3, hg, hd) if B == 1 else ws["a2a_full"]
+        t = time_kernel(lambda: hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"]), iters=8)
+        out["attn_self"] = dict(flops=4.0 * B * L * L * hg * hd, sec=t)
     else:
-        kv = ws["kv_cat"]                      # gathered K|V of the last block (same shape as every block's)
-        k4, v4 = kv[:, :, 0:d].unflatten(2, (nh, hd)), kv[:, :, d:].unflatten(2, (nh, hd))
-    t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd)), iters=8)
-    out["attn_self"] = dict(flops=4.0 * B * lc * L * d, sec=t)
+        if eng.sp_size == 1:
+            k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hd))
+            v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hd))
+        else:
+            kv = ws["kv_cat"]                  # gathered K|V of the last block (same shape as every block's)
+            k4, v4 = kv[:, :, 0:d].unflatten(2, (nh, hd)), kv[:, :, d:].unflatten(2, (nh, hd))
+        t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd)), iters=8)
+        out["attn_self"] = dict(flops=4.0 * B * lc * L * d, sec=t)
     t = time_kernel(lambda: hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv))
     out["gemm_qkv"] = dict(flops=2.0 * M * 3 * d * d, sec=t)
     t = time_kernel(lambda: hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH))
@@ -261,7 +268,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(L, cfg)
 
-    eng_cfg, eng_sp = eng.cfg_size, eng.sp_size
+    eng_cfg, eng_sp, eng_mode = eng.cfg_size, eng.sp_size, getattr(eng, "sp_mode", "-")
     vae_sec = enc_sec = enc_stream_sec = None
     if rank == 0 and world == 1 and not args.no_vae:
         del pipe, model, eng
@@ -282,7 +289,7 @@ def main():
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
                                    f"random-init bf16 weights, synthetic conditioning (BASELINE configs[1])",
                        "parallelism": (f"cfg{eng_cfg} x sp{eng_sp}: CFG rows split first (no per-block traffic), then token-chunk sequence "
-                                       f"parallel with one RCCL K/V all-gather per block") if world > 1 else "single GPU",
+                                       f"parallel, {eng_mode} exchange around self-attention (RCCL)") if world > 1 else "single GPU",
                        "layers": cfg["num_layers"]},
             "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
             "vae_decode_sec": vae_sec, "vae_encode_sec_per_stream": enc_stream_sec, "conditioning_encode_sec_8_streams": enc_sec,

@@ -4,10 +4,14 @@ wan_transformer3d_FlexAM.py:22-24, 801-815, 919-920, 970-975, 1103-1104).
 
 Design: one process per GPU, contiguous token chunks per rank (L/N tokens; attention is
 full 3-D so chunks need not be frame aligned, RoPE rows are looked up by the *global* token index),
-weights replicated, every op token-local except self-attention, which needs all keys/values:
-one RCCL all-gather of the block's post-norm, post-RoPE K|V per block ([B, L/N, 2C] bf16 per rank --
-17.9 MB at N = 8), plus one all-gather of the head output per step.  On the xGMI full mesh an
-all-gather maps 1:1 onto the point-to-point links (each peer pushes its shard over its own link).
+weights replicated, every op token-local except self-attention, which needs all keys/values.  Two
+exchange schemes per block (DiTEngine.sp_mode):
+  * "ulysses" (default when the heads divide over the ranks): all-to-all of the post-norm, post-RoPE q|k|v
+    so that every rank holds ALL tokens of H/N heads, attention, all-to-all of the output back to token
+    chunks -- (N-1)/N of 4 C elements per token leave a rank, each peer link carries 1/N of it;
+  * "allgather": one all-gather of K|V ([B, L/N, 2C] bf16 per rank), attention of the local queries against
+    all keys -- (N-1) x 2 C elements per token arrive, i.e. N/2 times the all-to-all volume.
+Plus one all-gather of the head output per step.
 
 These helpers are backend-agnostic torch.distributed code (RCCL on GPUs; the CPU tests run them
 under gloo with world_size 2)."""
@@ -62,6 +66,20 @@ class SeqGather:
         out = self.out if self.out is not None else torch.empty(b, self.world * lc, x, device=self.scratch.device, dtype=self.scratch.dtype)
         out.view(b, self.world, lc, x).copy_(self.scratch.view(self.world, b, lc, x).transpose(0, 1))
         return out
+
+
+def all_to_all_chunks(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """inp [N, ...] (chunk j goes to rank j) -> out [N, ...] (chunk i came from rank i), both contiguous.  RCCL: one
+    all_to_all_single (pairwise sends over the xGMI mesh).  Other backends (the gloo test runs) may lack all-to-all on device
+    tensors: the same result is assembled from an all-gather of every rank's send buffer."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        return dist.all_to_all_single(out, inp, group=group, async_op=async_op)
+    rank = dist.get_rank(group)
+    everything = torch.empty((world,) + tuple(inp.shape), device=inp.device, dtype=inp.dtype)
+    dist.all_gather_into_tensor(everything.view(world * inp.shape[0], *inp.shape[1:]), inp.contiguous(), group=group)
+    out.copy_(everything[:, rank])
+    return None
 
 
 def shard_rows(full: torch.Tensor, batch: int, seq_len: int, rank: int, world: int) -> torch.Tensor:

@@ -19,6 +19,7 @@ token through an int32 row index instead of the reference's materialised [B, L, 
 All arithmetic runs in libflexam_hip.so (flexam_amd/hip.py); torch only allocates and slices.
 """
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -148,6 +149,10 @@ class DiTEngine:
         """Parallel layout of this rank: token chunk `sp_rank` of `sp_size` inside `sp_group`; with cfg_size = 2 the
         world is two such groups, one per CFG row (world rank = cfg_row * sp_size + sp_rank)."""
         self.sp_group, self.sp_rank, self.sp_size = sp_group, sp_rank, sp_size
+        mode = os.environ.get("FLEXAM_SP_MODE", "ulysses")
+        if mode not in ("ulysses", "allgather"):
+            raise ValueError(f"FLEXAM_SP_MODE={mode!r}: expected 'ulysses' or 'allgather'")
+        self.sp_mode = mode if (mode == "allgather" or self.nh % max(sp_size, 1) == 0) else "allgather"
         self.world_group = world_group if cfg_size > 1 else sp_group
         self.world_size = world_size if world_size is not None else sp_size
         self.cfg_size, self.cfg_row = cfg_size, cfg_row
@@ -340,7 +345,13 @@ class DiTEngine:
         for i, p in enumerate(self.blocks if calc else ()):
             T = tab[i]
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
-            if sp > 1:
+            if sp > 1 and self.sp_mode == "ulysses":
+                # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back (flexam_amd/dist.py)
+                hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
+                hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                                 tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
+                self._ulysses_attention(qkv, ao, B, lc)
+            elif sp > 1:
                 # K|V projection + K norm/RoPE first, all-gather them asynchronously (RCCL over xGMI) and run the
                 # Q projection + Q norm/RoPE underneath the collective
                 hip.gemm(hbuf, p["wqkv"][d:], p["bqkv"][d:], out=qkv[:, d:])
@@ -407,6 +418,36 @@ class DiTEngine:
         return calc
 
     # ------------------------------------------------------------------ sequence parallel
+    def _ulysses_attention(self, qkv, ao, B, lc):
+        """qkv [B*lc, 3C] (this rank's tokens, all heads) -> ao [B*lc, C].  Head group j = heads j*H/sp .. goes to rank j."""
+        from .dist import all_to_all_chunks
+        sp, nh, hd, d = self.sp_size, self.nh, self.hd, self.dim
+        hg = nh // sp
+        ws = self._ws[(B, lc)]
+        if "a2a_send" not in ws:
+            dev = self.device
+            ws["a2a_send"] = torch.empty(sp, B, lc, 3, hg * hd, device=dev, dtype=BF16)
+            ws["a2a_recv"] = torch.empty(sp, B, lc, 3, hg * hd, device=dev, dtype=BF16)
+            ws["a2a_full"] = torch.empty(B, sp * lc, 3, hg, hd, device=dev, dtype=BF16) if B > 1 else None
+            ws["a2a_out"] = torch.empty(B, sp * lc, hg, hd, device=dev, dtype=BF16)
+            ws["a2a_send2"] = torch.empty(sp, B, lc, hg * hd, device=dev, dtype=BF16)
+            ws["a2a_recv2"] = torch.empty(sp, B, lc, hg * hd, device=dev, dtype=BF16)
+        ws["a2a_send"].copy_(qkv.view(B, lc, 3, sp, hg * hd).permute(3, 0, 1, 2, 4))          # pack by destination (re-layout)
+        all_to_all_chunks(ws["a2a_recv"], ws["a2a_send"], self.sp_group)
+        if B == 1:
+            full = ws["a2a_recv"].view(1, sp * lc, 3, hg, hd)                                   # rank-major chunks ARE the token order
+        else:
+            full = ws["a2a_full"]
+            full.view(B, sp, lc, 3, hg * hd).copy_(ws["a2a_recv"].permute(1, 0, 2, 3, 4))
+        hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"])
+        if B == 1:
+            send2 = ws["a2a_out"].view(sp, 1, lc, hg * hd)
+        else:
+            send2 = ws["a2a_send2"]
+            send2.copy_(ws["a2a_out"].view(B, sp, lc, hg * hd).permute(1, 0, 2, 3))
+        all_to_all_chunks(ws["a2a_recv2"], send2, self.sp_group)
+        ao.view(B, lc, sp, hg * hd).copy_(ws["a2a_recv2"].permute(1, 2, 0, 3))                 # head group j -> columns j*hg*hd ..
+
     def _gather_kv_start(self, qkv, B, lc):
         """Starts the all-gather of this block's post-norm, post-RoPE K|V over the sequence-parallel group (RCCL over
         xGMI, flexam_amd/dist.py); .finish() returns [B, L, 2C] with heads packed along the row."""

@@ -44,10 +44,13 @@ def _worker(rank, world, port, ret, cfg_parallel):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cfg_parallel", [(2, False), (2, True), (4, True)])
-def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel):
-    """(2, False): pure sequence parallel; (2, True): CFG-parallel, no per-block traffic; (4, True): 2 CFG rows x 2
-    token chunks -- the layout bench.py uses at 4 and 8 GPUs."""
+@pytest.mark.parametrize("world,cfg_parallel,mode", [(2, False, "ulysses"), (2, False, "allgather"), (2, True, "ulysses"),
+                                                     (4, True, "ulysses"), (4, True, "allgather")])
+def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel, mode, monkeypatch):
+    """(2, False): pure sequence parallel (CFG pair batched, B = 2 per rank); (2, True): CFG-parallel, no per-block traffic;
+    (4, True): 2 CFG rows x 2 token chunks -- the layout bench.py uses at 4 and 8 GPUs.  mode: the exchange around
+    self-attention -- "ulysses" (all-to-all over heads, the default) or "allgather" (K|V all-gather)."""
+    monkeypatch.setenv("FLEXAM_SP_MODE", mode)             # inherited by the spawned ranks
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -66,7 +69,7 @@ def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel):
         torch.testing.assert_close(lat0, ret[r][1], rtol=0, atol=0)
     want = golden("g4_dit_tokent")["out"]
     p = C.psnr(out0, want)
-    print(f"world={world} cfg_parallel={cfg_parallel}: DiT vs reference golden psnr {p:.1f} dB")
+    print(f"world={world} cfg_parallel={cfg_parallel} {mode}: DiT vs reference golden psnr {p:.1f} dB")
     assert p >= 40.0
     # single-process HIP result for the same inputs
     from flexam_amd import Wan2_2Transformer3DModel_FlexAM
