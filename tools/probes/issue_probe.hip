@@ -85,7 +85,7 @@ void run_(const char* name, const char* src, uint64_t* out, float* sink) {
 template <int KIND, int STG, int NREAD, int NW>
 __global__ __launch_bounds__(NW * 64) void mix(const char* __restrict__ src, uint64_t* __restrict__ out, float* sink, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.01f * ((lane * 7 + i) % 13)); b[i] = (__bf16)(0.02f * ((lane * 5 + i) % 11)); }
   f32x4 acc[8];
@@ -94,6 +94,16 @@ __global__ __launch_bounds__(NW * 64) void mix(const char* __restrict__ src, uin
   const uint32_t lds_lane = wave * 1024 + lane * 16;
   i32x4 st[2] = {{1, 2, 3, 4}, {5, 6, 7, 8}};
   i32x4 rd = {0, 0, 0, 0};
+  // raw buffer resource over `src`: base, stride 0, num_records = max, gfx9-family dword 3
+  i32x4 srd;
+  srd[0] = (int)(uintptr_t)src;
+  srd[1] = (int)((uintptr_t)src >> 32) & 0xFFFF;
+  srd[2] = -1;
+  srd[3] = 0x00020000;
+  srd[0] = __builtin_amdgcn_readfirstlane(srd[0]);
+  srd[1] = __builtin_amdgcn_readfirstlane(srd[1]);
+  srd[2] = __builtin_amdgcn_readfirstlane(srd[2]);
+  srd[3] = __builtin_amdgcn_readfirstlane(srd[3]);
   __syncthreads();
   const uint64_t t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < iters; ++it) {
@@ -108,6 +118,15 @@ __global__ __launch_bounds__(NW * 64) void mix(const char* __restrict__ src, uin
         if constexpr (KIND == 0) {
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + e * 65536),
                                            (__attribute__((address_space(3))) void*)(smem + lp + wave * 1024 + e * 1024 * NW), 16, 0, 0);
+        } else if constexpr (KIND == 2) {          // scalar base + 32-bit VGPR offset, M0 saved / set / restored (gemm.hip, attn.hip)
+          unsigned keep;
+          const char* sb = src + (size_t)blockIdx.x * 262144 + (it & 15) * 8192 + e * 65536;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"((unsigned)(threadIdx.x * 16)), "s"(sb), "s"(lp + wave * 1024 + e * 1024 * NW) : "memory");
+        } else if constexpr (KIND == 3) {          // buffer form: constant voffset, scalar offset per piece, M0 set without save/restore
+          asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                       :: "v"((unsigned)(threadIdx.x * 16)), "s"(srd), "s"((unsigned)(blockIdx.x * 262144 + (it & 15) * 8192 + e * 65536)),
+                          "s"(lp + wave * 1024 + e * 1024 * NW) : "memory");
         } else {
           asm volatile("ds_write_b128 %0, %1" ::"v"(lds_lane + lp + e * 1024 * NW), "v"(st[e & 1]) : "memory");
           asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(st[e & 1]) : "v"(gp + e * 65536) : "memory");
@@ -167,12 +186,16 @@ int main() {
   run_mix<0, 0, 0, 4>("MFMA only", src, out, sink);
   run_mix<0, 0, 2, 4>("reads only", src, out, sink);
   run_mix<0, 1, 2, 4>("LDS-DMA", src, out, sink);
+  run_mix<2, 1, 2, 4>("LDS-DMA asm global form + M0 swap", src, out, sink);
+  run_mix<3, 1, 2, 4>("LDS-DMA asm buffer form", src, out, sink);
   run_mix<1, 1, 2, 4>("global_load + ds_write_b128", src, out, sink);
   run_mix<0, 2, 2, 4>("LDS-DMA", src, out, sink);
   run_mix<1, 2, 2, 4>("global_load + ds_write_b128", src, out, sink);
   run_mix<0, 0, 0, 8>("MFMA only", src, out, sink);
   run_mix<0, 0, 3, 8>("reads only", src, out, sink);
   run_mix<0, 1, 3, 8>("LDS-DMA", src, out, sink);
+  run_mix<2, 1, 3, 8>("LDS-DMA asm global form + M0 swap", src, out, sink);
+  run_mix<3, 1, 3, 8>("LDS-DMA asm buffer form", src, out, sink);
   run_mix<1, 1, 3, 8>("global_load + ds_write_b128", src, out, sink);
   run_mix<0, 2, 3, 8>("LDS-DMA", src, out, sink);
   run_mix<1, 2, 3, 8>("global_load + ds_write_b128", src, out, sink);
