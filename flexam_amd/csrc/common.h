@@ -37,13 +37,12 @@ __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-  // torch.nn.GELU(approximate='tanh'): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  // tanh(u) = 1 - 2 / (exp(2u) + 1); exp via exp2
-  float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);
-  float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  // torch.nn.GELU(approximate='tanh'): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).  With
+  // 0.5 (1 + tanh(u)) = 1 / (1 + exp(-2u)) this is x / (1 + exp2(x (a + b x^2))), a = -2 log2(e) sqrt(2/pi), b = 0.044715 a:
+  // 5 plain VALU operations and 2 transcendentals per element (exp2 -> inf gives x * 0 for very negative x, -> 0 gives x).
+  const float a = -2.302208198f, b = -0.1029432396f;
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(b, x * x, a));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 __device__ __forceinline__ float silu(float x) {

@@ -360,6 +360,49 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       continue;                                        // next tile of this persistent workgroup
     }
   }
+  if constexpr (EPI != EPI_GATE_RESIDUAL && sizeof(OutT) == 2) {
+    // Interior tiles, bf16 output: the MFMA layout gives a lane 4 columns of 16 different rows, i.e. 16 x 32-byte pieces per
+    // store instruction.  The wave turns its 16*MT x 64 outputs around in LDS instead (64 rows = 8 KiB at a time in its own
+    // slice of buffer 1, idle until the next unit's second K block; 16-byte chunks XOR-swizzled by row so that both the
+    // 8-byte writes and the 16-byte reads are conflict-free) and stores whole 128-byte rows, 8 per instruction.
+    if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // nobody still reads fragments of the last K block out of buffer 1
+      char* stg = smem + 2 * TILE_BYTES + wave * 8192;
+      const int wr_row = lane & 15, wr_q = lane >> 4;
+      const int rd_row = lane >> 3, rd_c = lane & 7;
+      bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
+#pragma unroll
+      for (int c0 = 0; c0 < MT; c0 += 4) {
+        const int nmt = MT - c0 < 4 ? MT - c0 : 4;     // compile-time after unrolling
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (u >= nmt) continue;
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            f32x4 v = acc[c0 + u][nt] + bias[nt];
+            if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+            const int row = u * 16 + wr_row;
+            *(bf16x4*)(stg + row * 128 + (((2 * nt + (wr_q >> 1)) ^ (row & 7)) << 4) + (wr_q & 1) * 8) = o;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i >= 2 * nmt) continue;
+          const int row = 8 * i + rd_row;
+          const bf16x8 o8 = *(const bf16x8*)(stg + row * 128 + ((rd_c ^ (row & 7)) << 4));
+          *(bf16x8*)(crow + (int64_t)(c0 * 16 + 8 * i) * p.ldc) = o8;
+        }
+      }
+      continue;                                        // next tile of this persistent workgroup
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mrow + mt * 16;

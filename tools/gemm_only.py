@@ -12,6 +12,10 @@ if what == "gemm":
     b = torch.randn(f, device=dev); out = torch.empty(M, f, dtype=BF, device=dev)
     for _ in range(5):
         H.gemm(a, w, b, out=out, epilogue=1)
+elif what == "vendor":                      # hipBLASLt on the same FFN1 shape (context for the counters)
+    a = (torch.randn(M, d, generator=g) * 0.5).to(BF).to(dev); w = (torch.randn(f, d, generator=g) * 0.5).to(BF).to(dev)
+    for _ in range(5):
+        out = torch.nn.functional.linear(a, w)
 elif what == "ffn2":
     a = (torch.randn(M, f, generator=g) * 0.5).to(BF).to(dev); w = (torch.randn(d, f, generator=g) * 0.5).to(BF).to(dev)
     b = torch.randn(d, device=dev); out = torch.empty(M, d, dtype=BF, device=dev)
