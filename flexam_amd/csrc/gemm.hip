@@ -278,21 +278,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   if (ns > 1) {
     constexpr int SLAB = 256 * BN;                     // floats per slab; 16-byte element of (mt, nt) at ((mt*4+nt)*512 + tid)*4
     typedef unsigned long long u64;
+    int te = tid;                                      // opaque copy (see `le` below): slab addresses stay out of the K loop's registers
+    asm volatile("" : "+v"(te));
     const int tr = tile - p.split_full;
     float* slab = p.ws + ((int64_t)tr * ns + slice) * SLAB;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)          // 16-byte sc1 stores cost what plain ones do; 8-byte ones are one fabric write each
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slab + ((mt * NTW + nt) * 512 + tid) * 4), "v"(acc[mt][nt]) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slab + ((mt * NTW + nt) * 512 + te) * 4), "v"(acc[mt][nt]) : "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) arrive_flag = __hip_atomic_fetch_add(p.counters + tr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (te == 0) arrive_flag = __hip_atomic_fetch_add(p.counters + tr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const bool last = arrive_flag == ns - 1;
     __syncthreads();                                   // arrive_flag is rewritten by the next split unit
     if (!last) continue;
-    if (tid == 0) __hip_atomic_store(p.counters + tr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (te == 0) __hip_atomic_store(p.counters + tr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     const u64* base = (const u64*)(p.ws + (int64_t)tr * ns * SLAB);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const int e = ((mt * NTW + nt) * 512 + tid) * 2 + hf;
+          const int e = ((mt * NTW + nt) * 512 + te) * 2 + hf;
           f32x2 sum = __builtin_bit_cast(f32x2, __hip_atomic_load(base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           for (int s2 = 1; s2 < ns; ++s2)
             sum += __builtin_bit_cast(f32x2, __hip_atomic_load(base + (int64_t)s2 * (SLAB / 2) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -310,8 +312,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   }
 
   // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
-  const int mrow = m0 + wm * (16 * MT) + (lane & 15);
-  const int ncol = n0 + wn * (16 * NTW) + (lane >> 4) * 4;
+  int le = lane;                     // opaque copy of the lane id: the epilogue's per-lane address arithmetic must not be hoisted
+  asm volatile("" : "+v"(le));       // out of the tile loop, where it would hold registers across the K loop (spills into it)
+  const int mrow = m0 + wm * (16 * MT) + (le & 15);
+  const int ncol = n0 + wn * (16 * NTW) + (le >> 4) * 4;
   f32x4 bias[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
@@ -319,44 +323,76 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     bias[nt] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   if constexpr (EPI == EPI_GATE_RESIDUAL) {
-    // Interior tiles (all but the last tile row / column): the fp32 read-modify-write of X is latency-bound unless many
-    // loads are in flight, and the general path below waits for every 16-byte load on its own (bounds branches keep the
-    // compiler from batching them).  Here the X and gate loads of two m-tiles (16 x 16 B per lane) are issued together.
+    // Interior tiles (all but the last tile row / column): in the MFMA layout a lane's 16 bytes of X sit in 16 different rows
+    // per instruction (64-byte pieces).  The wave parks y (rounded to bf16, as the reference's Linear output is) in its LDS
+    // slice, 64 rows at a time, and walks X row-wise instead: 4 rows x 256 contiguous bytes per load / store instruction,
+    // the loads of 32 rows in flight together.
     if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // nobody still reads fragments of the last K block out of buffer 1
+      char* stg = smem + 2 * TILE_BYTES + wave * 8192;
+      const int wr_row = le & 15, wr_q = le >> 4;
+      const int rr = le >> 4, cc = le & 15;            // row inside a group of 4, 16-byte piece of the 256-byte row
+      const int mw = m0 + wm * (16 * MT);
+      const int nw = n0 + wn * (16 * NTW) + cc * 4;
+      // GATE: 0 no gate, 1 gate row from the per-row table, 2 gate row = m / rows_per_batch (one straight-line body each:
+      // a uniform branch per load would keep the loads from being issued together)
+      auto rmw = [&](auto gate_c) {
+        constexpr int GATE = decltype(gate_c)::value;
 #pragma unroll
-      for (int mt0 = 0; mt0 < MT; mt0 += 2) {
-        constexpr int NB = 2;
-        f32x4 xv[NB][NTW], gv[NB][NTW];
-        float* xp[NB];
+        for (int c0 = 0; c0 < MT; c0 += 4) {
+          const int nmt = MT - c0 < 4 ? MT - c0 : 4;   // compile-time after unrolling
 #pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          if (mt0 + u >= MT) continue;                         // compile-time after unrolling (odd MT)
-          const int m = mrow + (mt0 + u) * 16;
-          xp[u] = p.X + (int64_t)m * p.ldx + ncol;
-          const float* grow = nullptr;
-          if (p.gate) {
-            const int64_t r = p.gate_row ? (int64_t)p.gate_row[m] : (int64_t)m / p.rows_per_batch;
-            grow = p.gate + r * p.gate_ld + ncol;
+          for (int u = 0; u < 4; ++u) {
+            if (u >= nmt) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              const f32x4 v = acc[c0 + u][nt] + bias[nt];
+              bf16x4 o;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+              const int row = u * 16 + wr_row;
+              *(bf16x4*)(stg + row * 128 + (((2 * nt + (wr_q >> 1)) ^ (row & 7)) << 4) + (wr_q & 1) * 8) = o;
+            }
           }
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            xv[u][nt] = *(const f32x4*)(xp[u] + nt * 16);
-            gv[u][nt] = grow ? *(const f32x4*)(grow + nt * 16) : (f32x4){1.f, 1.f, 1.f, 1.f};
+          for (int i0 = 0; i0 < 16; i0 += 8) {
+            if (i0 >= 4 * nmt) continue;
+            f32x4 xv[8], gv[8];
+            float* xp[8];
+            int gr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              if (i0 + i >= 4 * nmt) continue;
+              const int m = mw + c0 * 16 + 4 * (i0 + i) + rr;
+              xp[i] = p.X + (int64_t)m * p.ldx + nw;
+              xv[i] = *(const f32x4*)xp[i];
+              if constexpr (GATE == 1) gr[i] = p.gate_row[m];
+              if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
+            }
+            if constexpr (GATE != 0) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                if (i0 + i >= 4 * nmt) continue;
+                gv[i] = *(const f32x4*)(p.gate + (int64_t)gr[i] * p.gate_ld + nw);
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              if (i0 + i >= 4 * nmt) continue;
+              const int row = 4 * (i0 + i) + rr;
+              const bf16x4 y = *(const bf16x4*)(stg + row * 128 + ((((cc >> 1)) ^ (row & 7)) << 4) + (cc & 1) * 8);
+              f32x4 x = xv[i];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[i][j] : bf2f(y[j]);
+              *(f32x4*)xp[i] = x;
+            }
           }
         }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-          if (mt0 + u >= MT) continue;
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            const f32x4 v = acc[mt0 + u][nt] + bias[nt];
-            f32x4 x = xv[u][nt];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(v[j])) * gv[u][nt][j];     // y rounded to bf16 first (FX.py:456,461,468)
-            *(f32x4*)(xp[u] + nt * 16) = x;
-          }
-        }
-      }
+      };
+      if (!p.gate) rmw(std::integral_constant<int, 0>{});
+      else if (p.gate_row) rmw(std::integral_constant<int, 1>{});
+      else rmw(std::integral_constant<int, 2>{});
       continue;                                        // next tile of this persistent workgroup
     }
   }
@@ -369,8 +405,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                    // nobody still reads fragments of the last K block out of buffer 1
       char* stg = smem + 2 * TILE_BYTES + wave * 8192;
-      const int wr_row = lane & 15, wr_q = lane >> 4;
-      const int rd_row = lane >> 3, rd_c = lane & 7;
+      const int wr_row = le & 15, wr_q = le >> 4;
+      const int rd_row = le >> 3, rd_c = le & 7;
       bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
 #pragma unroll
       for (int c0 = 0; c0 < MT; c0 += 4) {
