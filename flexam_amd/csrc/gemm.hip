@@ -60,6 +60,9 @@ struct GemmParams {
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
+template <int V>
+using IC = std::integral_constant<int, V>;
+
 #ifdef FLEXAM_GEMM_ABLATE
 #define ABLATE(p, bit) ((p).debug & (bit))
 #else
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   constexpr int NP = PA + 4;                // LDS-DMA pieces per thread per K block
   constexpr int NF = NTW + MT;              // fragments per 32-deep K half
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][2 KiB] of epilogue staging
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,7 +141,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   const int sw = (lane & 15) >> 1;
   const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
   const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
-  bool staged = false;          // K block 0 of the coming unit is already on its way into LDS buffer 0
+  bool staged = false;          // K blocks 0 and 1 of the coming unit are already on their way into the two LDS buffers
+  bool pend = false;            // ... and exactly PEND stores of the last epilogue were issued by this wave after them
+  constexpr int PEND = (EPI == EPI_GATE_RESIDUAL ? 4 : 2) * MT;
   const int nk = p.K / BK;
   auto kcol_a = [&](int kb) -> int64_t { return a_koff ? a_koff[kb < nk ? kb : nk - 1] : (int64_t)kb * BK; };
   // work unit -> (tile, first K block, K blocks, slice, slices)
@@ -182,8 +187,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
                  : "v"(voff), "s"(sbase), "s"(dst)
                  : "memory");
   };
-  auto dma_wait_barrier = [&]() {
-    if (!ABLATE(p, 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  auto wait_barrier = [&](auto n_c) {                  // at most N of this wave's vector-memory operations still in flight, then barrier
+    if (!ABLATE(p, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");
     if (!ABLATE(p, 2)) __syncthreads();
   };
   // fragment j of a set: j < 4 -> W n-tile j, else A m-tile j-4
@@ -210,18 +215,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   if (!staged) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma(i, kcol_a(kb0), (int64_t)kb0 * BK, smem);
-  }
-  int64_t kcol_next = kcol_a(kb0 + 1);    // A offset of the K block staged next, fetched one step ahead
-  dma_wait_barrier();
-  if (nkl > 1) {
+    if (nkl > 1) {
+      const int64_t k1 = kcol_a(kb0 + 1);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) dma(i, kcol_next, (int64_t)(kb0 + 1) * BK, smem + 2 * TILE_BYTES);
+      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(kb0 + 1) * BK, smem + 2 * TILE_BYTES);
+    }
   }
-  kcol_next = kcol_a(kb0 + 2);
+  int64_t kcol_next = kcol_a(kb0 + 2);    // A offset of the K block staged next, fetched one step ahead
+  // In flight per wave, oldest first: K block 0 (NP pieces), K block 1 (NP pieces, if there is one), then the PEND stores of the
+  // previous unit's epilogue.  vmcnt retires in issue order, so the waits for the two K blocks can leave the stores in
+  // flight: they drain under K block 0 instead of in front of it.
+  const bool counted = pend && nkl >= 3;
+  if (counted) wait_barrier(IC<NP + PEND>{});
+  else if (!pend && nkl > 1) wait_barrier(IC<NP>{});     // only K block 1 is younger than K block 0
+  else wait_barrier(IC<0>{});                            // (one or two K blocks: drain everything)
+  pend = false;
 #pragma unroll
   for (int g = 0; g < (NF + 1) / 2; ++g) ld2(smem, frag_off0, g, wf0, af0);
 
-  auto block = [&](int kb, auto dma_c, auto rd_c) {
+  auto block = [&](int kb, auto dma_c, auto rd_c, auto wait_c) {
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
     char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
     char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       if (!ABLATE(p, 8)) ld2(cur, frag_off1, g, wf1, af1);   // 8: no phase-A fragment reads (half the ds_reads)
     }
     __builtin_amdgcn_sched_barrier(0);
-    dma_wait_barrier();
+    wait_barrier(wait_c);
 #pragma unroll
     for (int g = 0; g < MT; ++g) {                      // phase B
       __builtin_amdgcn_sched_barrier(0);
@@ -254,12 +266,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
   int kb = 0;
-  for (; kb + 2 < nkl; ++kb) block(kb, T_{}, T_{});
-  if (kb + 1 < nkl) { block(kb, F_{}, T_{}); ++kb; }
-  block(kb, F_{}, F_{});
+  if (counted) { block(0, T_{}, T_{}, IC<PEND>{}); kb = 1; }     // K block 1 has landed; the epilogue stores may still be in flight
+  for (; kb + 2 < nkl; ++kb) block(kb, T_{}, T_{}, IC<0>{});
+  if (kb + 1 < nkl) { block(kb, F_{}, T_{}, IC<0>{}); ++kb; }
+  block(kb, F_{}, F_{}, IC<0>{});
 
-  // ---- the next tile's first K block goes on its way before this tile's epilogue: LDS is idle from here on (every wave
-  // passed the last barrier with its fragments in registers) and the epilogue only touches global memory
+  // ---- the next unit's first two K blocks go on their way before this tile's epilogue: both buffers are idle from here on
+  // (every wave passed the last barrier with its fragments in registers) and the epilogue has its own slice of LDS
   staged = it + 1 < n_whole + n_tail;
   if (staged) {
     int nm0, nn0, ntile, nkb0, nnkl, nslice, nns;
@@ -268,6 +281,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     stage_setup(nm0, nn0);
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma(i, kcol_a(nkb0), (int64_t)nkb0 * BK, smem);
+    if (nnkl > 1) {
+      const int64_t k1 = kcol_a(nkb0 + 1);
+#pragma unroll
+      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(nkb0 + 1) * BK, smem + 2 * TILE_BYTES);
+    }
   }
 
   // ---- tail split-K: park this slice's partial sums; the slice whose arrival count comes back last adds all of them up in
@@ -324,13 +342,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   }
   if constexpr (EPI == EPI_GATE_RESIDUAL) {
     // Interior tiles (all but the last tile row / column): in the MFMA layout a lane's 16 bytes of X sit in 16 different rows
-    // per instruction (64-byte pieces).  The wave parks y (rounded to bf16, as the reference's Linear output is) in its LDS
-    // slice, 64 rows at a time, and walks X row-wise instead: 4 rows x 256 contiguous bytes per load / store instruction,
-    // the loads of 32 rows in flight together.
+    // per instruction (64-byte pieces).  The wave parks y (rounded to bf16, as the reference's Linear output is) in its own
+    // 2 KiB of LDS, one m-tile (16 rows) at a time, and walks X row-wise instead: 4 rows x 256 contiguous bytes per load /
+    // store instruction, the loads of two m-tiles in flight together.  (LDS serves a wave's operations in order: no wait
+    // between the y writes and the reads behind them.)
     if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                    // nobody still reads fragments of the last K block out of buffer 1
-      char* stg = smem + 2 * TILE_BYTES + wave * 8192;
+      char* stg = smem + 4 * TILE_BYTES + wave * 2048;
       const int wr_row = le & 15, wr_q = le >> 4;
       const int rr = le >> 4, cc = le & 15;            // row inside a group of 4, 16-byte piece of the 256-byte row
       const int mw = m0 + wm * (16 * MT);
@@ -340,10 +357,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       auto rmw = [&](auto gate_c) {
         constexpr int GATE = decltype(gate_c)::value;
 #pragma unroll
-        for (int c0 = 0; c0 < MT; c0 += 4) {
-          const int nmt = MT - c0 < 4 ? MT - c0 : 4;   // compile-time after unrolling
+        for (int c0 = 0; c0 < MT; c0 += 2) {
+          const int nmt = MT - c0 < 2 ? 1 : 2;         // compile-time after unrolling
+          f32x4 xv[8], gv[8];
+          float* xp[8];
+          int gr[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int i = 0; i < 8; ++i) {
+            if (i >= 4 * nmt) continue;
+            const int m = mw + c0 * 16 + 4 * i + rr;
+            xp[i] = p.X + (int64_t)m * p.ldx + nw;
+            xv[i] = *(const f32x4*)xp[i];
+            if constexpr (GATE == 1) gr[i] = p.gate_row[m];
+            if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
+          }
+          if constexpr (GATE != 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              if (i >= 4 * nmt) continue;
+              gv[i] = *(const f32x4*)(p.gate + (int64_t)gr[i] * p.gate_ld + nw);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
             if (u >= nmt) continue;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
@@ -351,91 +387,59 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
               bf16x4 o;
 #pragma unroll
               for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-              const int row = u * 16 + wr_row;
-              *(bf16x4*)(stg + row * 128 + (((2 * nt + (wr_q >> 1)) ^ (row & 7)) << 4) + (wr_q & 1) * 8) = o;
-            }
-          }
-#pragma unroll
-          for (int i0 = 0; i0 < 16; i0 += 8) {
-            if (i0 >= 4 * nmt) continue;
-            f32x4 xv[8], gv[8];
-            float* xp[8];
-            int gr[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              if (i0 + i >= 4 * nmt) continue;
-              const int m = mw + c0 * 16 + 4 * (i0 + i) + rr;
-              xp[i] = p.X + (int64_t)m * p.ldx + nw;
-              xv[i] = *(const f32x4*)xp[i];
-              if constexpr (GATE == 1) gr[i] = p.gate_row[m];
-              if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
-            }
-            if constexpr (GATE != 0) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i) {
-                if (i0 + i >= 4 * nmt) continue;
-                gv[i] = *(const f32x4*)(p.gate + (int64_t)gr[i] * p.gate_ld + nw);
-              }
+              *(bf16x4*)(stg + wr_row * 128 + (((2 * nt + (wr_q >> 1)) ^ (wr_row & 7)) << 4) + (wr_q & 1) * 8) = o;
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              if (i0 + i >= 4 * nmt) continue;
-              const int row = 4 * (i0 + i) + rr;
-              const bf16x4 y = *(const bf16x4*)(stg + row * 128 + ((((cc >> 1)) ^ (row & 7)) << 4) + (cc & 1) * 8);
-              f32x4 x = xv[i];
+            for (int i = 0; i < 4; ++i) {
+              const int row = 4 * i + rr;
+              const bf16x4 y = *(const bf16x4*)(stg + row * 128 + (((cc >> 1) ^ (row & 7)) << 4) + (cc & 1) * 8);
+              f32x4 x = xv[4 * u + i];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[i][j] : bf2f(y[j]);
-              *(f32x4*)xp[i] = x;
+              for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[4 * u + i][j] : bf2f(y[j]);
+              *(f32x4*)xp[4 * u + i] = x;
             }
           }
         }
       };
-      if (!p.gate) rmw(std::integral_constant<int, 0>{});
-      else if (p.gate_row) rmw(std::integral_constant<int, 1>{});
-      else rmw(std::integral_constant<int, 2>{});
+      if (!p.gate) rmw(IC<0>{});
+      else if (p.gate_row) rmw(IC<1>{});
+      else rmw(IC<2>{});
+      pend = true;                                     // PEND = 4 MT stores per wave, issued after the next unit's K blocks
       continue;                                        // next tile of this persistent workgroup
     }
   }
   if constexpr (EPI != EPI_GATE_RESIDUAL && sizeof(OutT) == 2) {
     // Interior tiles, bf16 output: the MFMA layout gives a lane 4 columns of 16 different rows, i.e. 16 x 32-byte pieces per
-    // store instruction.  The wave turns its 16*MT x 64 outputs around in LDS instead (64 rows = 8 KiB at a time in its own
-    // slice of buffer 1, idle until the next unit's second K block; 16-byte chunks XOR-swizzled by row so that both the
-    // 8-byte writes and the 16-byte reads are conflict-free) and stores whole 128-byte rows, 8 per instruction.
+    // store instruction.  The wave turns its 16*MT x 64 outputs around in its own 2 KiB of LDS instead, one m-tile (16 rows)
+    // at a time (16-byte chunks XOR-swizzled by row: the 8-byte writes and the 16-byte reads are both conflict-free), and
+    // stores whole 128-byte rows, 8 per instruction.
     if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                    // nobody still reads fragments of the last K block out of buffer 1
-      char* stg = smem + 2 * TILE_BYTES + wave * 8192;
+      char* stg = smem + 4 * TILE_BYTES + wave * 2048;
       const int wr_row = le & 15, wr_q = le >> 4;
       const int rd_row = le >> 3, rd_c = le & 7;
       bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
 #pragma unroll
-      for (int c0 = 0; c0 < MT; c0 += 4) {
-        const int nmt = MT - c0 < 4 ? MT - c0 : 4;     // compile-time after unrolling
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (u >= nmt) continue;
+        for (int nt = 0; nt < NTW; ++nt) {
+          f32x4 v = acc[mt][nt] + bias[nt];
+          if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            f32x4 v = acc[c0 + u][nt] + bias[nt];
-            if constexpr (EPI == EPI_GELU) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-            const int row = u * 16 + wr_row;
-            *(bf16x4*)(stg + row * 128 + (((2 * nt + (wr_q >> 1)) ^ (row & 7)) << 4) + (wr_q & 1) * 8) = o;
+            for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
           }
+          bf16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+          *(bf16x4*)(stg + wr_row * 128 + (((2 * nt + (wr_q >> 1)) ^ (wr_row & 7)) << 4) + (wr_q & 1) * 8) = o;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (i >= 2 * nmt) continue;
+        for (int i = 0; i < 2; ++i) {
           const int row = 8 * i + rd_row;
           const bf16x8 o8 = *(const bf16x8*)(stg + row * 128 + ((rd_c ^ (row & 7)) << 4));
-          *(bf16x8*)(crow + (int64_t)(c0 * 16 + 8 * i) * p.ldc) = o8;
+          *(bf16x8*)(crow + (int64_t)(mt * 16 + 8 * i) * p.ldc) = o8;
         }
       }
+      pend = true;                                     // PEND = 2 MT stores per wave, issued after the next unit's K blocks
       continue;                                        // next tile of this persistent workgroup
     }
   }
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // edge tiles / fp32 outputs: an unknown number of stores, drained here (pend stays false)
   }   // tile loop
 }
 
@@ -526,7 +531,7 @@ template <int EPI, typename OutT, int MT>
 int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
   auto kern = gemm_bf16_kernel<EPI, OutT, MT>;
   static bool attr_set = false;
-  const int smem = 4 * TILE_BYTES;   // 128 KiB
+  const int smem = 4 * TILE_BYTES + 8 * 2048;   // two K-block buffers (128 KiB) + 2 KiB per wave for the epilogue
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
