@@ -230,6 +230,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   else if (!pend && nkl > 1) wait_barrier(IC<NP>{});     // only K block 1 is younger than K block 0
   else wait_barrier(IC<0>{});                            // (one or two K blocks: drain everything)
   pend = false;
+  // The staging offsets are read by asm statements inside the K loop.  Should one of them ever come back from a spill slot, the
+  // compiler's own wait for that reload must land here and not in the loop, where a vmcnt(0) would drain the LDS-DMA pipeline
+  // on every K block.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < PA) asm volatile("" : "+v"(a_off[i]));
+    asm volatile("" : "+v"(w_off[i]));
+  }
 #pragma unroll
   for (int g = 0; g < (NF + 1) / 2; ++g) ld2(smem, frag_off0, g, wf0, af0);
 
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt)          // 16-byte sc1 stores cost what plain ones do; 8-byte ones are one fabric write each
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slab + ((mt * NTW + nt) * 512 + te) * 4), "v"(acc[mt][nt]) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), as an instruction the compiler's own wait bookkeeping sees
     __syncthreads();
     if (te == 0) arrive_flag = __hip_atomic_fetch_add(p.counters + tr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -340,6 +348,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     const int n = ncol + nt * 16;
     bias[nt] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  // "used" on every path: a bias load that some path never reads stays pending in the compiler's wait bookkeeping, which then
+  // puts a vmcnt(0) in front of the first MFMA of the next unit that reuses the register - draining the epilogue stores
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(bias[nt]));
   if constexpr (EPI == EPI_GATE_RESIDUAL) {
     // Interior tiles (all but the last tile row / column): in the MFMA layout a lane's 16 bytes of X sit in 16 different rows
     // per instruction (64-byte pieces).  The wave parks y (rounded to bf16, as the reference's Linear output is) in its own
@@ -352,22 +364,36 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       const int rr = le >> 4, cc = le & 15;            // row inside a group of 4, 16-byte piece of the 256-byte row
       const int mw = m0 + wm * (16 * MT);
       const int nw = n0 + wn * (16 * NTW) + cc * 4;
+      // X addresses = uniform 64-bit row base (scalar registers) + ONE 32-bit per-lane offset: eight 64-bit per-lane pointers
+      // next to the 128 accumulators are what used to push loop-carried values into scratch
+      const uint32_t xlane = (uint32_t)((rr * p.ldx + wn * (16 * NTW) + cc * 4) * 4);
+      char* xtile = (char*)(p.X + (int64_t)mw * p.ldx + n0);
       // GATE: 0 no gate, 1 gate row from the per-row table, 2 gate row = m / rows_per_batch (one straight-line body each:
       // a uniform branch per load would keep the loads from being issued together)
+      // y = bf16(acc + bias) for the whole wave tile first: 64 packed registers instead of 128 + 16 while the X and gate loads
+      // of two m-tiles are in flight (the asm pins the conversion here; left to itself it sinks to the LDS writes and spills)
+      bf16x4 yp[MT][NTW];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const f32x4 v = acc[mt][nt] + bias[nt];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yp[mt][nt][j] = f2bf(v[j]);
+          asm volatile("" : "+v"(yp[mt][nt]));
+        }
       auto rmw = [&](auto gate_c) {
         constexpr int GATE = decltype(gate_c)::value;
 #pragma unroll
         for (int c0 = 0; c0 < MT; c0 += 2) {
           const int nmt = MT - c0 < 2 ? 1 : 2;         // compile-time after unrolling
           f32x4 xv[8], gv[8];
-          float* xp[8];
           int gr[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             if (i >= 4 * nmt) continue;
             const int m = mw + c0 * 16 + 4 * i + rr;
-            xp[i] = p.X + (int64_t)m * p.ldx + nw;
-            xv[i] = *(const f32x4*)xp[i];
+            xv[i] = *(const f32x4*)(xtile + (int64_t)(c0 * 16 + 4 * i) * p.ldx * 4 + xlane);
             if constexpr (GATE == 1) gr[i] = p.gate_row[m];
             if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
           }
@@ -382,13 +408,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
           for (int u = 0; u < 2; ++u) {
             if (u >= nmt) continue;
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-              const f32x4 v = acc[c0 + u][nt] + bias[nt];
-              bf16x4 o;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-              *(bf16x4*)(stg + wr_row * 128 + (((2 * nt + (wr_q >> 1)) ^ (wr_row & 7)) << 4) + (wr_q & 1) * 8) = o;
-            }
+            for (int nt = 0; nt < NTW; ++nt)
+              *(bf16x4*)(stg + wr_row * 128 + (((2 * nt + (wr_q >> 1)) ^ (wr_row & 7)) << 4) + (wr_q & 1) * 8) = yp[c0 + u][nt];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int row = 4 * i + rr;
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
               f32x4 x = xv[4 * u + i];
 #pragma unroll
               for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[4 * u + i][j] : bf2f(y[j]);
-              *(f32x4*)xp[4 * u + i] = x;
+              *(f32x4*)(xtile + (int64_t)(c0 * 16 + 4 * (4 * u + i)) * p.ldx * 4 + xlane) = x;
             }
           }
         }
@@ -404,6 +425,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       if (!p.gate) rmw(IC<0>{});
       else if (p.gate_row) rmw(IC<1>{});
       else rmw(IC<2>{});
+      // every load of this epilogue has been consumed; saying so with an instruction the compiler's wait bookkeeping sees keeps
+      // it from putting a vmcnt(0) of its own in front of the next unit's first register reuse (behind the stores)
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));
       pend = true;                                     // PEND = 4 MT stores per wave, issued after the next unit's K blocks
       continue;                                        // next tile of this persistent workgroup
     }
@@ -439,6 +463,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
           *(bf16x8*)(crow + (int64_t)(mt * 16 + 8 * i) * p.ldc) = o8;
         }
       }
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));   // see the gate-residual path
       pend = true;                                     // PEND = 2 MT stores per wave, issued after the next unit's K blocks
       continue;                                        // next tile of this persistent workgroup
     }
@@ -452,6 +477,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       if (p.gate) {
         const int64_t r = p.gate_row ? (int64_t)p.gate_row[m] : (int64_t)m / p.rows_per_batch;
         grow = p.gate + r * p.gate_ld;
+        asm volatile("" ::"v"(grow));                   // the gate_row load is "used" even if every column below is out of range
       }
     }
 #pragma unroll
@@ -481,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // edge tiles / fp32 outputs: an unknown number of stores, drained here (pend stays false)
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): edge tiles / fp32 outputs issue an unknown number of stores, drained here (pend stays false)
   }   // tile loop
 }
 
