@@ -101,13 +101,14 @@ __device__ __forceinline__ float pair_sum(float x) {
 // ------------------------------------------------------------------------------------------------
 constexpr int NT = 512;
 constexpr int NSLOT = 4;
+constexpr int V_RING = NSLOT * KV_TILE_BYTES;   // LDS: [4 K slots][4 V slots]
 template <int V>
 using IC = std::integral_constant<int, V>;
 constexpr float RESCALE_THR_LOG2 = 8.0f;
 
 template <int KIND>   // 0 = self-attention, 1 = short-context (text) attention: distinct profiler symbols
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // ring: [4][K tile | V tile]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 K tiles][4 V tiles], each a ring
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,13 +172,13 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   }
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
   auto issue_tile = [&](int t) {
-    const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * (2 * KV_TILE_BYTES) + wave * 1024);   // wave-uniform
+    const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * KV_TILE_BYTES + wave * 1024);   // wave-uniform; K ring, V ring = + V_RING
     const int tg = t0 + t;
     if ((tg + 1) * KVBLK <= p.Lk) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         lds_dma16(kbase + (k_go[i] + (unsigned)tg * k_step), slot + i * 8192);
-        lds_dma16(vbase + (v_go[i] + (unsigned)tg * v_step), slot + KV_TILE_BYTES + i * 8192);
+        lds_dma16(vbase + (v_go[i] + (unsigned)tg * v_step), slot + V_RING + i * 8192);
       }
     } else {                                 // last, partial tile: rows past Lk re-read the last key (masked later)
 #pragma unroll
@@ -186,33 +187,30 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
         const int col = ((tid & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 16;
         const int key = min(tg * KVBLK + row, p.Lk - 1);
         lds_dma16(kbase + ((int64_t)key * p.k_rs * 2 + col), slot + i * 8192);
-        lds_dma16(vbase + ((int64_t)key * p.v_rs * 2 + col), slot + KV_TILE_BYTES + i * 8192);
+        lds_dma16(vbase + ((int64_t)key * p.v_rs * 2 + col), slot + V_RING + i * 8192);
       }
     }
   };
-  // Half tile g lives in ring slot (g>>1)&3.  With the tile loop unrolled by 4 the slot is a compile-time constant:
-  // the per-lane fragment addresses are precomputed ONCE for slots 0 and 2 (two register sets) and everything
-  // else -- slot parity, K/V region, half, 16-key step -- is folded into the ds_read immediate (< 64 KiB).
-  const char* kaddr[2][8];
-  const char* vaddr[2][2][4];
+  // Half tile g lives in ring slot (g>>1)&3; the K slots fill the first 64 KiB of LDS and the V slots the second, so ONE set of
+  // per-lane fragment addresses per ring reaches all four slots through the 16-bit ds_read immediate (slot, half and 16-key step
+  // are compile-time constants once the tile loop is unrolled by 4).
+  const char* kaddr[8];
+  const char* vaddr[2][4];
 #pragma unroll
-  for (int set = 0; set < 2; ++set) {
+  for (int ds = 0; ds < 8; ++ds) kaddr[ds] = smem + koff[ds];
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) kaddr[set][ds] = smem + set * (4 * KV_TILE_BYTES) + koff[ds];
+  for (int half = 0; half < 2; ++half)
 #pragma unroll
-    for (int half = 0; half < 2; ++half)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) vaddr[set][half][dt] = smem + set * (4 * KV_TILE_BYTES) + voff[half][dt];
-  }
+    for (int dt = 0; dt < 4; ++dt) vaddr[half][dt] = smem + V_RING + voff[half][dt];
   // ds0 == 0 starts a new accumulation: the first MFMA takes a literal-zero C operand (no register zeroing)
   // `ghalf` (half-tile index modulo 8) must be a compile-time constant at every call site
   auto qk_part = [&](auto ghalf_c, auto ds0_c, f32x16& sacc) {      // 4 K fragments ds0 .. ds0+3 of half `ghalf`
     constexpr int ghalf = decltype(ghalf_c)::value, ds0 = decltype(ds0_c)::value;
     constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
-    constexpr int imm = (slot & 1) * (2 * KV_TILE_BYTES) + (ghalf & 1) * 8192;
+    constexpr int imm = slot * KV_TILE_BYTES + (ghalf & 1) * 8192;
     bf16x8 kf[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(kaddr[slot >> 1][ds0 + i] + imm);   // fragments first ...
+    for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(kaddr[ds0 + i] + imm);   // fragments first ...
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                                                             // ... then the MFMAs
       const int ds = ds0 + i;
@@ -243,14 +241,14 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   auto pv_half = [&](auto ghalf_c) {
     constexpr int ghalf = decltype(ghalf_c)::value;
     constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
-    constexpr int imm = (slot & 1) * (2 * KV_TILE_BYTES) + KV_TILE_BYTES + (ghalf & 1) * 8192;
+    constexpr int imm = slot * KV_TILE_BYTES + (ghalf & 1) * 8192;
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
       bf16x8 vf[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {                                                   // 8 transposed reads first ...
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[slot >> 1][0][dt] + imm + ss * 4096));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[slot >> 1][1][dt] + imm + ss * 4096));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[0][dt] + imm + ss * 4096));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[1][dt] + imm + ss * 4096));
         const bf16x4 lo_b = __builtin_bit_cast(bf16x4, lo), hi_b = __builtin_bit_cast(bf16x4, hi);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -268,7 +266,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const float c = p.scale_log2e;
 
   // ---- prologue: tiles 0 and 1 on their way, S(half 0) computed; zero the V half that PV(-1) multiplies by P = 0
-  *(u32x4*)(smem + (NSLOT - 1) * (2 * KV_TILE_BYTES) + KV_TILE_BYTES + 8192 + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+  *(u32x4*)(smem + V_RING + (NSLOT - 1) * KV_TILE_BYTES + 8192 + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
   issue_tile(0);
   if (ntiles > 1) issue_tile(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -461,7 +459,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.ws_o = ws_o; p.ws_ml = ws_ml;
   FX_REQUIRE((int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
-  const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 x (K tile | V tile): 128 KiB
+  const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
   auto kern = cross ? attn_fwd_kernel<1> : attn_fwd_kernel<0>;
   static bool attr_set[2] = {false, false};
