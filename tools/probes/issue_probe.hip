@@ -143,6 +143,65 @@ __global__ __launch_bounds__(NW * 64) void mix(const char* __restrict__ src, uin
   if (lane == 0) out[blockIdx.x * NW + wave] = t1 - t0;
 }
 
+// Same mix with the work of 8 x v_mfma_f32_16x16x32_bf16 done by 4 x v_mfma_f32_32x32x16_bf16 (same 128 matrix-pipe cycles, half
+// the MFMA issue slots): KIND 2 staging only.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int STG, int NREAD, int NW>
+__global__ __launch_bounds__(NW * 64) void mix32(const char* __restrict__ src, uint64_t* __restrict__ out, float* sink, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.01f * ((lane * 7 + i) % 13)); b[i] = (__bf16)(0.02f * ((lane * 5 + i) % 11)); }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j)
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const uint32_t lds_lane = wave * 1024 + lane * 16;
+  i32x4 rd = {0, 0, 0, 0};
+  __syncthreads();
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    const uint32_t lp = (it & 3) * 8192 * (NW / 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+#pragma unroll
+      for (int r = 2 * j; r < 2 * j + 2; ++r)
+        if (r < NREAD) asm volatile("ds_read_b128 %0, %1" : "+v"(rd) : "v"(lds_lane + 32768 + r * 1024 * NW / 4) : "memory");
+      if (STG > 0 && j >= 4 - STG) {
+        const int e = j - (4 - STG);
+        unsigned keep;
+        const char* sb = src + (size_t)blockIdx.x * 262144 + (it & 15) * 8192 + e * 65536;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"((unsigned)(threadIdx.x * 16)), "s"(sb), "s"(lp + wave * 1024 + e * 1024 * NW) : "memory");
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][5] + acc[j][10] + acc[j][15];
+  s += (float)(rd[0] ^ rd[1]) * 1e-30f;
+  if (s == 123.456f) sink[0] = s + smem[lane];
+  if (lane == 0) out[blockIdx.x * NW + wave] = t1 - t0;
+}
+
+template <int STG, int NREAD, int NW>
+void run_mix32(const char* name, const char* src, uint64_t* out, float* sink) {
+  const int iters = 4000, nb = 256;
+  static uint64_t h[256 * 8];
+  auto k = mix32<STG, NREAD, NW>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k, dim3(nb), dim3(NW * 64), 131072, 0, src, out, sink, iters);
+  hipDeviceSynchronize();
+  hipMemcpy(h, out, sizeof(uint64_t) * nb * NW, hipMemcpyDeviceToHost);
+  double sum = 0;
+  for (int i = 0; i < nb * NW; ++i) sum += (double)h[i];
+  const double cyc = sum / (nb * NW) / iters;
+  printf("%d waves/WG  32x32x16: %-26s stage %d KiB + %d ds_read per 4 MFMA: %7.1f cyc/iter/wave -> MFMA pipe use %4.1f %%\n", NW, name, STG, NREAD, cyc,
+         100.0 * 128.0 * (NW / 4) / cyc);
+  fflush(stdout);
+}
+
 template <int KIND, int STG, int NREAD, int NW>
 void run_mix(const char* name, const char* src, uint64_t* out, float* sink) {
   const int iters = 4000, nb = 256;
@@ -199,5 +258,12 @@ int main() {
   run_mix<1, 1, 3, 8>("global_load + ds_write_b128", src, out, sink);
   run_mix<0, 2, 3, 8>("LDS-DMA", src, out, sink);
   run_mix<1, 2, 3, 8>("global_load + ds_write_b128", src, out, sink);
+  printf("---- the same densities with 32x32x16 MFMAs\n");
+  run_mix32<0, 0, 4>("MFMA only", src, out, sink);
+  run_mix32<1, 2, 4>("LDS-DMA asm global form", src, out, sink);
+  run_mix32<0, 0, 8>("MFMA only", src, out, sink);
+  run_mix32<0, 3, 8>("reads only", src, out, sink);
+  run_mix32<1, 3, 8>("LDS-DMA asm global form", src, out, sink);
+  run_mix32<2, 3, 8>("LDS-DMA asm global form", src, out, sink);
   return 0;
 }
