@@ -77,15 +77,28 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // full last round (launch() picks MT).  (A 4-wave variant with 128x128 outputs per wave, one wave per SIMD and
 // AGPR accumulators ran at a higher clock -- a third fewer LDS bytes per MFMA -- but lower MFMA occupancy, 5-8 %
 // slower overall: profiles/r1e_gemm_notes.txt; it is in the history, not in the tree.)
-template <int EPI, typename OutT, int MT>
+// M32: the wave's 16*MT x 64 outputs as 32 x 32 MFMA tiles (v_mfma_f32_32x32x16_bf16, even MT) instead of 16 x 16 ones
+// (v_mfma_f32_16x16x32_bf16).  Same matrix-pipe time, LDS image, fragment bytes and accumulator registers, but half as many MFMA
+// instructions: a 16x16x32 holds the SIMD's vector issue for 8 of its 16 cycles, a 32x32x16 for 8 of its 32, which leaves the
+// LDS-DMA issues (~40 cycles each) and fragment reads of the K loop room beside them (tools/probes/issue_probe.hip: -7 % cycles
+// for the K loop's instruction mix).  Everything outside the MFMA calls is written once over "row tiles" of RT rows:
+//   lane -> row (lane % RT) of a row tile and column group g = lane / RT; a lane holds, for every 4-column unit v < NV of the
+//   wave's 64 columns, the 4 consecutive columns 4*NG*v + 4*g .. +3 of that row   (16x16: RT 16, NG 4, NV 4; 32x32: RT 32, NG 2, NV 8)
+template <int EPI, typename OutT, int MT, bool M32>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
+  static_assert(!M32 || MT % 2 == 0, "32 x 32 tiles need an even number of 16-row m-tiles per wave");
+  constexpr int RT = M32 ? 32 : 16;         // rows per row tile
+  constexpr int NRT = 16 * MT / RT;         // row tiles per wave
+  constexpr int NG = 64 / RT;               // column groups (lane / RT)
+  constexpr int NV = 16 / NG;               // 4-column units per lane
+  constexpr int STG_WAVE = RT * 128;        // epilogue staging per wave: one row tile of bf16 outputs (RT rows x 64 columns)
   constexpr int NTW = 4;                    // 16-wide n-tiles per wave
   constexpr int BM_ = 32 * MT;              // rows of this tile shape
   constexpr int PA = (BM_ + 63) / 64;       // 64-row staging pieces per thread for A (W always 4)
   constexpr int NP = PA + 4;                // LDS-DMA pieces per thread per K block
   constexpr int NF = NTW + MT;              // fragments per 32-deep K half
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][2 KiB] of epilogue staging
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][STG_WAVE] of epilogue staging
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,9 +151,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   };
 
   // ---- fragment read offsets (bytes inside a tile): row = base16 + (lane&15), chunk = (lane>>4) + 4*ks
-  const int sw = (lane & 15) >> 1;
-  const int frag_off0 = (lane & 15) * 128 + ((((lane >> 4) + 0) ^ sw) << 4);
-  const int frag_off1 = (lane & 15) * 128 + ((((lane >> 4) + 4) ^ sw) << 4);
+  // 16x16x32: row lane%16, 16-byte chunk lane/16 of a 32-deep K half; 32x32x16: row lane%32, chunk lane/32 of a 16-deep K step
+  const int sw = ((lane & (RT - 1)) >> 1) & 7;
+  int frag_off[M32 ? 4 : 2];
+#pragma unroll
+  for (int ks = 0; ks < (M32 ? 4 : 2); ++ks)
+    frag_off[ks] = (lane & (RT - 1)) * 128 + ((((M32 ? 2 * ks + (lane >> 5) : 4 * ks + (lane >> 4))) ^ sw) << 4);
   bool staged = false;          // K blocks 0 and 1 of the coming unit are already on their way into the two LDS buffers
   bool pend = false;            // ... and exactly PEND stores of the last epilogue were issued by this wave after them
   constexpr int PEND = (EPI == EPI_GATE_RESIDUAL ? 4 : 2) * MT;
@@ -159,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       nkl = (int)((int64_t)(slice + 1) * nk / ns) - kb0;
     }
   };
-  __shared__ int arrive_flag;
+  int& arrive_flag = *(int*)(smem + 4 * TILE_BYTES);   // first word of wave 0's epilogue staging: idle while split-K units hand over
 
   for (int it = 0; it < n_whole + n_tail; ++it) {
   int m0, n0, tile, kb0, nkl, slice, ns;
@@ -167,11 +183,32 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   tile_origin(tile, m0, n0);
   if (!staged) stage_setup(m0, n0);
 
-  f32x4 acc[MT][NTW];
+  f32x4 acc[M32 ? 1 : MT][NTW];              // 16x16 tiles: [m-tile][n-tile]
+  f32x16 acc32[M32 ? MT / 2 : 1][2];         // 32x32 tiles: [row tile][column tile]
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT / 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // the 4 consecutive columns of unit v in row tile t (see the kernel header), whatever the MFMA shape
+  auto accv = [&](int t, int v) -> f32x4 {
+    if constexpr (M32) {
+      f32x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = acc32[t][v >> 2][4 * (v & 3) + j];
+      return r;
+    } else {
+      return acc[t][v];
+    }
+  };
 
   // piece i (i < PA: A rows i*64.., else W rows (i-PA)*64..) of the tile at A K-offset ka / W K-offset kw -> LDS buffer `buf`.
   // Inline asm: the scalar-base form (uniform 64-bit base + one 32-bit VGPR offset) keeps the per-thread
@@ -191,17 +228,38 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     if (!ABLATE(p, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");
     if (!ABLATE(p, 2)) __syncthreads();
   };
-  // fragment j of a set: j < 4 -> W n-tile j, else A m-tile j-4
-  auto frag = [&](const char* buf, int fo, int j) -> bf16x8 {
-    return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
-                   : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
+  // fragment j (< NF = MT + 4) of the set of K half hf.  16x16x32: j < 4 -> W n-tile j, else A m-tile j-4, all 32 deep.
+  // 32x32x16: two 16-deep K steps, each [W column tile 0, W column tile 1, A row tile 0 .. MT/2-1], in the order the MFMAs want them.
+  auto frag = [&](const char* buf, int hf, int j) -> bf16x8 {
+    if constexpr (M32) {
+      constexpr int PER = 2 + MT / 2;
+      const int ks2 = j / PER, rem = j % PER;
+      const int fo = frag_off[2 * hf + ks2];
+      return rem < 2 ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + rem * 4096 + fo)
+                     : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (rem - 2) * 4096 + fo);
+    } else {
+      const int fo = frag_off[hf];
+      return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
+                     : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
+    }
   };
   // fragments 2g, 2g+1 of a set
-  auto ld2 = [&](const char* buf, int fo, int g, bf16x8 (&wf)[NTW], bf16x8 (&af)[MT]) {
+  auto ld2 = [&](const char* buf, int hf, int g, bf16x8 (&f)[NF]) {
 #pragma unroll
-    for (int j = 2 * g; j < 2 * g + 2; ++j) {
-      if (j < NTW) wf[j] = frag(buf, fo, j);
-      else if (j < NF) af[j - NTW] = frag(buf, fo, j);
+    for (int j = 2 * g; j < 2 * g + 2; ++j)
+      if (j < NF) f[j] = frag(buf, hf, j);
+  };
+  // MFMA group g (of MT per K half, 64 matrix-pipe cycles each) on fragment set f
+  auto mfma_group = [&](int g, const bf16x8 (&f)[NF]) {
+    if constexpr (M32) {
+      constexpr int MR = MT / 2, PER = 2 + MR;
+      const int ks2 = g / MR, r = g % MR;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        acc32[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks2 * PER + c], f[ks2 * PER + 2 + r], acc32[r][c], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[nt], f[NTW + g], acc[g][nt], 0, 0, 0);
     }
   };
 
@@ -211,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   //   phase B: LDS-DMA of tile kb+2 into `cur`; MFMAs on F1 while F0 of block kb+1 is read from `nxt`
   // so no wave crosses the barrier without MFMA work already in registers, and the DMA pieces and fragment
   // reads of a phase are spread one group (4 MFMAs) apart instead of stalling the wave up front.
-  bf16x8 wf0[NTW], af0[MT], wf1[NTW], af1[MT];
+  bf16x8 f0[NF], f1[NF];
   if (!staged) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma(i, kcol_a(kb0), (int64_t)kb0 * BK, smem);
@@ -239,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     asm volatile("" : "+v"(w_off[i]));
   }
 #pragma unroll
-  for (int g = 0; g < (NF + 1) / 2; ++g) ld2(smem, frag_off0, g, wf0, af0);
+  for (int g = 0; g < (NF + 1) / 2; ++g) ld2(smem, 0, g, f0);
 
   auto block = [&](int kb, auto dma_c, auto rd_c, auto wait_c) {
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
@@ -249,24 +307,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 #pragma unroll
     for (int g = 0; g < MT; ++g) {                      // phase A
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[nt], af0[g], acc[g][nt], 0, 0, 0);
+      mfma_group(g, f0);
       __builtin_amdgcn_sched_barrier(0);                // MFMAs first: the wait for F0 must not cover reads issued after it
-      if (!ABLATE(p, 8)) ld2(cur, frag_off1, g, wf1, af1);   // 8: no phase-A fragment reads (half the ds_reads)
+      if (!ABLATE(p, 8)) ld2(cur, 1, g, f1);            // 8: no phase-A fragment reads (half the ds_reads)
     }
     __builtin_amdgcn_sched_barrier(0);
     wait_barrier(wait_c);
 #pragma unroll
     for (int g = 0; g < MT; ++g) {                      // phase B
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[nt], af1[g], acc[g][nt], 0, 0, 0);
+      mfma_group(g, f1);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (DMA) {
         dma(g, kcol_next, kw, cur);
         if (g + MT < NP) dma(g + MT, kcol_next, kw, cur);
       }
-      if constexpr (RD) ld2(nxt, frag_off0, g, wf0, af0);
+      if constexpr (RD) ld2(nxt, 0, g, f0);
     }
     __builtin_amdgcn_sched_barrier(0);
     kcol_next = kcol_a(kb0 + kb + 3);
@@ -302,17 +358,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // agent-scope (sc1) accesses, each storing wave drains its stores, and one lane signals behind a workgroup barrier with a
   // relaxed agent-scope atomic add (MI355X_MICROARCH.md, inter-workgroup visibility: the "added last" row).
   if (ns > 1) {
-    constexpr int SLAB = 256 * BN;                     // floats per slab; 16-byte element of (mt, nt) at ((mt*4+nt)*512 + tid)*4
+    constexpr int SLAB = 256 * BN;                     // floats per slab; 16-byte element of (row tile t, unit v) at ((t*NV+v)*512 + tid)*4
     typedef unsigned long long u64;
     int te = tid;                                      // opaque copy (see `le` below): slab addresses stay out of the K loop's registers
     asm volatile("" : "+v"(te));
     const int tr = tile - p.split_full;
     float* slab = p.ws + ((int64_t)tr * ns + slice) * SLAB;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < NRT; ++t)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)          // 16-byte sc1 stores cost what plain ones do; 8-byte ones are one fabric write each
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slab + ((mt * NTW + nt) * 512 + te) * 4), "v"(acc[mt][nt]) : "memory");
+      for (int v = 0; v < NV; ++v) {            // 16-byte sc1 stores cost what plain ones do; 8-byte ones are one fabric write each
+        const f32x4 a4 = accv(t, v);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slab + ((t * NV + v) * 512 + te) * 4), "v"(a4) : "memory");
+      }
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), as an instruction the compiler's own wait bookkeeping sees
     __syncthreads();
     if (te == 0) arrive_flag = __hip_atomic_fetch_add(p.counters + tr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -323,44 +381,54 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     if (te == 0) __hip_atomic_store(p.counters + tr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     const u64* base = (const u64*)(p.ws + (int64_t)tr * ns * SLAB);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < NRT; ++t)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
+      for (int v = 0; v < NV; ++v)
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          const int e = ((mt * NTW + nt) * 512 + te) * 2 + hf;
+          const int e = ((t * NV + v) * 512 + te) * 2 + hf;
           f32x2 sum = __builtin_bit_cast(f32x2, __hip_atomic_load(base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
           for (int s2 = 1; s2 < ns; ++s2)
             sum += __builtin_bit_cast(f32x2, __hip_atomic_load(base + (int64_t)s2 * (SLAB / 2) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          acc[mt][nt][2 * hf] = sum[0];
-          acc[mt][nt][2 * hf + 1] = sum[1];
+          if constexpr (M32) {                   // (written out: an element store through a lambda parameter costs hipcc dozens of spills)
+            acc32[t][v >> 2][4 * (v & 3) + 2 * hf] = sum[0];
+            acc32[t][v >> 2][4 * (v & 3) + 2 * hf + 1] = sum[1];
+          } else {
+            acc[t][v][2 * hf] = sum[0];
+            acc[t][v][2 * hf + 1] = sum[1];
+          }
         }
   }
 
-  // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] per (mt, nt)
+  // ---- epilogue: lane holds C[m = .. + RT*t + lane%RT][n = .. + 4*NG*v + 4*(lane/RT) + 0..3] per (row tile t, unit v)
   int le = lane;                     // opaque copy of the lane id: the epilogue's per-lane address arithmetic must not be hoisted
   asm volatile("" : "+v"(le));       // out of the tile loop, where it would hold registers across the K loop (spills into it)
-  const int mrow = m0 + wm * (16 * MT) + (le & 15);
-  const int ncol = n0 + wn * (16 * NTW) + (le >> 4) * 4;
-  f32x4 bias[NTW];
+  const int mrow = m0 + wm * (16 * MT) + (le & (RT - 1));
+  const int ncol = n0 + wn * (16 * NTW) + (le / RT) * 4;
+  f32x4 bias[NV];
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int n = ncol + nt * 16;
-    bias[nt] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int v = 0; v < NV; ++v) {
+    const int n = ncol + v * (4 * NG);
+    bias[v] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   // "used" on every path: a bias load that some path never reads stays pending in the compiler's wait bookkeeping, which then
   // puts a vmcnt(0) in front of the first MFMA of the next unit that reuses the register - draining the epilogue stores
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) asm volatile("" ::"v"(bias[nt]));
+  for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(bias[v]));
+  // LDS staging of one row tile (RT rows x 64 bf16 columns = RT x 128 bytes per wave, 16-byte chunks XOR-swizzled by row: the
+  // 8-byte writes and the wider reads are conflict-free).  Unit v of a lane starts at byte 8*NG*v + 8*g of its row.
+  char* stg = smem + 4 * TILE_BYTES + wave * STG_WAVE;
+  const int wr_row = le & (RT - 1), wr_g = le / RT;
+  auto stg_write = [&](int v, bf16x4 o) {
+    *(bf16x4*)(stg + wr_row * 128 + ((((NG / 2) * v + (wr_g >> 1)) ^ (wr_row & 7)) << 4) + (wr_g & 1) * 8) = o;
+  };
   if constexpr (EPI == EPI_GATE_RESIDUAL) {
-    // Interior tiles (all but the last tile row / column): in the MFMA layout a lane's 16 bytes of X sit in 16 different rows
-    // per instruction (64-byte pieces).  The wave parks y (rounded to bf16, as the reference's Linear output is) in its own
-    // 2 KiB of LDS, one m-tile (16 rows) at a time, and walks X row-wise instead: 4 rows x 256 contiguous bytes per load /
-    // store instruction, the loads of two m-tiles in flight together.  (LDS serves a wave's operations in order: no wait
-    // between the y writes and the reads behind them.)
+    // Interior tiles (all but the last tile row / column): in the MFMA layout a lane's 16 bytes of X sit in RT different rows
+    // per instruction (64-byte pieces).  The wave parks y (rounded to bf16, as the reference's Linear output is) in its LDS
+    // slice, one row tile at a time, and walks X row-wise instead: 4 rows x 256 contiguous bytes per load / store instruction,
+    // the loads of 32 rows in flight together.  (LDS serves a wave's operations in order: no wait between the y writes and
+    // the reads behind them.)
     if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
-      char* stg = smem + 4 * TILE_BYTES + wave * 2048;
-      const int wr_row = le & 15, wr_q = le >> 4;
       const int rr = le >> 4, cc = le & 15;            // row inside a group of 4, 16-byte piece of the 256-byte row
       const int mw = m0 + wm * (16 * MT);
       const int nw = n0 + wn * (16 * NTW) + cc * 4;
@@ -368,58 +436,60 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       // next to the 128 accumulators are what used to push loop-carried values into scratch
       const uint32_t xlane = (uint32_t)((rr * p.ldx + wn * (16 * NTW) + cc * 4) * 4);
       char* xtile = (char*)(p.X + (int64_t)mw * p.ldx + n0);
+      // y = bf16(acc + bias) for the whole wave tile first: 64 packed registers instead of 128 + bias while the X and gate loads
+      // of 32 rows are in flight (the asm pins the conversion here; left to itself it sinks to the LDS writes and spills)
+      bf16x4 yp[NRT][NV];
+#pragma unroll
+      for (int t = 0; t < NRT; ++t)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const f32x4 y4 = accv(t, v) + bias[v];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yp[t][v][j] = f2bf(y4[j]);
+          asm volatile("" : "+v"(yp[t][v]));
+        }
       // GATE: 0 no gate, 1 gate row from the per-row table, 2 gate row = m / rows_per_batch (one straight-line body each:
       // a uniform branch per load would keep the loads from being issued together)
-      // y = bf16(acc + bias) for the whole wave tile first: 64 packed registers instead of 128 + 16 while the X and gate loads
-      // of two m-tiles are in flight (the asm pins the conversion here; left to itself it sinks to the LDS writes and spills)
-      bf16x4 yp[MT][NTW];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          const f32x4 v = acc[mt][nt] + bias[nt];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) yp[mt][nt][j] = f2bf(v[j]);
-          asm volatile("" : "+v"(yp[mt][nt]));
-        }
       auto rmw = [&](auto gate_c) {
         constexpr int GATE = decltype(gate_c)::value;
+        constexpr int TPB = 32 / RT;                   // row tiles per batch of 32 rows (8 load / store instructions)
 #pragma unroll
-        for (int c0 = 0; c0 < MT; c0 += 2) {
-          const int nmt = MT - c0 < 2 ? 1 : 2;         // compile-time after unrolling
+        for (int t0 = 0; t0 < NRT; t0 += TPB) {
+          const int ntb = NRT - t0 < TPB ? NRT - t0 : TPB;   // compile-time after unrolling
+          const int nit = ntb * RT / 4;
           f32x4 xv[8], gv[8];
           int gr[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            if (i >= 4 * nmt) continue;
-            const int m = mw + c0 * 16 + 4 * i + rr;
-            xv[i] = *(const f32x4*)(xtile + (int64_t)(c0 * 16 + 4 * i) * p.ldx * 4 + xlane);
+            if (i >= nit) continue;
+            const int m = mw + t0 * RT + 4 * i + rr;
+            xv[i] = *(const f32x4*)(xtile + (int64_t)(t0 * RT + 4 * i) * p.ldx * 4 + xlane);
             if constexpr (GATE == 1) gr[i] = p.gate_row[m];
             if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
           }
           if constexpr (GATE != 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              if (i >= 4 * nmt) continue;
+              if (i >= nit) continue;
               gv[i] = *(const f32x4*)(p.gate + (int64_t)gr[i] * p.gate_ld + nw);
             }
           }
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (u >= nmt) continue;
+          for (int u = 0; u < TPB; ++u) {
+            if (u >= ntb) continue;
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-              *(bf16x4*)(stg + wr_row * 128 + (((2 * nt + (wr_q >> 1)) ^ (wr_row & 7)) << 4) + (wr_q & 1) * 8) = yp[c0 + u][nt];
+            for (int v = 0; v < NV; ++v) stg_write(v, yp[t0 + u][v]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int row = 4 * i + rr;
+            for (int i = 0; i < RT / 4; ++i) {
+              const int row = 4 * i + rr, idx = u * (RT / 4) + i;
               const bf16x4 y = *(const bf16x4*)(stg + row * 128 + (((cc >> 1) ^ (row & 7)) << 4) + (cc & 1) * 8);
-              f32x4 x = xv[4 * u + i];
+              f32x4 x = xv[idx];
 #pragma unroll
-              for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[4 * u + i][j] : bf2f(y[j]);
-              *(f32x4*)(xtile + (int64_t)(c0 * 16 + 4 * (4 * u + i)) * p.ldx * 4 + xlane) = x;
+              for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[idx][j] : bf2f(y[j]);
+              *(f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane) = x;
             }
           }
+          __builtin_amdgcn_sched_barrier(0);           // one batch of loads in flight at a time: all of them at once would not fit the registers
         }
       };
       if (!p.gate) rmw(IC<0>{});
@@ -433,34 +503,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     }
   }
   if constexpr (EPI != EPI_GATE_RESIDUAL && sizeof(OutT) == 2) {
-    // Interior tiles, bf16 output: the MFMA layout gives a lane 4 columns of 16 different rows, i.e. 16 x 32-byte pieces per
-    // store instruction.  The wave turns its 16*MT x 64 outputs around in its own 2 KiB of LDS instead, one m-tile (16 rows)
-    // at a time (16-byte chunks XOR-swizzled by row: the 8-byte writes and the 16-byte reads are both conflict-free), and
-    // stores whole 128-byte rows, 8 per instruction.
+    // Interior tiles, bf16 output: the MFMA layout gives a lane 4 columns of RT different rows, i.e. 32-byte pieces per store
+    // instruction.  The wave turns its 16*MT x 64 outputs around in its LDS slice instead, one row tile at a time, and stores
+    // whole 128-byte rows, 8 per instruction.
     if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
-      char* stg = smem + 4 * TILE_BYTES + wave * 2048;
-      const int wr_row = le & 15, wr_q = le >> 4;
       const int rd_row = le >> 3, rd_c = le & 7;
       bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+      for (int t = 0; t < NRT; ++t) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          f32x4 v = acc[mt][nt] + bias[nt];
+        for (int v = 0; v < NV; ++v) {
+          f32x4 y4 = accv(t, v) + bias[v];
           if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
+            for (int j = 0; j < 4; ++j) y4[j] = gelu_tanh(y4[j]);
           }
           bf16x4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-          *(bf16x4*)(stg + wr_row * 128 + (((2 * nt + (wr_q >> 1)) ^ (wr_row & 7)) << 4) + (wr_q & 1) * 8) = o;
+          for (int j = 0; j < 4; ++j) o[j] = f2bf(y4[j]);
+          stg_write(v, o);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RT / 8; ++i) {
           const int row = 8 * i + rd_row;
           const bf16x8 o8 = *(const bf16x8*)(stg + row * 128 + ((rd_c ^ (row & 7)) << 4));
-          *(bf16x8*)(crow + (int64_t)(mt * 16 + 8 * i) * p.ldc) = o8;
+          *(bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc) = o8;
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));   // see the gate-residual path
@@ -469,8 +536,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     }
   }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = mrow + mt * 16;
+  for (int t = 0; t < NRT; ++t) {
+    const int m = mrow + t * RT;
     if (m >= p.M) continue;
     const float* grow = nullptr;
     if constexpr (EPI == EPI_GATE_RESIDUAL) {
@@ -481,13 +548,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       }
     }
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int n = ncol + nt * 16;
+    for (int v = 0; v < NV; ++v) {
+      const int n = ncol + v * (4 * NG);
       if (n >= p.N) continue;
-      f32x4 v = acc[mt][nt] + bias[nt];
+      f32x4 y4 = accv(t, v) + bias[v];
       if constexpr (EPI == EPI_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
+        for (int j = 0; j < 4; ++j) y4[j] = gelu_tanh(y4[j]);
       }
       if constexpr (EPI == EPI_GATE_RESIDUAL) {
         // y is rounded to bf16 first, like the reference's bf16 Linear output (FX.py:456,461,468)
@@ -495,15 +562,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
         f32x4 x = *(const f32x4*)xp;
         f32x4 g = grow ? *(const f32x4*)(grow + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(v[j])) * g[j];
+        for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(y4[j])) * g[j];
         *(f32x4*)xp = x;
       } else if constexpr (sizeof(OutT) == 2) {
         bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(y4[j]);
         *(bf16x4*)((bf16*)p.C + (int64_t)m * p.ldc + n) = o;
       } else {
-        *(f32x4*)((float*)p.C + (int64_t)m * p.ldc + n) = v;
+        *(f32x4*)((float*)p.C + (int64_t)m * p.ldc + n) = y4;
       }
     }
   }
@@ -553,11 +620,11 @@ void plan_split(int tiles, int nk, int& S, int& rem, double* cost = nullptr) {
   if (cost) *cost = best;
 }
 
-template <int EPI, typename OutT, int MT>
-int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
-  auto kern = gemm_bf16_kernel<EPI, OutT, MT>;
+template <int EPI, typename OutT, int MT, bool M32>
+int launch_shape(GemmParams p, const int64_t* a_koff, hipStream_t s) {
+  auto kern = gemm_bf16_kernel<EPI, OutT, MT, M32>;
   static bool attr_set = false;
-  const int smem = 4 * TILE_BYTES + 8 * 2048;   // two K-block buffers (128 KiB) + 2 KiB per wave for the epilogue
+  const int smem = 4 * TILE_BYTES + 8 * (M32 ? 32 : 16) * 128;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
@@ -575,9 +642,20 @@ int launch_mt(GemmParams p, const int64_t* a_koff, hipStream_t s) {
   const int nwg = p.units;
   int grid = (nwg + 7) / 8 * 8;                          // a multiple of 8 so that blockIdx & 7 is the XCD
   static const int persist = [] { const char* e = getenv("FLEXAM_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-  if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (128 KiB of LDS each)
+  if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (144 / 160 KiB of LDS each)
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, p, a_koff);
   return flexam_check_launch("flexam_gemm_bf16");
+}
+
+// FLEXAM_GEMM_M32=1 runs even tile heights on 32 x 32 MFMA tiles.  Off by default: correct (same tests), and faster in the
+// instruction-mix probe, but 3-4 % SLOWER than 16 x 16 tiles in the real kernel on every DiT shape (profiles/r1e_gemm_notes.txt #15).
+template <int EPI, typename OutT, int MT>
+int launch_mt(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
+  if constexpr (MT % 2 == 0) {
+    static const int m32 = [] { const char* e = getenv("FLEXAM_GEMM_M32"); return e ? atoi(e) : 0; }();
+    if (m32) return launch_shape<EPI, OutT, MT, true>(p, a_koff, s);
+  }
+  return launch_shape<EPI, OutT, MT, false>(p, a_koff, s);
 }
 
 // Tile height: rounds of 256 concurrently resident workgroups x relative cost of one tile (MT m-tiles of MFMA work
