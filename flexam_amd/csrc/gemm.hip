@@ -217,12 +217,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     const char* sbase = i < PA ? a_tile + ka * 2 : w_tile + kw * 2;
     const uint32_t voff = i < PA ? a_off[i] : w_off[i - PA];
     const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * 8192 : TILE_BYTES + (i - PA) * 8192) + wave * 1024;
-    uint32_t keep;
     if (ABLATE(p, 4) || (ABLATE(p, 16) && i >= PA)) return;      // 16: no W-tile staging (half the LDS-DMA)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(dst)
-                 : "memory");
+    // M0 (the LDS base of the DMA) is written and NOT restored: nothing else in this kernel uses it (gfx9+ LDS instructions do not;
+    // tools/isa_loopwaits.py lists any other M0 reader of the listing), and the save / restore pair was 2 of the 6 scalar
+    // instructions of every piece
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(dst) : "memory");
   };
   auto wait_barrier = [&](auto n_c) {                  // at most N of this wave's vector-memory operations still in flight, then barrier
     if (!ABLATE(p, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");

@@ -15,3 +15,7 @@ for m in re.finditer(r'^(_ZN\S*gemm_bf16_kernelI\S*):', src, re.M):
             waits = re.findall(r'(s_waitcnt [^\n;]*|s_barrier|scratch_\w+)', b)
             short = re.sub(r'_ZN12_GLOBAL__N_116gemm_bf16_kernelI|EEvNS_10GemmParamsEPKl', '', name)
             print(f"{short:22s} {lab:10s} mfma {nm} dma {nd}: " + ', '.join(w.strip() for w in waits))
+
+# the LDS-DMA statements write M0 without restoring it: report anything else that touches it
+other = [l.strip() for l in src.split('\n') if re.search(r'\bm0\b', l.split(';')[0]) and not re.match(r'\s*s_mov_b32 m0, s\d+', l)]
+print(f"other M0 users in the listing: {len(other)}" + ("" if not other else "  e.g. " + other[0]))
