@@ -101,6 +101,30 @@ def test_gemm_tail_split_k_is_exact_and_repeatable(H, m, n, k, monkeypatch):
     assert_bf16_close(out16, ref16.float(), ulps=2.0, atol=1e-2, msg="gelu epilogue after split-K")
 
 
+@pytest.mark.parametrize("m,n,k", [(16384, 2048, 256), (12000, 3072, 448), (23296, 3072, 192)])
+def test_gemm_many_units_per_workgroup_exact(H, m, n, k):
+    """More tiles than CUs: every persistent workgroup runs several units back to back, i.e. the path where the next unit's
+    first two K blocks are prefetched under the epilogue and waited for with counted vmcnt while the epilogue stores are still
+    in flight.  Integer data -> exact, for the bf16, fp32, GELU and gated-residual (per-row table) epilogues, three launches each."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    w = torch.randint(-2, 3, (n, k), generator=g).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    want = a @ w.t() + b
+    ad, wd, bd = bf(a).to(dev()), bf(w).to(dev()), b.to(dev())
+    gate = torch.randint(-2, 3, (4, n), generator=g).float()
+    rows = torch.randint(0, 4, (m,), generator=g, dtype=torch.int32)
+    x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+    ref16 = torch.nn.functional.gelu(want, approximate="tanh").to(BF)
+    for _ in range(3):
+        torch.testing.assert_close(H.gemm(ad, wd, bd).float().cpu(), want.to(BF).float(), rtol=0, atol=0)
+        torch.testing.assert_close(H.gemm(ad, wd, bd, out_dtype=torch.float32).cpu(), want, rtol=0, atol=0)
+        assert_bf16_close(H.gemm(ad, wd, bd, epilogue=H.EPI_GELU_TANH), ref16.float(), ulps=2.0, atol=1e-2, msg="gelu, many units")
+        x = x0.clone().to(dev())
+        H.gemm_gate_residual(ad, wd, bd, x, gate.to(dev()), rows.to(dev()))
+        torch.testing.assert_close(x.cpu(), x0 + want.to(BF).float() * gate[rows.long()], rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
 def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
     """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on
