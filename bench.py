@@ -97,7 +97,7 @@ def kernel_rooflines(eng, B, L, lc):
         # this rank's attention: all L tokens of nh / sp heads (the q|k|v it received in the last block's all-to-all)
         hg = nh // eng.sp_size
         full = ws["a2a_recv"].view(1, L, 3, hg, hd) if B == 1 else ws["a2a_full"]
-        t = time_kernel(lambda: hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"]), iters=8)
+        t = time_kernel(lambda: hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"], prescaled=True), iters=8)
         out["attn_self"] = dict(flops=4.0 * B * L * L * hg * hd, sec=t)
     else:
         if eng.sp_size == 1:
@@ -106,7 +106,7 @@ def kernel_rooflines(eng, B, L, lc):
         else:
             kv = ws["kv_cat"]                  # gathered K|V of the last block (same shape as every block's)
             k4, v4 = kv[:, :, 0:d].unflatten(2, (nh, hd)), kv[:, :, d:].unflatten(2, (nh, hd))
-        t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd)), iters=8)
+        t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd), prescaled=True), iters=8)
         out["attn_self"] = dict(flops=4.0 * B * lc * L * d, sec=t)
     t = time_kernel(lambda: hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv))
     out["gemm_qkv"] = dict(flops=2.0 * M * 3 * d * d, sec=t)
@@ -307,13 +307,13 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r1i_attn_traffic.json")
             if world == 1 and (args.frames, args.height, args.width) == (97, 512, 896) and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0> (self-attention, head_dim 128)", "achieved": a["tflops"],
+            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0, true> (self-attention, head_dim 128, q pre-scaled by its RMSNorm weight)", "achieved": a["tflops"],
                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                   "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r1i_pmc_attn_*)",
                                   "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"],
-                                  "launch_note": "one self-attention call = attn_fwd_kernel<0> over the full rounds of work units + "
-                                                 "attn_fwd_kernel<0> over the last partial round with its keys cut in 3 + attn_merge_kernel; "
-                                                 "launch_ms is the whole call, so rocprofv3 shows 2 attn_fwd_kernel<0> rows per call "
+                                  "launch_note": "one self-attention call = attn_fwd_kernel<0, true> over the full rounds of work units + "
+                                                 "attn_fwd_kernel<0, true> over the last partial round with its keys cut in 3 + attn_merge_kernel; "
+                                                 "launch_ms is the whole call, so rocprofv3 shows 2 attn_fwd_kernel<0, true> rows per call "
                                                  "(launch_ms = 2 x its AverageNs + the merge)"}
             result["kernels"] = {k: {"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1),
                                      "frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} for k, v in kern.items()}

@@ -40,6 +40,7 @@ struct AttnParams {
   int64_t o_bs, o_rs;
   int B, H, Lq, Lk;
   float scale_log2e;    // softmax_scale * log2(e)
+  int prescaled;        // q already carries that factor (see flexam_hip.h): the kernel instance with PRE = true runs
   int q_blocks;
   // split-KV (kv_splits > 1): workgroup (q block, head, split) covers key tiles [split*tiles_per_split, ..) and writes its
   // un-normalised O (fp32) and (running max, row sum) to the workspace; attn_merge_kernel combines the splits
@@ -106,7 +107,11 @@ template <int V>
 using IC = std::integral_constant<int, V>;
 constexpr float RESCALE_THR_LOG2 = 8.0f;
 
-template <int KIND>   // 0 = self-attention, 1 = short-context (text) attention: distinct profiler symbols
+// KIND: 0 = self-attention, 1 = short-context (text) attention: distinct profiler symbols.
+// PRE: q was multiplied by softmax_scale * log2(e) by its producer, BEFORE its one rounding to bf16 (in the DiT: folded into the
+// RMSNorm weight of q).  The scores then leave the MFMA chain in exp2 units, and with the row reference of the online softmax as
+// the chain's initial accumulator p = exp2(S') needs no FMA per score (16 of ~85 vector operations per 16 MFMAs).
+template <int KIND, bool PRE>
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 K tiles][4 V tiles], each a ring
   const int tid = threadIdx.x;
@@ -202,7 +207,14 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   for (int half = 0; half < 2; ++half)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vaddr[half][dt] = smem + V_RING + voff[half][dt];
-  // ds0 == 0 starts a new accumulation: the first MFMA takes a literal-zero C operand (no register zeroing)
+  // PRE: row reference of the online softmax in exp2 units (a lane holds 32 scores of ONE query row, so it is one value per lane,
+  // kept 16 times as the C operand that starts every S^T chain).  It is NOT the running maximum: it is only raised when a score
+  // exceeds it by more than 2^THR (deferred rescale).
+  f32x16 negref;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) negref[e] = 0.f;
+  float ref = 0.f;
+  // ds0 == 0 starts a new accumulation: from a literal-zero C operand (no register zeroing), or from -ref (PRE)
   // `ghalf` (half-tile index modulo 8) must be a compile-time constant at every call site
   auto qk_part = [&](auto ghalf_c, auto ds0_c, f32x16& sacc) {      // 4 K fragments ds0 .. ds0+3 of half `ghalf`
     constexpr int ghalf = decltype(ghalf_c)::value, ds0 = decltype(ds0_c)::value;
@@ -216,7 +228,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       const int ds = ds0 + i;
       if (ds == 0) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[ds], zero, 0, 0, 0);
+        if constexpr (PRE) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[ds], negref, 0, 0, 0);   // S' = s - ref
+        else sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[ds], zero, 0, 0, 0);
       } else {
         sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[ds], sacc, 0, 0, 0);
       }
@@ -293,32 +306,66 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
     for (int e = 1; e < 16; ++e) m = fmaxf(m, s_cur[e]);
     const float mx = pair_max(m);
-    // ---- deferred rescale (always taken for half 0): O, l AND the pending P(g-1) move to the new max
-    if (__any((mx - m_run) * c > RESCALE_THR_LOG2)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
-      m_run = m_new;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf_prev[ss][e] = f2bf(bf2f(pf_prev[ss][e]) * alpha);
-    }
-    // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
-    qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
-    pv_half(IC<((g8 + 7) & 7)>{});
-    const float mc = m_run * c;
     float psum = 0.f;
     bf16x8 pn[2];
+    if constexpr (PRE) {
+      // ---- deferred rescale (always taken for half 0, which sets the reference to the first row maximum): O, l, the pending
+      // P(g-1), the scores of this half and the already started chain of the next half all move to the new reference
+      if (g == 0 || __any(mx > RESCALE_THR_LOG2)) {            // mx is relative to ref
+        const float delta = g == 0 ? mx : fmaxf(mx, 0.f);
+        const float alpha = g == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        ref += delta;
+        l_run *= alpha;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], c, -mc));
-      psum += pv;
-      pn[e >> 3][e & 7] = f2bf(pv);
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf_prev[ss][e] = f2bf(bf2f(pf_prev[ss][e]) * alpha);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          s_cur[e] -= delta;
+          s_nxt[e] -= delta;
+          negref[e] = -ref;
+        }
+      }
+      // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
+      qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
+      pv_half(IC<((g8 + 7) & 7)>{});
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s_cur[e]);
+        psum += pv;
+        pn[e >> 3][e & 7] = f2bf(pv);
+      }
+    } else {
+      // ---- deferred rescale (always taken for half 0): O, l AND the pending P(g-1) move to the new max
+      if (__any((mx - m_run) * c > RESCALE_THR_LOG2)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o_acc[dt][e] *= alpha;
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf_prev[ss][e] = f2bf(bf2f(pf_prev[ss][e]) * alpha);
+      }
+      // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
+      qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
+      pv_half(IC<((g8 + 7) & 7)>{});
+      const float mc = m_run * c;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], c, -mc));
+        psum += pv;
+        pn[e >> 3][e & 7] = f2bf(pv);
+      }
     }
     l_run += psum;
     pf_prev[0] = pn[0];            // PV(g-1) above consumed the old value (program order)
@@ -331,7 +378,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < 12; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU (exp2 / fma / add / cvt)
+      __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 5, 0);   // VALU (exp2 / fma / add / cvt)
     }
   };
 
@@ -385,7 +432,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
           for (int e = 0; e < 4; ++e) ov[e] = o_acc[dt][4 * i + e];
           *(f32x4*)(orow + 32 * dt + 8 * i + 4 * h) = ov;
         }
-      if (h == 0) *(f32x2*)(p.ws_ml + row * 2) = (f32x2){m_run, l_tot};
+      if (h == 0) *(f32x2*)(p.ws_ml + row * 2) = (f32x2){PRE ? ref : m_run, l_tot};      // PRE: reference in exp2 units
     }
     return;
   }
@@ -421,7 +468,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
     f32x2 acc = {0.f, 0.f};
     for (int s = 0; s < p.kv_splits; ++s) {
       const f32x2 ml = *(const f32x2*)(p.ws_ml + (s * rows + row) * 2);
-      const float w = __builtin_amdgcn_exp2f((ml[0] - m) * p.scale_log2e);
+      const float w = __builtin_amdgcn_exp2f((ml[0] - m) * (p.prescaled ? 1.0f : p.scale_log2e));
       l += w * ml[1];
       const f32x2 o = *(const f32x2*)(p.ws_o + (s * rows + row) * HD + 2 * lane);
       acc += o * w;
@@ -452,7 +499,8 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o;
   p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
   p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk;
-  p.scale_log2e = softmax_scale * 1.4426950408889634f;
+  p.prescaled = softmax_scale < 0.f;                   // FLEXAM_ATTN_PRESCALED: q already carries softmax_scale * log2(e)
+  p.scale_log2e = p.prescaled ? 1.0f : softmax_scale * 1.4426950408889634f;
   p.q_blocks = (Lq + QBLK - 1) / QBLK;
   p.tiles_per_split = (tiles_all + kv_splits - 1) / kv_splits;
   p.kv_splits = (tiles_all + p.tiles_per_split - 1) / p.tiles_per_split;     // drop empty trailing splits
@@ -461,12 +509,14 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
-  auto kern = cross ? attn_fwd_kernel<1> : attn_fwd_kernel<0>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[cross]) {
+  auto kern = cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
+                    : (p.prescaled ? attn_fwd_kernel<0, true> : attn_fwd_kernel<0, false>);
+  static bool attr_set[4] = {false, false, false, false};
+  const int which = (cross ? 1 : 0) + (p.prescaled ? 2 : 0);
+  if (!attr_set[which]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return flexam_fail(FLEXAM_E_LAUNCH, "attn_fwd: cannot raise dynamic LDS to %d bytes", smem);
-    attr_set[cross] = true;
+    attr_set[which] = true;
   }
   const int units = B * H * p.q_blocks;
   FX_REQUIRE(split_from_unit >= 0 && split_from_unit <= units, FLEXAM_E_ARG, "attn_fwd: split_from_unit %d of %d units", split_from_unit, units);

@@ -122,15 +122,18 @@ class DiTEngine:
         self.time = [(small(l.weight), f32(l.bias)) for l in (m.time_embedding[0], m.time_embedding[2], m.time_projection[1])]
         self.dens = [(small(l.weight), f32(l.bias)) for l in (m.density_embedding[0], m.density_embedding[2], m.density_projection[1])]
         self.blocks = []
+        # softmax_scale * log2(e) rides on the RMSNorm weight of q: q leaves flexam_rmsnorm_rope in exp2 units with the one rounding
+        # to bf16 it always had, and the attention kernel's FLEXAM_ATTN_PRESCALED form needs no multiply per score (RoPE is linear)
+        qs = (self.hd ** -0.5) * 1.4426950408889634
         for blk in m.blocks:
             sa, ca = blk.self_attn, blk.cross_attn
             self.blocks.append(dict(
                 wqkv=torch.cat([bf(sa.q.weight), bf(sa.k.weight), bf(sa.v.weight)]),
                 bqkv=torch.cat([f32(sa.q.bias), f32(sa.k.bias), f32(sa.v.bias)]),
-                wo=bf(sa.o.weight), bo=f32(sa.o.bias), nq=f32(sa.norm_q.weight), nk=f32(sa.norm_k.weight),
+                wo=bf(sa.o.weight), bo=f32(sa.o.bias), nq=f32(sa.norm_q.weight) * qs, nk=f32(sa.norm_k.weight),
                 cwq=bf(ca.q.weight), cbq=f32(ca.q.bias),
                 cwkv=torch.cat([bf(ca.k.weight), bf(ca.v.weight)]), cbkv=torch.cat([f32(ca.k.bias), f32(ca.v.bias)]),
-                cwo=bf(ca.o.weight), cbo=f32(ca.o.bias), cnq=f32(ca.norm_q.weight), cnk=f32(ca.norm_k.weight),
+                cwo=bf(ca.o.weight), cbo=f32(ca.o.bias), cnq=f32(ca.norm_q.weight) * qs, cnk=f32(ca.norm_k.weight),
                 n3w=f32(blk.norm3.weight), n3b=f32(blk.norm3.bias),
                 w1=bf(blk.ffn[0].weight), b1=f32(blk.ffn[0].bias), w2=bf(blk.ffn[2].weight), b2=f32(blk.ffn[2].bias)))
         self.mod = torch.stack([f32(b.modulation)[0] for b in m.blocks])                       # [nl, 6, d]
@@ -362,12 +365,12 @@ class DiTEngine:
                 hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc,
                                  token_offset=tok0, head_dim=hdim)
                 kv = gather.finish()
-                hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4)
+                hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
             else:
                 hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
                 hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
                                  tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
-                hip.attn_fwd(q4, k4, v4, out=ao4)
+                hip.attn_fwd(q4, k4, v4, out=ao4, prescaled=True)
             hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             # cross-attention on the text context (K/V precomputed per clip)
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
@@ -375,7 +378,7 @@ class DiTEngine:
             hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
             hip.rmsnorm_rope(qc, p["cnq"], eps=self.eps)
             kv = cd["cross_kv"][i][rsel]
-            hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4)
+            hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
             hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
             # FFN
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
@@ -439,7 +442,7 @@ class DiTEngine:
         else:
             full = ws["a2a_full"]
             full.view(B, sp, lc, 3, hg * hd).copy_(ws["a2a_recv"].permute(1, 0, 2, 3, 4))
-        hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"])
+        hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"], prescaled=True)
         if B == 1:
             send2 = ws["a2a_out"].view(sp, 1, lc, hg * hd)
         else:

@@ -196,10 +196,14 @@ def attn_kv_splits(batch_heads: int, lq: int, lk: int, n_cu: int = 256) -> int:
 _ATTN_WS = {}
 
 
-def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_unit=None):
+ATTN_PRESCALED = -1.0      # flexam_hip.h FLEXAM_ATTN_PRESCALED
+
+
+def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_unit=None, prescaled=False):
     """q [B,Lq,H,128], k/v [B,Lk,H,128] bf16 (arbitrary batch/row strides, head dim contiguous and
     heads packed: stride(2) == 128) -> out [B,Lq,H,128] bf16.  kv_splits None: plan from attn_split_plan (only the last,
-    partial round of the CUs is split); an explicit kv_splits splits every unit unless split_from_unit is given too."""
+    partial round of the CUs is split); an explicit kv_splits splits every unit unless split_from_unit is given too.
+    prescaled: q already carries softmax_scale * log2(e) (folded into its producer before the rounding to bf16)."""
     B, Lq, H, D = q.shape
     Lk = k.shape[1]
     for t in (q, k, v):
@@ -207,7 +211,7 @@ def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_u
             raise RuntimeError("attn_fwd: heads must be packed along the row (stride(2) == head_dim, stride(3) == 1)")
     if out is None:
         out = torch.empty(B, Lq, H, D, device=q.device, dtype=BF16)
-    scale = softmax_scale if softmax_scale is not None else D ** -0.5
+    scale = ATTN_PRESCALED if prescaled else (softmax_scale if softmax_scale is not None else D ** -0.5)
     units = B * H * ((Lq + 255) // 256)
     if kv_splits is None:
         S, from_unit = attn_split_plan(B * H, Lq, Lk)

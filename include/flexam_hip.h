@@ -68,7 +68,11 @@ int flexam_gemm_set_workspace(void* ws, int64_t bytes);
  * q/k/v/o are [B, L, H, 128] views given by batch stride `*_bs` and row stride `*_rs` (elements);
  * head h starts at column h*128 of a row.  bf16 in/out, fp32 softmax/accumulate.
  * Replaces attention() -> flash_attn / sageattn / SDPA: FlexAM/models/attention_utils.py:43-233
- * (call sites wan_transformer3d_FlexAM.py:251-256 self, :367 cross). */
+ * (call sites wan_transformer3d_FlexAM.py:251-256 self, :367 cross).
+ * softmax_scale > 0: the scale of the formula.  softmax_scale = FLEXAM_ATTN_PRESCALED: the producer of q already multiplied it
+ * by scale * log2(e) before its one rounding to bf16 (the DiT engine folds that factor into the RMSNorm weight of q), so the
+ * scores are in exp2 units and the kernel saves one FMA per score: o = softmax2(q k^T) v with softmax2 built on 2^x. */
+#define FLEXAM_ATTN_PRESCALED (-1.0f)
 int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                     int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk,
                     int head_dim, float softmax_scale, void* stream);

@@ -263,6 +263,24 @@ def test_attention_strided_qkv_and_scale(H):
     assert_bf16_close(out, _attn_ref(q, k, v), ulps=2.0, atol=6e-3, msg="attention strided")
 
 
+@pytest.mark.parametrize("b,h,lq,lk,splits", [(1, 2, 300, 1111, None), (2, 1, 256, 640, 3), (1, 1, 77, 2055, 4)])
+def test_attention_prescaled_q_matches_oracle(H, b, h, lq, lk, splits):
+    """FLEXAM_ATTN_PRESCALED: q carries softmax_scale * log2(e) from its producer (one rounding to bf16 AFTER the multiply, as
+    when the factor sits in the RMSNorm weight); the kernel then works on exp2(q.k) with the row reference inside the MFMA
+    chain.  Oracle: softmax over the same rounded q, i.e. attention(q' / (scale log2 e), k, v).  Includes a late spike that
+    forces the reference to move, and the split-KV merge."""
+    g = torch.Generator().manual_seed(lq * 3 + lk)
+    qf = torch.randn(b, lq, h, 128, generator=g)
+    k = torch.randn(b, lk, h, 128, generator=g)
+    v = torch.randn(b, lk, h, 128, generator=g)
+    k[0, lk - 40, 0] = qf[0, 5, 0] * 4.0
+    c = 128 ** -0.5 * 1.4426950408889634
+    qs, k, v = bf(qf * c), bf(k), bf(v)
+    kw = {} if splits is None else dict(kv_splits=splits)
+    out = H.attn_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), prescaled=True, **kw)
+    assert_bf16_close(out, _attn_ref(qs.float() / c, k, v), ulps=2.0, atol=6e-3, msg="attention, pre-scaled q")
+
+
 def test_attention_online_softmax_rescale_spike(H):
     """Force the running max to jump at a late key tile (cdna guide rule 26): one key aligned with
     one query and scaled up, placed in the 5th tile; rows that see it must still be exact."""
