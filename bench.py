@@ -304,12 +304,12 @@ def main():
         if kern is not None:
             a = kern["attn_self"]
             traffic = None                       # HBM bytes per launch from the committed PMC passes (not collected live)
-            tpath = os.path.join(ROOT, "profiles", "r1i_attn_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r1m_attn_traffic.json")
             if world == 1 and (args.frames, args.height, args.width) == (97, 512, 896) and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0, true> (self-attention, head_dim 128, q pre-scaled by its RMSNorm weight)", "achieved": a["tflops"],
                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
-                                  "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r1i_pmc_attn_*)",
+                                  "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r1m_pmc_attn_*)",
                                   "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"],
                                   "launch_note": "one self-attention call = attn_fwd_kernel<0, true> over the full rounds of work units + "
                                                  "attn_fwd_kernel<0, true> over the last partial round with its keys cut in 3 + attn_merge_kernel; "

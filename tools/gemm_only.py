@@ -27,5 +27,5 @@ else:
     q, k, v = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (24, 128)) for i in range(3))
     o = torch.empty(2, L, 24, 128, dtype=BF, device=dev)
     for _ in range(3):
-        H.attn_fwd(q, k, v, out=o)
+        H.attn_fwd(q, k, v, out=o, prescaled=True)      # the form the DiT engine runs
 torch.cuda.synchronize()
