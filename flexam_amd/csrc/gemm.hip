@@ -647,7 +647,7 @@ int launch_shape(GemmParams p, const int64_t* a_koff, hipStream_t s) {
 }
 
 // FLEXAM_GEMM_M32=1 runs even tile heights on 32 x 32 MFMA tiles.  Off by default: correct (same tests), and faster in the
-// instruction-mix probe, but 3-4 % SLOWER than 16 x 16 tiles in the real kernel on every DiT shape (profiles/r1e_gemm_notes.txt #15).
+// instruction-mix probe and 10 % fewer cycles in the real kernel, but the power-capped clock falls 13 %: 3-4 % SLOWER on every DiT shape (notes #15).
 template <int EPI, typename OutT, int MT>
 int launch_mt(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
   if constexpr (MT % 2 == 0) {
