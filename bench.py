@@ -288,8 +288,11 @@ def main():
             "config": {"workload": f"Wan2.2-Fun-5B-FLEXAM DiT denoise step, {args.frames}x{args.height}x{args.width}, "
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
                                    f"random-init bf16 weights, synthetic conditioning (BASELINE configs[1])",
-                       "parallelism": (f"cfg{eng_cfg} x sp{eng_sp}: CFG rows split first (no per-block traffic), then token-chunk sequence "
-                                       f"parallel, {eng_mode} exchange around self-attention (RCCL)") if world > 1 else "single GPU",
+                       "parallelism": ((f"cfg{eng_cfg} x sp{eng_sp}: one CFG row per rank" + (", no per-block traffic" if eng_sp == 1 else
+                                        f", token-chunk sequence parallel inside each half, {eng_mode} exchange around self-attention (RCCL)"))
+                                       if eng_cfg == 2 else
+                                       f"cfg1 x sp{eng_sp}: CFG pair batched on every rank, token-chunk sequence parallel over all ranks, "
+                                       f"{eng_mode} exchange around self-attention (RCCL)") if world > 1 else "single GPU",
                        "layers": cfg["num_layers"]},
             "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
             "vae_decode_sec": vae_sec, "vae_encode_sec_per_stream": enc_stream_sec, "conditioning_encode_sec_8_streams": enc_sec,

@@ -223,16 +223,20 @@ class WanTransformer3DModel_FlexAM(nn.Module):
     def enable_multi_gpus_inference(self, group=None, cfg_parallel=None):
         """Multi-GPU inference over `group` (default: the world group).  Stands in for the reference's missing
         FlexAM/dist + xfuser USP (wan_transformer3d_FlexAM.py:801-815).  Layout (flexam_amd/dist.py):
-          * cfg_parallel (default: on when the group size is even): the two classifier-free-guidance rows are
-            independent until the guidance combine (PIPE.py:926-928), so the first split is by CFG row -- no
-            per-block traffic at all;
-          * inside each half, contiguous token chunks per rank with one RCCL all-gather of K/V per block;
+          * cfg_parallel: the two classifier-free-guidance rows are independent until the guidance combine
+            (PIPE.py:926-928), so a split by CFG row has no per-block traffic at all.  Default: on for TWO ranks (no exchange
+            inside the blocks), and for larger even groups only when the all-to-all exchange is not available (heads not
+            divisible by the ranks, or FLEXAM_SP_MODE=allgather).  With the all-to-all ("ulysses") exchange, N >= 4 ranks run
+            pure sequence parallelism with the CFG pair batched on every rank: on the xGMI full mesh each of the N-1 peer links
+            then carries 1/N of a rank's q|k|v, half of what a link carries when 2 x N/2 ranks only talk inside their half;
+          * inside a sequence-parallel group, contiguous token chunks per rank and one exchange around self-attention per block;
           * one all-gather of the head output per step over the whole group."""
         import torch.distributed as dist
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
         if cfg_parallel is None:
-            cfg_parallel = world % 2 == 0
+            a2a = os.environ.get("FLEXAM_SP_MODE", "ulysses") == "ulysses" and self.num_heads % world == 0
+            cfg_parallel = world % 2 == 0 and (world == 2 or not a2a)
         if cfg_parallel and world % 2:
             raise ValueError("cfg_parallel needs an even number of ranks")
         if cfg_parallel:

@@ -16,20 +16,27 @@ from oracle import dit as O
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, ret, cfg_parallel):
+def _wide_cfg():
+    """DIT_TINY with four 128-wide heads: the all-to-all exchange needs heads % ranks == 0."""
+    return dict(O.DIT_TINY, dim=512, num_heads=4)
+
+
+def _worker(rank, world, port, ret, cfg_parallel, wide=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from flexam_amd import Wan2_2FunControlPipeline_FlexAM, Wan2_2Transformer3DModel_FlexAM
         from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
-        cfg = dict(O.DIT_TINY)
+        cfg = _wide_cfg() if wide else dict(O.DIT_TINY)
         kw = dict(cfg)
         kw.pop("eps")
         m = Wan2_2Transformer3DModel_FlexAM(**kw)
         m.load_state_dict(C.dit_weights(cfg, 7), strict=True)
         m = m.to("cuda:0")
         m.enable_multi_gpus_inference(cfg_parallel=cfg_parallel)
+        if wide:
+            assert m.engine().sp_mode == "ulysses" and m.engine().sp_size == world and m.engine().cfg_size == 1
         case = C.dit_case(cfg, 41, per_token_t=True)                    # L = 192 + 64 = 256 -> 128 tokens per rank
         d = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
         out = m(**d).float().cpu()
@@ -45,11 +52,13 @@ def _worker(rank, world, port, ret, cfg_parallel):
 
 
 @pytest.mark.parametrize("world,cfg_parallel,mode", [(2, False, "ulysses"), (2, False, "allgather"), (2, True, "ulysses"),
-                                                     (4, True, "ulysses"), (4, True, "allgather")])
+                                                     (4, True, "ulysses"), (4, True, "allgather"), (4, False, "ulysses"),
+                                                     (4, None, "ulysses"), (2, None, "ulysses")])
 def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel, mode, monkeypatch):
     """(2, False): pure sequence parallel (CFG pair batched, B = 2 per rank); (2, True): CFG-parallel, no per-block traffic;
-    (4, True): 2 CFG rows x 2 token chunks -- the layout bench.py uses at 4 and 8 GPUs.  mode: the exchange around
-    self-attention -- "ulysses" (all-to-all over heads, the default) or "allgather" (K|V all-gather)."""
+    (4, True): 2 CFG rows x 2 token chunks; (4, False): four token chunks, CFG pair batched -- what the default (None)
+    picks at 4 and 8 GPUs with the all-to-all exchange, while two ranks default to the CFG split.  mode: the exchange
+    around self-attention -- "ulysses" (all-to-all over heads, the default) or "allgather" (K|V all-gather)."""
     monkeypatch.setenv("FLEXAM_SP_MODE", mode)             # inherited by the spawned ranks
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -86,3 +95,48 @@ def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel, mo
     print(f"multi-rank vs single-process HIP: rel-rms {rel:.2e}")
     assert rel < 2e-3
     assert bool(torch.isfinite(lat0).all())
+
+
+def test_four_ranks_default_layout_is_pure_ulysses_and_matches_single_process(monkeypatch):
+    """Four heads, four ranks, default layout: pure sequence parallelism with the all-to-all exchange and the CFG pair batched on
+    every rank (what bench.py runs at 4 and 8 GPUs).  No reference golden for this width: the check is against the single-process
+    HIP result of the same model and inputs, for the DiT forward and a 2-step sampler run."""
+    monkeypatch.delenv("FLEXAM_SP_MODE", raising=False)
+    world = 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, None, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    out0, lat0 = ret[0]
+    for r in range(1, world):
+        torch.testing.assert_close(out0, ret[r][0], rtol=0, atol=0)
+        torch.testing.assert_close(lat0, ret[r][1], rtol=0, atol=0)
+    from flexam_amd import Wan2_2FunControlPipeline_FlexAM, Wan2_2Transformer3DModel_FlexAM
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    cfg = _wide_cfg()
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    m.load_state_dict(C.dit_weights(cfg, 7), strict=True)
+    m = m.to("cuda:0")
+    case = C.dit_case(cfg, 41, per_token_t=True)
+    d = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    single = m(**d).float().cpu()
+    rel = ((out0 - single).pow(2).mean().sqrt() / single.pow(2).mean().sqrt()).item()
+    sc = C.sampler_case(cfg)
+    pipe = Wan2_2FunControlPipeline_FlexAM(transformer=m)
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], sc["mask_pixels"])
+    lat = pipe(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+               num_inference_steps=2, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond,
+               output_type="latent").videos.float().cpu()
+    rel_l = ((lat0 - lat).pow(2).mean().sqrt() / lat.pow(2).mean().sqrt()).item()
+    print(f"4-rank pure ulysses vs single process: DiT rel-rms {rel:.2e}, sampler latents rel-rms {rel_l:.2e}")
+    assert rel < 2e-3 and rel_l < 2e-3
