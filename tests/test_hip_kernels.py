@@ -316,6 +316,27 @@ def test_attention_linearity_in_v_full_size(H):
     assert_bf16_close(o1[:, rows], ref, ulps=2.0, atol=4e-3, msg="attention full size rows")
 
 
+def test_attention_prescaled_full_size_properties_and_rows(H):
+    """The DiT's form of the kernel at the BASELINE shape (L = 11648, B = 2 x 24 heads as in one self-attention call, so that the
+    tail split and its merge run): constant V comes back, and 64 spot-checked query rows per batch row match the oracle evaluated on
+    the same pre-scaled, once-rounded q."""
+    g = torch.Generator().manual_seed(8)
+    l, h = 11648, 24
+    c = 128 ** -0.5 * 1.4426950408889634
+    qf = torch.randn(2, l, h, 128, generator=g)
+    qs = bf(qf * c).to(dev())
+    k = bf(torch.randn(2, l, h, 128, generator=g)).to(dev())
+    ones = torch.ones(2, l, h, 128, dtype=BF, device=dev())
+    out = H.attn_fwd(qs, k, ones, prescaled=True)
+    torch.testing.assert_close(out.float(), torch.ones_like(out).float(), rtol=0, atol=2.0 ** -7)
+    v = bf(torch.randn(2, l, h, 128, generator=g)).to(dev())
+    o = H.attn_fwd(qs, k, v, prescaled=True).float()
+    rows = torch.arange(0, l, l // 64)[:64]
+    heads = [0, 11, 23]
+    ref = _attn_ref(qs[:, rows][:, :, heads].float().cpu() / c, k[:, :, heads].cpu(), v[:, :, heads].cpu())
+    assert_bf16_close(o[:, rows][:, :, heads], ref, ulps=2.0, atol=4e-3, msg="pre-scaled attention, full size rows")
+
+
 # ----------------------------------------------------------------------------- row kernels
 def test_ln_modulate_two_row_table(H):
     from oracle import dit as O
