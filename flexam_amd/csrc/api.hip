@@ -25,6 +25,24 @@ int flexam_check_launch(const char* what) {
   return FLEXAM_OK;
 }
 
+int flexam_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev < FLEXAM_MAX_DEVICES ? dev : FLEXAM_MAX_DEVICES - 1;
+}
+
+int flexam_num_cus() {
+  static int cus[FLEXAM_MAX_DEVICES] = {};               // filled on first use per device (benign race: same value)
+  const int dev = flexam_current_device();
+  if (cus[dev] == 0) {
+    int n = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) n = prop.multiProcessorCount / 8 * 8;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 extern "C" const char* flexam_last_error(void) { return g_err; }
 extern "C" int flexam_version(void) { return FLEXAM_HIP_VERSION; }
 extern "C" const char* flexam_arch(void) { return "gfx950"; }

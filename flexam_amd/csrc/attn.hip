@@ -511,12 +511,13 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
   auto kern = cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
                     : (p.prescaled ? attn_fwd_kernel<0, true> : attn_fwd_kernel<0, false>);
-  static bool attr_set[4] = {false, false, false, false};
+  static bool attr_set[FLEXAM_MAX_DEVICES][4] = {};      // per device and kernel instance
   const int which = (cross ? 1 : 0) + (p.prescaled ? 2 : 0);
-  if (!attr_set[which]) {
+  const int dev = flexam_current_device();
+  if (!attr_set[dev][which]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return flexam_fail(FLEXAM_E_LAUNCH, "attn_fwd: cannot raise dynamic LDS to %d bytes", smem);
-    attr_set[which] = true;
+    attr_set[dev][which] = true;
   }
   const int units = B * H * p.q_blocks;
   FX_REQUIRE(split_from_unit >= 0 && split_from_unit <= units, FLEXAM_E_ARG, "attn_fwd: split_from_unit %d of %d units", split_from_unit, units);

@@ -24,6 +24,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 // host: record an error string and return the code (thread-local; see api.hip)
 int flexam_fail(int code, const char* fmt, ...);
 int flexam_check_launch(const char* what);
+// host: per-device state (one process may drive several GPUs): index of the current device, clamped to the table size, and
+// its CU count rounded down to a multiple of 8 (one workgroup per CU, blockIdx & 7 = XCD)
+#define FLEXAM_MAX_DEVICES 16
+int flexam_current_device();
+int flexam_num_cus();
 
 #define FX_REQUIRE(cond, code, ...)                     \
   do {                                                  \

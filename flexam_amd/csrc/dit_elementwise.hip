@@ -446,6 +446,35 @@ inline int grid_for(int64_t total, int block) {
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
+// ------------------------------------------------------------------------------------------
+// Content fingerprint of a buffer: out[0] += sum of its 32-bit words, out[1] += sum of word * (word index + 1), both mod 2^64.
+// Host logic uses it to recognise step-invariant conditioning that the reference sampler re-materialises with torch.cat on
+// every step (PIPE.py:850-886).  Integer sums: the order of the atomic adds does not matter.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restrict__ w, int64_t n_words, const uint8_t* __restrict__ tail,
+                                                       int n_tail, unsigned long long* __restrict__ out) {
+  unsigned long long s0 = 0, s1 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long v = w[i];
+    s0 += v;
+    s1 += v * (unsigned long long)(i + 1);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int j = 0; j < n_tail; ++j) {
+      s0 += tail[j];
+      s1 += (unsigned long long)tail[j] * (unsigned long long)(n_words + 1 + j);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, s0);
+    atomicAdd(out + 1, s1);
+  }
+}
+
 }  // namespace
 
 #define DISPATCH_VPT(C, ...)                                                          \
@@ -616,4 +645,13 @@ extern "C" int flexam_axpby_f32(float* y, float a, const float* x, float b, int6
   FX_REQUIRE(y && x && n > 0 && n % 4 == 0, FLEXAM_E_ARG, "axpby_f32: null pointer or n %% 4 != 0");
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, a, x, b, n / 4);
   return flexam_check_launch("flexam_axpby_f32");
+}
+
+extern "C" int flexam_checksum(const void* data, int64_t nbytes, uint64_t* out2, void* stream) {
+  FX_REQUIRE(data && out2 && nbytes > 0, FLEXAM_E_ARG, "checksum: null pointer or empty buffer");
+  FX_REQUIRE((uintptr_t)data % 4 == 0 && (uintptr_t)out2 % 8 == 0, FLEXAM_E_ARG, "checksum: data must be 4-byte, out 8-byte aligned");
+  const int64_t words = nbytes / 4;
+  hipLaunchKernelGGL(checksum_kernel, dim3(grid_for(words > 0 ? words : 1, 256)), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)data,
+                     words, (const uint8_t*)data + words * 4, (int)(nbytes - words * 4), (unsigned long long*)out2);
+  return flexam_check_launch("flexam_checksum");
 }

@@ -577,25 +577,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   }   // tile loop
 }
 
-// scratch for the tail split-K, registered by the host side (flexam_gemm_set_workspace): [256 ints | slabs of 256 x 256 fp32]
+// scratch for the tail split-K, handed in by the caller with every launch (nothing is retained between calls):
+// [256 ints | slabs of 256 x 256 fp32]
 struct GemmWorkspace {
   int* counters = nullptr;
   float* slabs = nullptr;
   int64_t n_slabs = 0;
 };
-GemmWorkspace g_ws;
 
-int num_cus() {
-  static const int n = [] {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount / 8 * 8;
-    }
-    return cus;
-  }();
-  return n;
-}
+int num_cus() { return flexam_num_cus(); }
 
 // Tail split-K plan: `rem` = tiles of the last, partial round of the CUs.  Cutting each of them into S K slices turns that
 // round into ceil(rem*S/G) passes of 1/S of a tile, and every pass pays the hand-off: parking 256 KiB of partial sums and the
@@ -603,7 +593,7 @@ int num_cus() {
 // in K blocks of main loop (1.15 us each): 13 + 9 S.  S (<= 8, slabs must fit the workspace) minimises the sum; with
 // K = 3072 (48 K blocks) the hand-off eats the gain and nothing is split, with K = 14336 the tail shrinks to ~0.5 tile
 // times.  `cost` = resulting length of the tail in tile times (1.0 without a split).
-void plan_split(int tiles, int nk, int& S, int& rem, double* cost = nullptr) {
+void plan_split(const GemmWorkspace& g_ws, int tiles, int nk, int& S, int& rem, double* cost = nullptr) {
   const int G = num_cus();
   static const int enabled = [] { const char* e = getenv("FLEXAM_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
   rem = tiles % G;
@@ -620,19 +610,20 @@ void plan_split(int tiles, int nk, int& S, int& rem, double* cost = nullptr) {
 }
 
 template <int EPI, typename OutT, int MT, bool M32>
-int launch_shape(GemmParams p, const int64_t* a_koff, hipStream_t s) {
+int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
   auto kern = gemm_bf16_kernel<EPI, OutT, MT, M32>;
-  static bool attr_set = false;
+  static bool attr_set[FLEXAM_MAX_DEVICES] = {};          // per device: the attribute belongs to the device's copy of the code object
   const int smem = 4 * TILE_BYTES + 8 * (M32 ? 32 : 16) * 128;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave
-  if (!attr_set) {
+  const int dev = flexam_current_device();
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   p.tiles_m = (p.M + 32 * MT - 1) / (32 * MT);
   const int tiles = p.tiles_m * p.tiles_n;
   int split_s, rem;
-  plan_split(tiles, p.K / BK, split_s, rem);
+  plan_split(g_ws, tiles, p.K / BK, split_s, rem);
   p.split_s = split_s;
   p.split_full = split_s > 1 ? tiles - rem : tiles;
   p.units = p.split_full + (split_s > 1 ? rem * split_s : 0);
@@ -649,17 +640,17 @@ int launch_shape(GemmParams p, const int64_t* a_koff, hipStream_t s) {
 // FLEXAM_GEMM_M32=1 runs even tile heights on 32 x 32 MFMA tiles.  Off by default: correct (same tests), and faster in the
 // instruction-mix probe and 10 % fewer cycles in the real kernel, but the power-capped clock falls 13 %: 3-4 % SLOWER on every DiT shape (notes #15).
 template <int EPI, typename OutT, int MT>
-int launch_mt(const GemmParams& p, const int64_t* a_koff, hipStream_t s) {
+int launch_mt(const GemmParams& p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
   if constexpr (MT % 2 == 0) {
     static const int m32 = [] { const char* e = getenv("FLEXAM_GEMM_M32"); return e ? atoi(e) : 0; }();
-    if (m32) return launch_shape<EPI, OutT, MT, true>(p, a_koff, s);
+    if (m32) return launch_shape<EPI, OutT, MT, true>(p, g_ws, a_koff, s);
   }
-  return launch_shape<EPI, OutT, MT, false>(p, a_koff, s);
+  return launch_shape<EPI, OutT, MT, false>(p, g_ws, a_koff, s);
 }
 
 // Tile height: rounds of 256 concurrently resident workgroups x relative cost of one tile (MT m-tiles of MFMA work
 // plus a fixed part for the W side, barriers and the epilogue); FLEXAM_GEMM_MT=8..4 forces a shape (tuning only).
-int pick_mt(int M, int tiles_n, int nk) {
+int pick_mt(const GemmWorkspace& g_ws, int M, int tiles_n, int nk) {
   const char* e = getenv("FLEXAM_GEMM_MT");
   const int forced = e ? atoi(e) : 0;
   if (forced >= 4 && forced <= 8) return forced;
@@ -670,16 +661,28 @@ int pick_mt(int M, int tiles_n, int nk) {
     const int tiles = (int)((long)((M + 32 * mt - 1) / (32 * mt)) * tiles_n);
     int S, rem;
     double tail;
-    plan_split(tiles, nk, S, rem, &tail);
+    plan_split(g_ws, tiles, nk, S, rem, &tail);
     const double cost = (tiles / G + tail) * (mt + 1.25);
     if (cost < best_cost * 0.97) { best_cost = cost; best = mt; }      // a smaller tile must win by > 3 %
   }
   return best;
 }
 
+// caller's scratch -> workspace view; too small or NULL = no split-K
+GemmWorkspace make_ws(void* ws, int64_t bytes) {
+  GemmWorkspace g;
+  if (ws && bytes >= 1024 + (int64_t)256 * BN * 4) {
+    g.counters = (int*)ws;                                // 256 ints, zero on entry (the kernels leave them zero)
+    g.slabs = (float*)((char*)ws + 1024);
+    g.n_slabs = (bytes - 1024) / ((int64_t)256 * BN * 4);
+  }
+  return g;
+}
+
 template <int EPI, typename OutT>
-int launch(const GemmParams& p_, const int64_t* a_koff, hipStream_t s) {
+int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_koff, hipStream_t s) {
   GemmParams p = p_;
+  const GemmWorkspace g_ws = make_ws(ws, ws_bytes);
   {
     const char* g = getenv("FLEXAM_GEMM_GM");
     p.gm = g ? atoi(g) : 4;                  // 4 tile-rows x (32 / 4) tile-columns resident per XCD measured best (profiles/r1e notes)
@@ -689,12 +692,12 @@ int launch(const GemmParams& p_, const int64_t* a_koff, hipStream_t s) {
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
   p.debug = dbg ? atoi(dbg) : 0;
 #endif
-  switch (pick_mt(p.M, p.tiles_n, p.K / BK)) {
-    case 7: return launch_mt<EPI, OutT, 7>(p, a_koff, s);
-    case 6: return launch_mt<EPI, OutT, 6>(p, a_koff, s);
-    case 5: return launch_mt<EPI, OutT, 5>(p, a_koff, s);
-    case 4: return launch_mt<EPI, OutT, 4>(p, a_koff, s);
-    default: return launch_mt<EPI, OutT, 8>(p, a_koff, s);
+  switch (pick_mt(g_ws, p.M, p.tiles_n, p.K / BK)) {
+    case 7: return launch_mt<EPI, OutT, 7>(p, g_ws, a_koff, s);
+    case 6: return launch_mt<EPI, OutT, 6>(p, g_ws, a_koff, s);
+    case 5: return launch_mt<EPI, OutT, 5>(p, g_ws, a_koff, s);
+    case 4: return launch_mt<EPI, OutT, 4>(p, g_ws, a_koff, s);
+    default: return launch_mt<EPI, OutT, 8>(p, g_ws, a_koff, s);
   }
 }
 
@@ -702,13 +705,13 @@ int launch(const GemmParams& p_, const int64_t* a_koff, hipStream_t s) {
 
 extern "C" int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, int out_f32,
-                                const int64_t* a_koff, void* stream) {
+                                const int64_t* a_koff, void* ws, int64_t ws_bytes, void* stream) {
   FX_REQUIRE(A && W && C, FLEXAM_E_ARG, "gemm: null pointer");
   FX_REQUIRE(M > 0 && N > 0 && K > 0, FLEXAM_E_SHAPE, "gemm: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
   FX_REQUIRE(K % BK == 0, FLEXAM_E_SHAPE, "gemm: K=%ld must be a multiple of %d (pad on the host)", (long)K, BK);
   FX_REQUIRE(N % 4 == 0 && ldc % 4 == 0, FLEXAM_E_SHAPE, "gemm: N=%ld and ldc=%ld must be multiples of 4", (long)N, (long)ldc);
   FX_REQUIRE(lda % 8 == 0 && ldw % 8 == 0, FLEXAM_E_SHAPE, "gemm: lda/ldw must be multiples of 8 elements (16-byte rows)");
-  FX_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) % 16 == 0, FLEXAM_E_ARG, "gemm: pointers must be 16-byte aligned");
+  FX_REQUIRE(((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)ws) % 16 == 0, FLEXAM_E_ARG, "gemm: pointers must be 16-byte aligned");
   FX_REQUIRE(epilogue == EPI_NONE || epilogue == EPI_GELU, FLEXAM_E_ARG, "gemm: unknown epilogue %d", epilogue);
   GemmParams p{};
   p.A = (const bf16*)A; p.W = (const bf16*)W; p.C = C; p.bias = bias;
@@ -717,15 +720,15 @@ extern "C" int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64
   hipStream_t s = (hipStream_t)stream;
   if (out_f32) {
     FX_REQUIRE(epilogue == EPI_NONE, FLEXAM_E_ARG, "gemm: f32 output supports no activation epilogue");
-    return launch<EPI_NONE, float>(p, a_koff, s);
+    return launch<EPI_NONE, float>(p, ws, ws_bytes, a_koff, s);
   }
-  return epilogue == EPI_GELU ? launch<EPI_GELU, bf16>(p, a_koff, s) : launch<EPI_NONE, bf16>(p, a_koff, s);
+  return epilogue == EPI_GELU ? launch<EPI_GELU, bf16>(p, ws, ws_bytes, a_koff, s) : launch<EPI_NONE, bf16>(p, ws, ws_bytes, a_koff, s);
 }
 
 extern "C" int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                               float* X, int64_t ldx, const float* gate, int64_t gate_ld,
                                               const int32_t* gate_row, int64_t rows_per_batch, int64_t M, int64_t N,
-                                              int64_t K, const int64_t* a_koff, void* stream) {
+                                              int64_t K, const int64_t* a_koff, void* ws, int64_t ws_bytes, void* stream) {
   FX_REQUIRE(A && W && X, FLEXAM_E_ARG, "gemm_gate_residual: null pointer");
   FX_REQUIRE(M > 0 && N > 0 && K > 0, FLEXAM_E_SHAPE, "gemm_gate_residual: empty problem");
   FX_REQUIRE(K % BK == 0 && N % 4 == 0 && ldx % 4 == 0, FLEXAM_E_SHAPE, "gemm_gate_residual: K%%64, N%%4, ldx%%4 required");
@@ -737,17 +740,6 @@ extern "C" int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const 
   p.tiles_n = (int)((N + BN - 1) / BN);   // tiles_m depends on the tile height launch() picks
   p.X = X; p.ldx = ldx; p.gate = gate; p.gate_ld = gate_ld; p.gate_row = gate_row;
   p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
-  return launch<EPI_GATE_RESIDUAL, bf16>(p, a_koff, (hipStream_t)stream);
-}
-
-extern "C" int flexam_gemm_set_workspace(void* ws, int64_t bytes) {
-  if (!ws || bytes < 1024 + 256 * BN * 4) {
-    g_ws = GemmWorkspace{};
-    return 0;
-  }
-  FX_REQUIRE((uintptr_t)ws % 16 == 0, FLEXAM_E_ARG, "gemm_set_workspace: pointer must be 16-byte aligned");
-  g_ws.counters = (int*)ws;                              // 256 ints, must be zero on entry (the kernels leave them zero)
-  g_ws.slabs = (float*)((char*)ws + 1024);
-  g_ws.n_slabs = (bytes - 1024) / ((int64_t)256 * BN * 4);
-  return 0;
+  FX_REQUIRE((uintptr_t)ws % 16 == 0, FLEXAM_E_ARG, "gemm_gate_residual: workspace must be 16-byte aligned");
+  return launch<EPI_GATE_RESIDUAL, bf16>(p, ws, ws_bytes, a_koff, (hipStream_t)stream);
 }

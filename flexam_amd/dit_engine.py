@@ -98,6 +98,11 @@ class DiTEngine:
         self._ws = {}
         self._angles = None
         self.cond = None
+        self.n_conditioning = 0                     # set_conditioning runs so far (tests: the per-clip work is hoisted)
+        # AdaLN tables of all layers are built in one launch per step ([layers, R, 6, C] fp32, R = distinct timesteps x batch);
+        # beyond this many bytes (masks with fractional edges: hundreds of distinct timesteps) ONE [R, 6, C] table is rebuilt
+        # per layer instead -- the reference's own footprint is [B, L, 6, C] per step (wan_transformer3d_FlexAM.py:944)
+        self.table_limit = int(os.environ.get("FLEXAM_ADALN_TABLE_BYTES", str(1 << 30)))
         self._pack()
 
     # ------------------------------------------------------------------ weights
@@ -121,23 +126,19 @@ class DiTEngine:
                     (bf(m.text_embedding[2].weight), f32(m.text_embedding[2].bias))]
         self.time = [(small(l.weight), f32(l.bias)) for l in (m.time_embedding[0], m.time_embedding[2], m.time_projection[1])]
         self.dens = [(small(l.weight), f32(l.bias)) for l in (m.density_embedding[0], m.density_embedding[2], m.density_projection[1])]
-        self.blocks = []
-        # softmax_scale * log2(e) rides on the RMSNorm weight of q: q leaves flexam_rmsnorm_rope in exp2 units with the one rounding
-        # to bf16 it always had, and the attention kernel's FLEXAM_ATTN_PRESCALED form needs no multiply per score (RoPE is linear)
-        qs = (self.hd ** -0.5) * 1.4426950408889634
+        # per-layer parameter packs live on the block modules (`_Block.packed()`: fused q|k|v and cross k|v buffers that the
+        # parameters alias, softmax_scale * log2(e) folded into norm_q for the FLEXAM_ATTN_PRESCALED attention form); a block that
+        # was replaced (`transformer.blocks[i] = wrapper`, comfyui_nodes.py:67-71) or whose forward / attention forward was
+        # re-bound (wan_transformer3d_FlexAM.py:807-815) has no pack here and is CALLED as a module by run()
+        self.blocks, self.block_modules = [], list(m.blocks)
         for blk in m.blocks:
-            sa, ca = blk.self_attn, blk.cross_attn
-            self.blocks.append(dict(
-                wqkv=torch.cat([bf(sa.q.weight), bf(sa.k.weight), bf(sa.v.weight)]),
-                bqkv=torch.cat([f32(sa.q.bias), f32(sa.k.bias), f32(sa.v.bias)]),
-                wo=bf(sa.o.weight), bo=f32(sa.o.bias), nq=f32(sa.norm_q.weight) * qs, nk=f32(sa.norm_k.weight),
-                cwq=bf(ca.q.weight), cbq=f32(ca.q.bias),
-                cwkv=torch.cat([bf(ca.k.weight), bf(ca.v.weight)]), cbkv=torch.cat([f32(ca.k.bias), f32(ca.v.bias)]),
-                cwo=bf(ca.o.weight), cbo=f32(ca.o.bias), cnq=f32(ca.norm_q.weight) * qs, cnk=f32(ca.norm_k.weight),
-                n3w=f32(blk.norm3.weight), n3b=f32(blk.norm3.bias),
-                w1=bf(blk.ffn[0].weight), b1=f32(blk.ffn[0].bias), w2=bf(blk.ffn[2].weight), b2=f32(blk.ffn[2].bias)))
-        self.mod = torch.stack([f32(b.modulation)[0] for b in m.blocks])                       # [nl, 6, d]
-        self.mdens = torch.stack([f32(b.modulation_density)[0] for b in m.blocks])            # [nl, 2, d]
+            blk = getattr(blk, "_orig_mod", blk)          # torch.compile(block) wraps the same module: nothing to compile in a HIP-call block
+            native = hasattr(blk, "packed") and hasattr(blk, "pristine") and blk.pristine()
+            self.blocks.append(blk.packed() if native else None)
+        self.fused = all(p is not None for p in self.blocks)
+        nat = [p for p in self.blocks if p is not None]
+        self.mod = torch.stack([p["mod"] for p in nat]) if self.fused else None                # [nl, 6, d]
+        self.mdens = torch.stack([p["mdens"] for p in nat]) if self.fused else None           # [nl, 2, d]
         self.hmod, self.hmdens = f32(m.head.modulation), f32(m.head.modulation_density)       # [1,2,d], [1,1,d]
         self.cnn = None
         if m.cnn_conv1 is not None:
@@ -230,7 +231,7 @@ class DiTEngine:
         hmid = hip.gemm(ctx_in, self.txt[0][0], self.txt[0][1], epilogue=hip.EPI_GELU_TANH)
         ctx = hip.gemm(hmid, self.txt[1][0], self.txt[1][1])
         cross_kv = []
-        for p in self.blocks:
+        for p in (self.blocks if self.fused else ()):
             kv = hip.gemm(ctx, p["cwkv"], p["cbkv"])
             hip.rmsnorm_rope(kv[:, :d], p["cnk"], eps=self.eps)
             cross_kv.append(kv.view(B, self.text_len, 2 * d))
@@ -246,7 +247,9 @@ class DiTEngine:
             self._angles = self.model._rope_angles()
         cos, sin = rope_tables(grid, L, self.hd, self._angles)
         self.cond = dict(B=B, nb=nb, L=L, lvid=lvid, ref_len=ref_len, latent_shape=(cx, f, h, w), patch_a=patch_a, ref_tok=ref_tok,
-                         cross_kv=cross_kv, dens_emb=dens_emb, dens0=dens0, cos=cos.to(dev), sin=sin.to(dev))
+                         cross_kv=cross_kv, dens_emb=dens_emb, dens0=dens0, cos=cos.to(dev), sin=sin.to(dev),
+                         ctx=ctx.view(B, self.text_len, d), grid=grid)
+        self.n_conditioning += 1
         return self.cond
 
     # ------------------------------------------------------------------ workspace
@@ -276,7 +279,7 @@ class DiTEngine:
         return e, e0.view(R, 6, d)
 
     def run(self, x: torch.Tensor, t_rows: torch.Tensor, row_index: Optional[torch.Tensor], rows_per_batch: int,
-            only_row: Optional[int] = None, teacache=None, cond_flag: bool = True) -> torch.Tensor:
+            only_row: Optional[int] = None, teacache=None, cond_flag: bool = True, rows_shared: bool = False) -> torch.Tensor:
         """x [Bx, 48, F, H, W] (Bx = B, or 1 when all rows share the latent); t_rows [R] distinct
         timesteps with R = B * rows_per_batch table rows (rows of batch b are b*rows_per_batch ..);
         row_index int32 [B * L] global table row per token, or None (then token (b, l) uses row b).
@@ -317,10 +320,20 @@ class DiTEngine:
 
         # ---- timestep embedding on the distinct rows + AdaLN tables of all blocks and the head
         R = t_rows.numel()
-        e, e0 = self.embed_time(t_rows)
-        tab = torch.empty(self.nl, R, 6, d, device=dev, dtype=F32)
-        hip.mod_table(self.mod, e0, tab, rows_per_batch, 0b010010, self.mdens, dens0.contiguous() if dens0 is not None else None,
-                      0xFF1FF0 if dens0 is not None else -1)
+        if rows_shared and R > rows_per_batch:     # every sample carries the same timestep rows (the sampler's CFG pair): embed once
+            e1, e01 = self.embed_time(t_rows[:rows_per_batch])
+            reps = R // rows_per_batch
+            e, e0 = e1.repeat(reps, 1), e01.repeat(reps, 1, 1)
+        else:
+            e, e0 = self.embed_time(t_rows)
+        per_layer = (not self.fused) or self.nl * R * 6 * d * 4 > self.table_limit
+        dens0c = dens0.contiguous() if dens0 is not None else None
+        if per_layer:
+            tab = None
+            tab1 = torch.empty(1, R, 6, d, device=dev, dtype=F32)
+        else:
+            tab = torch.empty(self.nl, R, 6, d, device=dev, dtype=F32)
+            hip.mod_table(self.mod, e0, tab, rows_per_batch, 0b010010, self.mdens, dens0c, 0xFF1FF0 if dens0 is not None else -1)
         htab = torch.empty(1, R, 2, d, device=dev, dtype=F32)
         e2 = e.unsqueeze(1).expand(R, 2, d).contiguous()
         hd_dens = dens_emb.reshape(B, 1, d).contiguous() if dens_emb is not None else None
@@ -342,11 +355,21 @@ class DiTEngine:
         if teacache is not None:
             key = "previous_residual_cond" if cond_flag else "previous_residual_uncond"
             if not calc:                                   # skipped step: x += residual of the last computed step (FX.py:1003-1006)
-                hip.axpby(xres, 1.0, getattr(teacache, key), 1.0)
+                res = getattr(teacache, key)
+                n = xres.shape[0]                          # `previous_residual[-x.size(0):]`: a cfg-skipped (B = 1) forward takes the
+                res = res[-n:] if res.shape[0] >= n else res.repeat(n // res.shape[0], 1)      # conditional row of a B = 2 residual
+                hip.axpby(xres, 1.0, res.contiguous(), 1.0)
             else:
                 ori = xres.clone()
-        for i, p in enumerate(self.blocks if calc else ()):
-            T = tab[i]
+        if calc and not self.fused:
+            self._run_block_modules(xres, B, lc, e0, row_index, rows_per_batch, dens0, t_rows, rsel)
+        for i, p in enumerate(self.blocks if (calc and self.fused) else ()):
+            if per_layer:                                  # one table, rebuilt per layer (bounded memory, see table_limit)
+                hip.mod_table(self.mod[i:i + 1], e0, tab1, rows_per_batch, 0b010010, self.mdens[i:i + 1], dens0c,
+                              0xFF1FF0 if dens0 is not None else -1)
+                T = tab1[0]
+            else:
+                T = tab[i]
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
             if sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back (flexam_amd/dist.py)
@@ -392,6 +415,29 @@ class DiTEngine:
         hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=H[:, 0], scale=H[:, 1], row_index=row_index, rows_per_batch=rpb)
         hip.gemm(hbuf, self.head_w, self.head_b, out=head)
         return head.view(B, lc, -1)
+
+    # ------------------------------------------------------------------ block-level seam
+    def _run_block_modules(self, xres, B, lc, e0, row_index, rows_per_batch, dens0, t_rows, rsel):
+        """Some block is not a pristine native block (replaced, wrapped, or with a re-bound forward): every block is CALLED
+        with the reference's block signature (wan_transformer3d_FlexAM.py:1053-1089) on [B, L, C] fp32 tensors.  The AdaLN
+        input is materialised per token like the reference's e0 ([B, L, 6, C]); native blocks find its compact form in the
+        `_flexam_rows` attribute."""
+        if self.sp_size > 1:
+            raise NotImplementedError("replaced / re-bound blocks are called as whole-sequence modules: not with sequence parallelism")
+        cd, d = self.cond, self.dim
+        if row_index is not None:
+            e_full = e0[row_index.long()].view(B, lc, 6, d)
+        else:
+            e_full = e0.view(B, 6, d)
+        e_full._flexam_rows = (e0, row_index, rows_per_batch)
+        grid_sizes = torch.tensor([list(cd["grid"])] * B, dtype=torch.long)
+        seq_lens = torch.tensor([lc] * B, dtype=torch.long)
+        x3 = xres.view(B, lc, d)
+        ctx = cd["ctx"][rsel]
+        for blk in self.block_modules:
+            out = blk(x3, e=e_full, density_emb=dens0, seq_lens=seq_lens, grid_sizes=grid_sizes, freqs=self.model.freqs, context=ctx,
+                      context_lens=None, dtype=BF16, t=t_rows)
+            x3.copy_(out.view(B, lc, d))
 
     # ------------------------------------------------------------------ TeaCache
     @staticmethod

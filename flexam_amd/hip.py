@@ -22,9 +22,8 @@ _SIGNATURES = {
     "flexam_arch": ([], c_char_p),
     "flexam_last_error": ([], c_char_p),
     "flexam_device_check": ([], c_int),
-    "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P], c_int),
-    "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P], c_int),
-    "flexam_gemm_set_workspace": ([_P, _L], c_int),
+    "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _L, _P], c_int),
+    "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
     "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
@@ -37,6 +36,7 @@ _SIGNATURES = {
     "flexam_unpatchify": ([_P, _L, _L, _I, _I, _I, _I, _P, _I, _P], c_int),
     "flexam_cfg_euler_blend": ([_P, _P, _L, _L, _F, _F, _P, _P, _P, _I, _I, _I, _I, _P], c_int),
     "flexam_axpby_f32": ([_P, _F, _P, _F, _L, _P], c_int),
+    "flexam_checksum": ([_P, _L, _P, _P], c_int),
     "flexam_cfg_velocity": ([_P, _P, _L, _L, _F, _P, _I, _I, _I, _I, _P], c_int),
     "flexam_lincomb_f32": ([_P, _L, _I, _P, _P, _P], c_int),
     "flexam_mask_blend_f32": ([_P, _P, _P, _I, _L, _P], c_int),
@@ -120,15 +120,17 @@ def device_check():
 
 # ----------------------------------------------------------------------------- GEMM
 _GEMM_WS = {}
+GEMM_WS_BYTES = 1024 + 256 * 256 * 256 * 4          # FLEXAM_GEMM_WS_BYTES
 
 
-def _gemm_workspace(device):
-    """Registers the tail split-K scratch (64 MiB + counters) once per process; see flexam_gemm_set_workspace."""
-    if "buf" not in _GEMM_WS:
-        buf = torch.zeros(1024 + 256 * 256 * 256 * 4, device=device, dtype=torch.uint8)
-        _check(lib().flexam_gemm_set_workspace(buf.data_ptr(), buf.numel()), "flexam_gemm_set_workspace")
-        _GEMM_WS["buf"] = buf
-    return _GEMM_WS["buf"]
+def _gemm_workspace(device, stream: int):
+    """Tail split-K scratch (64 MiB + zeroed arrival counters) handed to every GEMM call: one buffer per
+    (device, stream), so launches that can run concurrently never share slabs or counters."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
+    buf = _GEMM_WS.get(key)
+    if buf is None:
+        buf = _GEMM_WS[key] = torch.zeros(GEMM_WS_BYTES, device=device, dtype=torch.uint8)
+    return buf
 
 
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=None, m=None, k=None):
@@ -145,9 +147,10 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=No
     om, on, ldc = _rows(out)
     if (om, on) != (M, wn):
         raise RuntimeError(f"gemm: out shape {tuple(out.shape)} != ({M}, {wn})")
-    _gemm_workspace(a.device)
+    st = _stream()
+    ws = _gemm_workspace(a.device, st)
     _check(lib().flexam_gemm_bf16(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(out), ldc, M, wn, K, epilogue,
-                                  1 if out.dtype == F32 else 0, _ptr(a_koff, I64), _stream()), "flexam_gemm_bf16")
+                                  1 if out.dtype == F32 else 0, _ptr(a_koff, I64), ws.data_ptr(), ws.numel(), st), "flexam_gemm_bf16")
     return out
 
 
@@ -160,10 +163,11 @@ def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0
     if (a_koff is None and (ak != K or am != M)) or xn != N:
         raise RuntimeError("gemm_gate_residual: shape mismatch")
     gate_ld = gate.stride(0) if gate is not None else 0
-    _gemm_workspace(a.device)
+    st = _stream()
+    ws = _gemm_workspace(a.device, st)
     _check(lib().flexam_gemm_bf16_gate_residual(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(x, F32), ldx,
                                                 _ptr(gate, F32), gate_ld, _ptr(gate_row, I32), rows_per_batch, M, N, K,
-                                                _ptr(a_koff, I64), _stream()), "flexam_gemm_bf16_gate_residual")
+                                                _ptr(a_koff, I64), ws.data_ptr(), ws.numel(), st), "flexam_gemm_bf16_gate_residual")
     return x
 
 
@@ -223,11 +227,11 @@ def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_u
                                      B, H, Lq, Lk, D, scale, _stream()), "flexam_attn_fwd")
         return out
     n = units - from_unit
-    key = (q.device, S, n)
-    if key not in _ATTN_WS:                     # per-shape scratch, reused across launches (stream-ordered)
-        _ATTN_WS.clear()
-        _ATTN_WS[key] = (torch.empty(S, n, 256, D, device=q.device, dtype=F32), torch.empty(S, n, 256, 2, device=q.device, dtype=F32))
-    ws_o, ws_ml = _ATTN_WS[key]
+    st = _stream()
+    slot, key = (q.device, st), (S, n)
+    if _ATTN_WS.get(slot, (None,))[0] != key:   # per-shape scratch per (device, stream), reused across launches (stream-ordered)
+        _ATTN_WS[slot] = (key, torch.empty(S, n, 256, D, device=q.device, dtype=F32), torch.empty(S, n, 256, 2, device=q.device, dtype=F32))
+    _, ws_o, ws_ml = _ATTN_WS[slot]
     _check(lib().flexam_attn_fwd_splitkv(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1),
                                          _ptr(v, BF16), v.stride(0), v.stride(1), _ptr(out, BF16), out.stride(0), out.stride(1),
                                          B, H, Lq, Lk, D, scale, S, from_unit, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()),
@@ -340,6 +344,15 @@ def axpby(y, a, x, b):
         raise RuntimeError("axpby: contiguous tensors of equal shape required")
     _check(lib().flexam_axpby_f32(_ptr(y, F32), a, _ptr(x, F32), b, y.numel(), _stream()), "flexam_axpby_f32")
     return y
+
+
+def checksum(t: torch.Tensor):
+    """Content fingerprint (two 64-bit sums over the raw words) of a device tensor; synchronises (host logic only)."""
+    t = t.contiguous()
+    out = torch.zeros(2, device=t.device, dtype=I64)
+    _check(lib().flexam_checksum(_ptr(t), t.numel() * t.element_size(), _ptr(out), _stream()), "flexam_checksum")
+    a, b = out.tolist()
+    return a, b
 
 
 def cfg_velocity(tok_uncond, tok_cond, tok0, guidance, out):

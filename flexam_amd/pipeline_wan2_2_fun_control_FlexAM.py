@@ -88,6 +88,10 @@ class Wan2_2FunControlPipeline_FlexAM:
         self._guidance_scale = 6.0
         self._num_timesteps = 0
         self._state = None
+        # The reference builds the per-token timesteps as `mask.to(weight_dtype) * t` (PIPE.py:679,891-898): with the bf16
+        # checkpoint both the mask and the product are bf16, so the DiT embeds bf16-ROUNDED timesteps (multiples of 4 in
+        # [512, 1024)).  None = follow the transformer's dtype like the reference does; torch.float32 = exact timesteps.
+        self.timestep_dtype = None
 
     # ------------------------------------------------------------------ housekeeping (reference surface)
     def to(self, device):
@@ -190,9 +194,12 @@ class Wan2_2FunControlPipeline_FlexAM:
         nrow = len(context)
         dens = torch.full((nrow,), float(density), device=dev, dtype=F32)
         eng.set_conditioning(context, y, cond.ref_latents, cond.additional_control, dens, (c, f, h, w), shared=True)
+        tr._cond_key = None                        # the engine's per-clip state no longer belongs to a forward() call
         cd = eng.cond
         # per-token timestep pattern: t * mask[::2, ::2] (PIPE.py:891-898); ref tokens take the last value
-        sub = mask[0, 0, :, ::2, ::2].reshape(-1)
+        tdt = self.timestep_dtype if self.timestep_dtype is not None else tr.dtype
+        tdt = tdt if tdt in (torch.bfloat16, torch.float16) else F32
+        sub = mask[0, 0, :, ::2, ::2].reshape(-1).to(tdt).to(F32)               # the reference's mask lives in weight_dtype
         seq = torch.cat([sub[-1:].repeat(cd["ref_len"]), sub]) if cd["ref_len"] else sub
         uniq, inv = torch.unique(seq, return_inverse=True)
         U = uniq.numel()
@@ -209,7 +216,7 @@ class Wan2_2FunControlPipeline_FlexAM:
         self._num_timesteps = len(self.scheduler.timesteps)
         tr.num_inference_steps = num_inference_steps
         self._state = dict(latents=latents[0].contiguous(), known=known[0].contiguous() if pinned else None,
-                           mask=mask[0, 0].contiguous() if pinned else None, uniq=uniq.to(F32), row_index=row_index, U=U, nrow=nrow,
+                           mask=mask[0, 0].contiguous() if pinned else None, uniq=uniq.to(F32), tdt=tdt, row_index=row_index, U=U, nrow=nrow,
                            cfg=cfg, guidance=float(guidance_scale), ref_len=cd["ref_len"], shape=(c, f, h, w))
         return self._state
 
@@ -220,27 +227,34 @@ class Wan2_2FunControlPipeline_FlexAM:
         eng = tr.engine()
         tr.current_steps = i
         t = float(self.scheduler.timesteps[i])
-        t_rows = (st["uniq"] * t).repeat(st["nrow"])
+        t_rows = (st["uniq"].to(st["tdt"]) * t).to(F32).repeat(st["nrow"])        # rounded like `mask.to(weight_dtype) * t`
         skip_uncond = (st["cfg"] and tr.cfg_skip_ratio is not None and tr.num_inference_steps is not None
                        and i >= tr.num_inference_steps * (1 - tr.cfg_skip_ratio))
         c, f, h, w = st["shape"]
         if skip_uncond and eng.cfg_size == 1:
             # cfg_skip (cfg_optimization.py:5-37): only the conditional row runs and is duplicated, so
             # uncond + g (cond - uncond) = cond
+            # TeaCache keeps counting on these B = 1 forwards exactly as the reference's forward does (FX.py:977-1006,1119-1122)
             U = st["U"]
             head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows[:U], st["row_index"][: st["row_index"].numel() // st["nrow"]],
-                                             U, only_row=st["nrow"] - 1))
+                                             U, only_row=st["nrow"] - 1, teacache=tr.teacache))
+            self._teacache_tick(tr.teacache)
             return self._sampler_update(i, head[0], None)
         tc = tr.teacache
-        head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"], teacache=tc))
-        if tc is not None:
-            tc.cnt += 1
-            if tc.cnt == tc.num_steps:
-                tc.reset()
+        head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"], teacache=tc, rows_shared=True))
+        self._teacache_tick(tc)
         # head: [rows, L, 192] with rows = (uncond, cond) after the gather, whatever the parallel layout
         if skip_uncond:                                  # CFG-parallel ranks: both rows were computed anyway, take cond
             return self._sampler_update(i, head[1], None)
         return self._sampler_update(i, head[0], head[1] if st["cfg"] else None)
+
+    @staticmethod
+    def _teacache_tick(tc):
+        """FX.py:1119-1122: one count per conditional forward; the cache resets itself after `num_steps` of them."""
+        if tc is not None:
+            tc.cnt += 1
+            if tc.cnt == tc.num_steps:
+                tc.reset()
 
     def _sampler_update(self, i: int, tok_uncond, tok_cond):
         """PIPE.py:926-934: CFG combine, scheduler.step, masked blend with the known latents.  Flow-match Euler: ONE

@@ -32,13 +32,21 @@ class FlowMatchEulerDiscreteScheduler:
 
     def set_timesteps(self, num_inference_steps: int = None, device=None, sigmas=None, mu=None, timesteps=None):
         n = self.config.num_train_timesteps
+        custom_t = None
         if sigmas is None:
-            sigmas = np.linspace(self.sigma_max * n, self.sigma_min * n, num_inference_steps) / n
+            if timesteps is not None:                             # custom timesteps: sigmas = t / n, the given timesteps are kept
+                custom_t = np.asarray([float(v) for v in timesteps], dtype=np.float64)
+                sigmas = custom_t / n
+            else:
+                if num_inference_steps is None:
+                    raise ValueError("set_timesteps needs num_inference_steps, sigmas or timesteps")
+                sigmas = np.linspace(self.sigma_max * n, self.sigma_min * n, num_inference_steps) / n
         sigmas = np.asarray(sigmas, dtype=np.float64)
         s = self.config.shift
         sigmas = s * sigmas / (1 + (s - 1) * sigmas)              # shifted again at inference (double shift)
         sig = torch.from_numpy(sigmas).to(torch.float32)
-        self.timesteps = (sig * n).to(device) if device is not None else sig * n
+        ts = torch.from_numpy(custom_t).to(torch.float32) if custom_t is not None else sig * n
+        self.timesteps = ts.to(device) if device is not None else ts
         self.sigmas = torch.cat([sig, torch.zeros(1)])
         self._step_index = None
 

@@ -6,9 +6,12 @@
  *   - every function returns 0 (FLEXAM_OK) or a negative FLEXAM_E_* code; flexam_last_error()
  *     returns the message of the last failure on the calling thread;
  *   - all pointers are DEVICE pointers unless a comment says host; the caller (PyTorch-ROCm in
- *     flexam_amd/hip.py) owns every buffer, the library never allocates, frees or retains one;
+ *     flexam_amd/hip.py) owns every buffer, the library never allocates, frees or retains one:
+ *     scratch (GEMM split-K slabs, split-KV attention partials) is an argument of the call that uses it;
  *   - `stream` is a hipStream_t; calls are asynchronous and ordered on it, no hidden syncs,
- *     safe to capture into a hipGraph;
+ *     safe to capture into a hipGraph; calls on different streams / devices are independent as long
+ *     as they are given different scratch buffers (the only process-global state is a per-device
+ *     "kernel attribute set" flag table and the per-device CU count);
  *   - bf16 = IEEE bfloat16 (torch.bfloat16); "f32 table row" arguments are row pointers of
  *     small fp32 tables selected per token through an int32 row index ("two-row
  *     modulation").
@@ -22,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FLEXAM_HIP_VERSION 1
+#define FLEXAM_HIP_VERSION 2
 #define FLEXAM_OK 0
 #define FLEXAM_E_ARG (-1)
 #define FLEXAM_E_SHAPE (-2)
@@ -42,10 +45,17 @@ int flexam_device_check(void);          /* FLEXAM_E_ARCH unless the current devi
  * K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0 (pad on the host).  a_koff (optional, [K/64] int64,
  * device): element offset added to every A row base for K block kb instead of kb*64 -- the
  * implicit-GEMM form of the VAE's causal convolutions (one entry per (tap, 64-channel slice)).
- * Replaces nn.Linear -> cuBLAS: FlexAM/models/wan_transformer3d_FlexAM.py:242-244,261,363-365,
+ * ws / ws_bytes (optional): scratch for the tail split-K -- the tiles of the last, partial round of the CUs are cut along K so
+ * that all CUs work; partial sums are reduced in a fixed order by the slice that finishes last (deterministic).  Device
+ * memory, 16-byte aligned, first 1 KiB ZEROED once by the caller (arrival counters; every launch leaves them zero), then
+ * slabs of 256 KiB; FLEXAM_GEMM_WS_BYTES covers every shape.  NULL / too small: the GEMM never splits.  The buffer is used
+ * only by this launch (stream-ordered): launches that may run concurrently (other streams, other devices) need their own.
+ * Replaces nn.Linear -> cuBLAS (+ its workspace): FlexAM/models/wan_transformer3d_FlexAM.py:242-244,261,363-365,
  * 370,415-416,487,626-636 and Conv3d/Conv2d -> cuDNN: FlexAM/models/wan_vae3_8.py:39-47,94,99. */
+#define FLEXAM_GEMM_WS_BYTES (1024 + 256 * 262144)
 int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
-                     int64_t M, int64_t N, int64_t K, int epilogue, int out_f32, const int64_t* a_koff, void* stream);
+                     int64_t M, int64_t N, int64_t K, int epilogue, int out_f32, const int64_t* a_koff, void* ws,
+                     int64_t ws_bytes, void* stream);
 
 /* X[m,n] += bf16(A.W^T + bias)[m,n] * gate[row(m), n]   (fp32 residual stream updated in place)
  * row(m) = gate_row[m] if gate_row else m / rows_per_batch; gate == NULL means gate = 1.
@@ -55,14 +65,7 @@ int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, con
 int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* X,
                                    int64_t ldx, const float* gate, int64_t gate_ld, const int32_t* gate_row,
                                    int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, const int64_t* a_koff,
-                                   void* stream);
-
-/* Optional scratch for the GEMMs' tail split-K (the tiles of the last, partial round of the CUs are cut along K so that all CUs
- * work; partial sums are reduced in a fixed order by the slice that finishes last -> deterministic).  `ws`: device memory,
- * 16-byte aligned, first 1 KiB ZEROED by the caller (arrival counters; kernels leave them zero), then slabs of 256 KiB; 64 MiB
- * + 1 KiB covers every shape.  ws = NULL unregisters (GEMMs then never split).  One registration per process (one GPU per
- * process); launches that use it must be ordered on one stream at a time. */
-int flexam_gemm_set_workspace(void* ws, int64_t bytes);
+                                   void* ws, int64_t ws_bytes, void* stream);
 
 /* Flash attention forward, head_dim 128, non-causal, keys [0, Lk): o = softmax(q k^T * scale) v.
  * q/k/v/o are [B, L, H, 128] views given by batch stride `*_bs` and row stride `*_rs` (elements);
@@ -154,6 +157,11 @@ int flexam_mask_blend_f32(float* x, const float* known, const float* mask, int C
 /* y[i] = a*x[i] + b*y[i], fp32, n % 4 == 0.  TeaCache bookkeeping: residual = x_after_blocks - x_before and
  * x += cached residual on skipped steps (wan_transformer3d_FlexAM.py:1003-1051). */
 int flexam_axpby_f32(float* y, float a, const float* x, float b, int64_t n, void* stream);
+
+/* out2[0] += sum of the buffer's 32-bit words, out2[1] += sum of word * (index + 1), mod 2^64 (out2: two uint64 the caller
+ * zeroed).  A content key for the step-invariant conditioning tensors that the reference sampler re-creates with torch.cat on
+ * every step (pipeline_wan2_2_fun_control_FlexAM.py:850-886): the DiT's per-clip work is redone only when it changes. */
+int flexam_checksum(const void* data, int64_t nbytes, uint64_t* out2, void* stream);
 
 /* Channels-last helpers around the implicit-GEMM convolutions (cnn-block: wan_transformer3d_FlexAM.py:
  * 680-705,869-881; VAE decoder: wan_vae3_8.py).  A conv input is a spatially zero-padded bf16 image

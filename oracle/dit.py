@@ -262,7 +262,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, context:
         taps.update(x_embed=x.clone(), e=e, e0=e0, dens0=dens0, context=ctx)
     calc = True if teacache is None else _teacache_decide(teacache, e0)
     if not calc:
-        x = x + teacache["residual"]                                              # FX.py:1003-1006
+        x = x + teacache["residual"][-x.size(0):]                                 # FX.py:1003-1006 (a B = 1 cfg-skipped call takes the cond row)
     else:
         x_in = x
         for i in range(nl):
