@@ -1,0 +1,247 @@
+"""Parity at MODEL WIDTH (Wan2.2-Fun-5B-FLEXAM: d = 3072, 24 heads x 128, ffn 14336, text 512 x 4096; VAE dec_dim 256,
+dim_mult (1, 2, 4, 4)) -- the other GPU tests use dim 256 models.  HIP path through the C ABI vs the fp32 oracle
+(oracle/dit.py block_forward / dit_forward = FX.py:422-472, 817-1123; oracle/vae.py = VAE.py:677-728, 820-849) on seeded
+inputs, at sizes the oracle finishes in tens of seconds on the GPU box's host cores.
+
+Stated tolerance (north_star): bf16 GEMM / attention operands, fp32 accumulation, softmax, norms, modulation and
+residual stream -> relative RMS <= 1.5e-2 and PSNR >= 40 dB on block / model outputs; integer-valued GEMMs are bit exact."""
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import dit as O
+from oracle import vae as OV
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+CFG_5B = dict(O.DIT_5B)
+
+
+def stats(got, want, what, rel_max=1.5e-2, psnr_min=40.0, peak=None):
+    got, want = got.float().cpu(), want.float().cpu()
+    rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    p = C.psnr(got, want, peak=peak)
+    print(f"{what}: rel-rms {rel:.3e}, psnr {p:.1f} dB")
+    assert rel <= rel_max and p >= psnr_min, f"{what}: rel-rms {rel:.3e}, psnr {p:.1f} dB"
+
+
+# ----------------------------------------------------------------------------- one block at d = 3072
+def _block_problem(grid, seed=3):
+    d, f, nh, T = CFG_5B["dim"], CFG_5B["ffn_dim"], CFG_5B["num_heads"], CFG_5B["text_len"]
+    one = dict(CFG_5B, num_layers=1)
+    shapes = {k[len("blocks.0."):]: v for k, v in O.dit_param_shapes(one).items() if k.startswith("blocks.0.")}
+    bw = O.seeded_state_dict(shapes, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    L = grid[0] * grid[1] * grid[2]
+    x = torch.randn(2, L, d, generator=g)
+    rows = torch.randn(2, 2, 6, d, generator=g) * 0.3          # two distinct AdaLN rows per sample (frame 0: t = 0, rest: t)
+    sel = torch.zeros(L, dtype=torch.long)
+    sel[grid[1] * grid[2]:] = 1
+    dens0 = torch.randn(2, 2, d, generator=g) * 0.3
+    ctx = torch.randn(2, T, d, generator=g)
+    return bw, x, rows, sel, dens0, ctx, L
+
+
+@pytest.mark.parametrize("grid", [(26, 8, 14), (26, 16, 28)])
+def test_full_width_block_vs_oracle(grid):
+    """WanAttentionBlock.forward (FX.py:422-472) at d = 3072 / 24 heads / ffn 14336 / 512 text rows, CFG pair, per-token
+    two-row AdaLN input + density: L = 2912, and the BASELINE config-2 token count L = 11648 (26 x 16 x 28 incl. the
+    reference-image slab).  Checks the module seam (`_Block.forward`) AND the engine's fused-epilogue block body."""
+    from flexam_amd.wan_transformer3d_FlexAM import _Block
+    from flexam_amd.rope import rope_angle_table
+    from flexam_amd import hip
+    bw, x, rows, sel, dens0, ctx, L = _block_problem(grid)
+    d, nh = CFG_5B["dim"], CFG_5B["num_heads"]
+    e0 = rows[:, sel]                                           # [B, L, 6, C] as the reference materialises it
+    want = O.block_forward({"b." + k: v for k, v in bw.items()}, "b", x, e0, dens0, grid, O.rope_angles(1024, 128), ctx, nh)
+    blk = _Block(d, CFG_5B["ffn_dim"], nh, 1e-6)
+    blk.load_state_dict(bw, strict=True)
+    blk = blk.cuda().to(BF)                                     # the checkpoint dtype of the real model
+    bw_b = {k: v.to(BF).float() for k, v in bw.items()}
+    want_b = O.block_forward({"b." + k: v for k, v in bw_b.items()}, "b", x, e0, dens0, grid, O.rope_angles(1024, 128), ctx, nh) \
+        if L <= 4096 else None
+    # (1) module seam with the compact AdaLN rows (what the model hands to a wrapped block) ...
+    e_dev = e0.cuda()
+    idx = (sel.repeat(2) + torch.arange(2).repeat_interleave(L) * 2).to(torch.int32).cuda()
+    e_dev._flexam_rows = (rows.reshape(4, 6, d).cuda().contiguous(), idx, 2)
+    kw = dict(density_emb=dens0.cuda(), seq_lens=torch.tensor([L, L]), grid_sizes=torch.tensor([list(grid)] * 2),
+              freqs=rope_angle_table(1024, 128), context=ctx.cuda(), context_lens=None)
+    out = blk(x.cuda(), e=e_dev, **kw)
+    stats(out, want, f"block module L={L} (bf16 weights vs fp32-weight oracle)")
+    if want_b is not None:
+        stats(out, want_b, f"block module L={L} (vs oracle on the bf16-rounded weights)", rel_max=1.0e-2)
+        # ... and with a plain per-token tensor (no compact rows attached)
+        out2 = blk(x.cuda(), e=e0.cuda(), **kw)
+        stats(out2, out, "per-token e tensor vs compact rows", rel_max=1e-5, psnr_min=90.0)
+    # (2) the engine's fused block body (GEMM epilogues: GELU, fp32 gated residual, split-K tails) on the same problem
+    pk = blk.packed()
+    B = 2
+    xres = x.reshape(B * L, d).cuda().clone()
+    tab = torch.empty(1, 4, 6, d, device="cuda", dtype=torch.float32)
+    hip.mod_table(pk["mod"].unsqueeze(0), rows.reshape(4, 6, d).cuda().contiguous(), tab, 2, 0b010010, pk["mdens"].unsqueeze(0),
+                  dens0.cuda().contiguous(), 0xFF1FF0)
+    T = tab[0]
+    from flexam_amd.rope import rope_tables
+    cos, sin = (t.cuda() for t in rope_tables(grid, L, 128, rope_angle_table(1024, 128)))
+    hbuf = hip.ln_modulate(xres, eps=1e-6, shift=T[:, 0], scale=T[:, 1], row_index=idx)
+    qkv = hip.gemm(hbuf, pk["wqkv"], pk["bqkv"])
+    hip.rmsnorm_rope(qkv[:, 0:d], pk["nq"], qkv[:, d:2 * d], pk["nk"], eps=1e-6, rope_cos=cos, rope_sin=sin, tokens_per_batch=L, head_dim=128)
+    q3 = qkv.view(B, L, 3 * d)
+    ao = hip.attn_fwd(q3[:, :, 0:d].unflatten(2, (nh, 128)), q3[:, :, d:2 * d].unflatten(2, (nh, 128)), q3[:, :, 2 * d:].unflatten(2, (nh, 128)),
+                      prescaled=True)
+    hip.gemm_gate_residual(ao.view(B * L, d), pk["wo"], pk["bo"], xres, gate=T[:, 2], gate_row=idx)
+    hip.ln_modulate(xres, out=hbuf, eps=1e-6, ln_w=pk["n3w"], ln_b=pk["n3b"])
+    qc = hip.gemm(hbuf, pk["cwq"], pk["cbq"])
+    hip.rmsnorm_rope(qc, pk["cnq"], eps=1e-6)
+    kv = blk.cross_attn.context_kv(ctx.reshape(-1, d).to(BF).cuda()).view(B, -1, 2 * d)
+    hip.attn_fwd(qc.view(B, L, nh, 128), kv[:, :, 0:d].unflatten(2, (nh, 128)), kv[:, :, d:].unflatten(2, (nh, 128)), out=ao, prescaled=True)
+    hip.gemm_gate_residual(ao.view(B * L, d), pk["cwo"], pk["cbo"], xres)
+    hip.ln_modulate(xres, out=hbuf, eps=1e-6, shift=T[:, 3], scale=T[:, 4], row_index=idx)
+    mid = hip.gemm(hbuf, pk["w1"], pk["b1"], epilogue=hip.EPI_GELU_TANH)
+    hip.gemm_gate_residual(mid, pk["w2"], pk["b2"], xres, gate=T[:, 5], gate_row=idx)
+    stats(xres.view(B, L, d), want, f"fused block body L={L}")
+    stats(xres.view(B, L, d), out, "fused epilogues vs module seam", rel_max=2e-3, psnr_min=60.0)
+
+
+def test_full_width_one_layer_model_at_config2_shape():
+    """Whole forward (cnn-block, patch embedding of 148 channels, ref tokens, per-token time embedding, text embedding, one
+    block, head, unpatchify; FX.py:817-1123) of a ONE-layer model at the 5B width on the BASELINE config-2 latent
+    [2, 48, 25, 32, 56] (L = 11648, B = 2, two prompts of different length) vs the fp32 oracle."""
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+    cfg = dict(CFG_5B, num_layers=1)
+    sd = C.dit_weights(cfg, 13)
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    case = C.dit_case(cfg, 14, frames=25, h=32, w=56, batch=2, text_lens=(77, 126))
+    dcase = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    out = m(**dcase)
+    assert out.shape == (2, 48, 25, 32, 56)
+    with torch.no_grad():
+        want = O.dit_forward(sd, cfg, **case)
+    stats(out, want, "one-layer 5B-width model, 97x512x896 latent")
+
+
+# ----------------------------------------------------------------------------- exact GEMMs at the FFN shapes
+def _checksums_exact(out_dev, a, w, bias_rowsum, what):
+    """A single wrong element changes one row sum and one column sum: both are exact in fp64 for integer data."""
+    col = out_dev.double().sum(dim=0).cpu()
+    row = out_dev.double().sum(dim=1).cpu()
+    want_col = a.double().sum(dim=0) @ w.double().t()
+    want_row = a.double() @ w.double().sum(dim=0)
+    if bias_rowsum is not None:
+        want_col = want_col + bias_rowsum[0].double() * a.shape[0]
+        want_row = want_row + bias_rowsum[0].double().sum()
+    assert torch.equal(col, want_col), f"{what}: column checksums differ in {int((col != want_col).sum())} columns"
+    assert torch.equal(row, want_row), f"{what}: row checksums differ in {int((row != want_row).sum())} rows"
+
+
+def test_gemm_exact_at_ffn1_shape():
+    """flexam_gemm_bf16 at M = 23296 (B*L), N = 14336, K = 3072 (ffn.0, FX.py:415): integer operands -> every output is an exact
+    integer in fp32; all 91 x 56 tiles checked through row / column checksums, 1536 rows element by element; GELU epilogue
+    on those rows (2 bf16 ulps)."""
+    from flexam_amd import hip
+    g = torch.Generator().manual_seed(91)
+    m, n, k = 23296, 14336, 3072
+    a = torch.randint(-2, 3, (m, k), generator=g, dtype=torch.int8).float()
+    w = torch.randint(-2, 3, (n, k), generator=g, dtype=torch.int8).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    ad, wd, bd = a.to(BF).cuda(), w.to(BF).cuda(), b.cuda()
+    out = hip.gemm(ad, wd, bd, out_dtype=torch.float32)
+    _checksums_exact(out, a, w, (b,), "ffn1 shape")
+    rows = torch.cat([torch.arange(0, 256), torch.arange(m - 256, m), torch.randint(256, m - 256, (1024,), generator=g)])
+    want = a[rows] @ w.t() + b
+    assert torch.equal(out[rows.cuda()].cpu(), want)
+    o16 = hip.gemm(ad, wd, bd, epilogue=hip.EPI_GELU_TANH)[rows.cuda()].float().cpu()
+    ref = torch.nn.functional.gelu(want, approximate="tanh")
+    tol = 2.0 * 2.0 ** -8 * ref.abs() + 1e-2
+    assert not ((o16 - ref).abs() > tol).any()
+
+
+def test_gemm_gate_residual_exact_at_ffn2_shape_with_tail_split_k():
+    """flexam_gemm_bf16_gate_residual at M = 23296, N = 3072, K = 14336 (ffn.2 + `x + y * e[5]`, FX.py:416,468): 91 x 12 tiles =
+    4 rounds of 256 CUs + 68, the tail cut along K through the per-call scratch.  x0 + bf16(a.w^T + b) * gate[row] is an exact
+    integer in fp32; checked by checksums over everything and element-wise on 1536 rows; repeatable bit for bit."""
+    from flexam_amd import hip
+    g = torch.Generator().manual_seed(92)
+    m, n, k = 23296, 3072, 14336
+    a = torch.randint(-1, 2, (m, k), generator=g, dtype=torch.int8).float()
+    w = torch.randint(-1, 2, (n, k), generator=g, dtype=torch.int8).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    gate = torch.randint(-2, 3, (4, n), generator=g).float()
+    grow = torch.randint(0, 4, (m,), generator=g, dtype=torch.int32)
+    x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+    ad, wd, bd = a.to(BF).cuda(), w.to(BF).cuda(), b.cuda()
+    xs = []
+    for _ in range(2):
+        x = x0.clone().cuda()
+        hip.gemm_gate_residual(ad, wd, bd, x, gate.cuda(), grow.cuda())
+        xs.append(x)
+    assert torch.equal(xs[0], xs[1])
+    rows = torch.cat([torch.arange(0, 256), torch.arange(m - 256, m), torch.randint(256, m - 256, (1024,), generator=g)])
+    y = (a[rows] @ w.t() + b)
+    assert float(y.abs().max()) < 256.0                       # |y| < 256: integers that bf16 holds exactly -> no rounding in the epilogue
+    want = x0[rows] + y * gate[grow[rows].long()]
+    assert torch.equal(xs[0][rows.cuda()].cpu(), want)
+    # all rows: per-gate-row column checksums of (x - x0) / gate are exact integer sums
+    delta = (xs[0] - x0.cuda()).double()
+    for r in range(4):
+        sel = (grow == r)
+        col = delta[sel.cuda()].sum(dim=0).cpu()
+        want_col = (a[sel].double().sum(dim=0) @ w.double().t() + b.double() * int(sel.sum())) * gate[r].double()
+        assert torch.equal(col, want_col), f"gate row {r}: {int((col != want_col).sum())} columns differ"
+
+
+# ----------------------------------------------------------------------------- depth and step accumulation
+def test_thirty_layers_fifty_steps_accumulation():
+    """SURVEY section 7 hard part (ii): 30 layers x 50 Euler steps (the real depth and step count) with the fp32 residual
+    stream and latents: final latents vs the oracle loop, PSNR >= 40 dB.  Width 256 keeps the oracle at seconds."""
+    from flexam_amd import Wan2_2FunControlPipeline_FlexAM, Wan2_2Transformer3DModel_FlexAM
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    from oracle import sampler as S
+    cfg = dict(O.DIT_TINY, num_layers=30)
+    sd = C.dit_weights(cfg, 29)
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    m.load_state_dict(sd, strict=True)
+    pipe = Wan2_2FunControlPipeline_FlexAM(transformer=m.to("cuda:0"))
+    sc = C.sampler_case(cfg)
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], sc["mask_pixels"])
+    trace = []
+    out = pipe(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+               num_inference_steps=50, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent",
+               callback_on_step_end=lambda p, i, t, k: trace.append(k["latents"].float().cpu().clone()))
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    ref_trace = []
+    with torch.no_grad():
+        ref = S.denoise_loop(lambda **k: O.dit_forward(sd, cfg, **k), S.FlowMatchEulerSchedule(1000, 5.0), 50, sc["latents"],
+                             sc["context_uncond"], sc["context_cond"], sc["control_latents"], sc["additional_control"], ml,
+                             sc["masked_video_latents"], sc["ref_latents"], mask, pinned, 0.1, 6.0, trace=ref_trace)
+    ps = [C.psnr(a, b) for a, b in zip(trace, ref_trace)]
+    print("psnr after steps 1, 10, 25, 50:", [round(ps[i], 1) for i in (0, 9, 24, 49)], "min", round(min(ps), 1))
+    stats(out.videos, ref, "30 layers x 50 steps, final latents", rel_max=2e-2)
+    assert min(ps) >= 40.0
+
+
+# ----------------------------------------------------------------------------- VAE at true widths
+def test_vae_decode_chunk_true_widths_sixteenth_area():
+    """Wan2.2 VAE decoder at its real widths (dec_dim 256, dim_mult (1,2,4,4): 1024/1024/512/256 channels, 555 M parameters;
+    VAE.py:621-728) on a [1, 48, 2, 8, 14] latent = 1/16 of the 32 x 56 area, first chunk + one cached 4-frame chunk."""
+    from flexam_amd.wan_vae3_8 import AutoencoderKLWan3_8
+    v = dict(z_dim=48, dec_dim=256, dim_mult=(1, 2, 4, 4), temporal_up=(True, True, False))
+    sd = C.vae_weights(v, seed=61, prefix="model.")
+    vae = AutoencoderKLWan3_8(latent_channels=48, dec_dim=256, dim_mult=[1, 2, 4, 4], temperal_downsample=[False, True, True],
+                              spatial_compression_ratio=16)
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith(("model.encoder.", "model.conv1.")) for k in missing)
+    vae = vae.to("cuda:0").to(BF)
+    z = C.vae_case(seed=62, frames=2, h=8, w=14)
+    out = vae.decode(z.cuda()).sample
+    assert out.shape == (1, 3, 5, 128, 224)
+    sd_b = {k: u.to(BF).float() for k, u in sd.items()}
+    with torch.no_grad():
+        want = OV.vae_decode(sd_b, z, v["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
+    stats(out, want, "VAE decode, true widths, 1/16 area", rel_max=2e-2, peak=2.0)

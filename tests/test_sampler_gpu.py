@@ -90,3 +90,84 @@ def test_sampler_cfg_skip_uses_conditional_row_only():
     p = C.psnr(out.videos.float().cpu(), ref)
     print(f"cfg_skip sampler: psnr {p:.1f} dB")
     assert p >= 40.0
+
+
+@pytest.mark.parametrize("thresh,want_calc", [(1.5, [True, False, True, False, True, False, True, True]),
+                                              (2.5, [True, False, False, True, False, False, True, True])])
+def test_sampler_teacache_together_with_cfg_skip(thresh, want_calc):
+    """TeaCache + cfg_skip in one run: the reference's forward makes the TeaCache decision and counts on EVERY conditional
+    forward, the cfg-skipped B = 1 ones included, and adds `previous_residual[-x.size(0):]` (FX.py:977-1006, 1119-1122); with
+    thresh 2.5 step 4 is a skipped B = 1 step that re-uses the conditional row of a B = 2 residual.  The oracle loop below is
+    the reference's composition: cfg_skip decorator (cfg_optimization.py:5-37) around dit_forward with its TeaCache state."""
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    from oracle import sampler as S
+    cfg = dict(O.DIT_TINY)
+    pipe = make_pipe(cfg, 7)
+    sd = C.dit_weights(cfg, 7)
+    sc = C.sampler_case(cfg)
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], sc["mask_pixels"])
+    n = 8
+    tr = pipe.transformer
+    tr.enable_teacache([1.0, 0.0], n, rel_l1_thresh=thresh, num_skip_start_steps=1)
+    tr.enable_cfg_skip(0.5, n)
+    seen = []
+    out = pipe(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+               num_inference_steps=n, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent",
+               callback_on_step_end=lambda p, i, t, kw: seen.append(bool(tr.teacache.should_calc)))
+    assert tr.teacache.cnt == 0 and tr.teacache.previous_modulated_input is None       # the reset fired at the clip's end
+    assert seen == want_calc
+    tr.disable_teacache()
+    tr.disable_cfg_skip()
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    tc = O.teacache_state([1.0, 0.0], n, thresh, 1)
+    calls, dec = {"n": 0}, []
+
+    def model(**kw):
+        step = calls["n"]
+        calls["n"] += 1
+        if step >= n // 2:
+            cut = lambda v: v[1:] if isinstance(v, (torch.Tensor, list, tuple)) else v
+            o = O.dit_forward(sd, cfg, teacache=tc, **{k: cut(v) for k, v in kw.items()})
+            o = torch.cat([o, o])
+        else:
+            o = O.dit_forward(sd, cfg, teacache=tc, **kw)
+        dec.append(bool(tc["should_calc"]))
+        return o
+    ref = S.denoise_loop(model, S.FlowMatchEulerSchedule(1000, 5.0), n, sc["latents"], sc["context_uncond"], sc["context_cond"],
+                         sc["control_latents"], sc["additional_control"], ml, sc["masked_video_latents"], sc["ref_latents"], mask, pinned,
+                         0.1, 6.0)
+    assert dec == want_calc
+    p = C.psnr(out.videos.float().cpu(), ref)
+    print(f"teacache + cfg_skip sampler (thresh {thresh}): psnr {p:.1f} dB")
+    assert p >= 40.0
+
+
+def test_fractional_mask_many_timestep_rows_and_bounded_table():
+    """A mask whose frame 0 is not all-known is NOT pinned (PIPE.py:688-690): the trilinear latent mask then has many distinct
+    values, i.e. many distinct per-token timesteps (foreground edits with soft edges).  The AdaLN table is then rebuilt per
+    layer from one bounded buffer instead of [layers, R, 6, C]; results must not depend on which form is used."""
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    from oracle import sampler as S
+    cfg = dict(O.DIT_TINY)
+    pipe = make_pipe(cfg, 7)
+    sd = C.dit_weights(cfg, 7)
+    sc = C.sampler_case(cfg)
+    g = torch.Generator().manual_seed(77)
+    mp = torch.rand(sc["mask_pixels"].shape, generator=g)                          # soft mask values, frame 0 included
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], mp)
+    kw = dict(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+              num_inference_steps=2, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent")
+    eng = pipe.transformer.engine()
+    out_a = pipe(**kw).videos.float().cpu().clone()
+    assert pipe._state["U"] > 50                            # many distinct timesteps per sample
+    eng.table_limit = 0                                     # force the per-layer table
+    out_b = pipe(**kw).videos.float().cpu().clone()
+    torch.testing.assert_close(out_a, out_b, rtol=0, atol=0)
+    ml, mask, pinned = S.prepare_masks(mp, sc["latents"])
+    assert not pinned
+    ref = S.denoise_loop(lambda **k: O.dit_forward(sd, cfg, **k), S.FlowMatchEulerSchedule(1000, 5.0), 2, sc["latents"], sc["context_uncond"],
+                         sc["context_cond"], sc["control_latents"], sc["additional_control"], ml, sc["masked_video_latents"],
+                         sc["ref_latents"], mask, pinned, 0.1, 6.0)
+    p = C.psnr(out_b, ref)
+    print(f"fractional mask, U = {pipe._state['U']}: psnr {p:.1f} dB")
+    assert p >= 40.0
