@@ -53,10 +53,10 @@ struct GemmParams {
   int64_t rows_per_batch;  // used when gate_row is null: row = m / rows_per_batch
   int gm;                  // tile-rows per L2 group (XCD-aware order)
   // tail split-K: work units 0..split_full-1 are whole tiles; the remaining tiles (the last, partial round of the CUs) are
-  // cut into split_s K slices each; partial sums go through `ws`, the last slice to arrive (counters) reduces + finishes
+  // cut into split_s K slices each; their partial sums are parked in `ws` and a second, stream-ordered launch
+  // (gemm_splitk_finish_kernel) adds the slices up in slice order and runs the epilogue
   int units, split_full, split_s;
   float* ws;
-  int* counters;
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -84,7 +84,11 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // for the K loop's instruction mix).  Everything outside the MFMA calls is written once over "row tiles" of RT rows:
 //   lane -> row (lane % RT) of a row tile and column group g = lane / RT; a lane holds, for every 4-column unit v < NV of the
 //   wave's 64 columns, the 4 consecutive columns 4*NG*v + 4*g .. +3 of that row   (16x16: RT 16, NG 4, NV 4; 32x32: RT 32, NG 2, NV 8)
-template <int EPI, typename OutT, int MT, bool M32>
+// TAIL: the instance that runs the K slices of the tail tiles (units >= split_full) and parks their partial sums; it has no
+// epilogue (gemm_splitk_finish_kernel runs it).  The TAIL = false instance runs the whole tiles only.  Two instances instead of
+// one kernel with both paths: with the slab stores between the K loop and the epilogues hipcc spills 30-50 registers in the
+// gate-residual epilogue and leaves a reload pending into the next unit's K loop.
+template <int EPI, typename OutT, int MT, bool M32, bool TAIL = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
   static_assert(!M32 || MT % 2 == 0, "32 x 32 tiles need an even number of 16-row m-tiles per wave");
   constexpr int RT = M32 ? 32 : 16;         // rows per row tile
@@ -115,8 +119,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   const int chunk0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
   const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
   const int local = blockIdx.x >> 3;
-  const int n_whole = local < chunk_n ? (chunk_n - local + per_xcd - 1) / per_xcd : 0;
-  const int n_tail = (int)blockIdx.x < p.units - p.split_full ? (p.units - p.split_full - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int n_whole = TAIL ? 0 : (local < chunk_n ? (chunk_n - local + per_xcd - 1) / per_xcd : 0);
+  const int n_tail = !TAIL ? 0 : ((int)blockIdx.x < p.units - p.split_full ? (p.units - p.split_full - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0);
   auto nth_unit = [&](int j) -> int {       // j-th work unit of this workgroup, -1 past the end
     if (j < n_whole) return chunk0 + local + j * per_xcd;
     if (j < n_whole + n_tail) return p.split_full + (int)blockIdx.x + (j - n_whole) * (int)gridDim.x;
@@ -175,7 +179,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       nkl = (int)((int64_t)(slice + 1) * nk / ns) - kb0;
     }
   };
-  int& arrive_flag = *(int*)(smem + 4 * TILE_BYTES);   // first word of wave 0's epilogue staging: idle while split-K units hand over
 
   for (int it = 0; it < n_whole + n_tail; ++it) {
   int m0, n0, tile, kb0, nkl, slice, ns;
@@ -351,14 +354,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     }
   }
 
-  // ---- tail split-K: park this slice's partial sums; the slice whose arrival count comes back last adds all of them up in
-  // slice order (deterministic) and runs the epilogue.  Per-XCD L2s are not coherent with each other, and an agent-scope
-  // fence would write back / invalidate a whole L2 per hand-off; instead EVERY handed-off byte is stored and loaded with
-  // agent-scope (sc1) accesses, each storing wave drains its stores, and one lane signals behind a workgroup barrier with a
-  // relaxed agent-scope atomic add (MI355X_MICROARCH.md, inter-workgroup visibility: the "added last" row).
-  if (ns > 1) {
+  // ---- tail split-K: park this slice's partial sums and go on; gemm_splitk_finish_kernel, launched behind this kernel on the
+  // same stream, adds the slices of a tile up in slice order (deterministic) and runs the epilogue.  The kernel boundary is the
+  // hand-off: plain stores here, plain loads there.  (r1 handed over inside the launch -- sc1 stores, an arrival counter, the
+  // last slice reducing with sc1 loads; at the production FFN2 shape and at the VAE's K = 27648 convolutions some lanes of the
+  // reducing workgroup read zeros instead of another slice's sums: profiles/r2_splitk_handoff_bug.txt.)
+  if constexpr (TAIL) {
     constexpr int SLAB = 256 * BN;                     // floats per slab; 16-byte element of (row tile t, unit v) at ((t*NV+v)*512 + tid)*4
-    typedef unsigned long long u64;
     int te = tid;                                      // opaque copy (see `le` below): slab addresses stay out of the K loop's registers
     asm volatile("" : "+v"(te));
     const int tr = tile - p.split_full;
@@ -366,38 +368,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 #pragma unroll
     for (int t = 0; t < NRT; ++t)
 #pragma unroll
-      for (int v = 0; v < NV; ++v) {            // 16-byte sc1 stores cost what plain ones do; 8-byte ones are one fabric write each
-        const f32x4 a4 = accv(t, v);
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slab + ((t * NV + v) * 512 + te) * 4), "v"(a4) : "memory");
-      }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), as an instruction the compiler's own wait bookkeeping sees
-    __syncthreads();
-    if (te == 0) arrive_flag = __hip_atomic_fetch_add(p.counters + tr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const bool last = arrive_flag == ns - 1;
-    __syncthreads();                                   // arrive_flag is rewritten by the next split unit
-    if (!last) continue;
-    if (te == 0) __hip_atomic_store(p.counters + tr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    const u64* base = (const u64*)(p.ws + (int64_t)tr * ns * SLAB);
-#pragma unroll
-    for (int t = 0; t < NRT; ++t)
-#pragma unroll
-      for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const int e = ((t * NV + v) * 512 + te) * 2 + hf;
-          f32x2 sum = __builtin_bit_cast(f32x2, __hip_atomic_load(base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          for (int s2 = 1; s2 < ns; ++s2)
-            sum += __builtin_bit_cast(f32x2, __hip_atomic_load(base + (int64_t)s2 * (SLAB / 2) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          if constexpr (M32) {                   // (written out: an element store through a lambda parameter costs hipcc dozens of spills)
-            acc32[t][v >> 2][4 * (v & 3) + 2 * hf] = sum[0];
-            acc32[t][v >> 2][4 * (v & 3) + 2 * hf + 1] = sum[1];
-          } else {
-            acc[t][v][2 * hf] = sum[0];
-            acc[t][v][2 * hf + 1] = sum[1];
-          }
-        }
+      for (int v = 0; v < NV; ++v) *(f32x4*)(slab + ((t * NV + v) * 512 + te) * 4) = accv(t, v);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the stores are drained here (pend stays false)
+    continue;
   }
+  if constexpr (!TAIL) {
 
   // ---- epilogue: lane holds C[m = .. + RT*t + lane%RT][n = .. + 4*NG*v + 4*(lane/RT) + 0..3] per (row tile t, unit v)
   int le = lane;                     // opaque copy of the lane id: the epilogue's per-lane address arithmetic must not be hoisted
@@ -574,13 +549,66 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): edge tiles / fp32 outputs issue an unknown number of stores, drained here (pend stays false)
+  }   // !TAIL
   }   // tile loop
 }
 
+// Second half of the tail split-K: one workgroup per (tail tile, row tile t).  Thread `te` owns the same 16-byte elements the
+// main kernel's thread `te` parked -- (row tile t, unit v) at ((t*NV+v)*512 + te)*4 of every slice's slab -- sums the slices in
+// slice order and applies the epilogue (bias, GELU-tanh, fp32 gated residual, bf16 / fp32 store) in the accumulator layout.
+template <int EPI, typename OutT, int MT, bool M32>
+__global__ __launch_bounds__(512) void gemm_splitk_finish_kernel(GemmParams p) {
+  constexpr int RT = M32 ? 32 : 16, NRT = 16 * MT / RT, NG = 64 / RT, NV = 16 / NG, NTW = 4, BM_ = 32 * MT, SLAB = 256 * BN;
+  const int te = threadIdx.x, lane = te & 63, wave = te >> 6, wm = wave >> 2, wn = wave & 3;
+  const int tr = blockIdx.x / NRT, t = blockIdx.x % NRT;
+  const int tile = p.split_full + tr;
+  int m0, n0;
+  {
+    const int GM = p.gm, per_group = GM * p.tiles_n, group = tile / per_group, first_m = group * GM;
+    const int gsz = min(p.tiles_m - first_m, GM), in_group = tile - group * per_group;
+    m0 = (first_m + in_group % gsz) * BM_;
+    n0 = (in_group / gsz) * BN;
+  }
+  const int m = m0 + wm * (16 * MT) + t * RT + (lane & (RT - 1));
+  if (m >= p.M) return;
+  const float* base = p.ws + (int64_t)tr * p.split_s * SLAB;
+  const float* grow = nullptr;
+  if constexpr (EPI == EPI_GATE_RESIDUAL) {
+    if (p.gate) grow = p.gate + (p.gate_row ? (int64_t)p.gate_row[m] : (int64_t)m / p.rows_per_batch) * p.gate_ld;
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int n = n0 + wn * (16 * NTW) + (lane / RT) * 4 + v * (4 * NG);
+    if (n >= p.N) continue;
+    const int64_t e = ((int64_t)(t * NV + v) * 512 + te) * 4;
+    f32x4 y4 = *(const f32x4*)(base + e);
+    for (int s2 = 1; s2 < p.split_s; ++s2) y4 += *(const f32x4*)(base + (int64_t)s2 * SLAB + e);
+    if (p.bias) y4 += *(const f32x4*)(p.bias + n);
+    if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y4[j] = gelu_tanh(y4[j]);
+    }
+    if constexpr (EPI == EPI_GATE_RESIDUAL) {
+      float* xp = p.X + (int64_t)m * p.ldx + n;
+      f32x4 x = *(const f32x4*)xp;
+      const f32x4 g = grow ? *(const f32x4*)(grow + n) : (f32x4){1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] += bf2f(f2bf(y4[j])) * g[j];     // y rounded to bf16 first, like the main kernel's epilogue
+      *(f32x4*)xp = x;
+    } else if constexpr (sizeof(OutT) == 2) {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(y4[j]);
+      *(bf16x4*)((bf16*)p.C + (int64_t)m * p.ldc + n) = o;
+    } else {
+      *(f32x4*)((float*)p.C + (int64_t)m * p.ldc + n) = y4;
+    }
+  }
+}
+
 // scratch for the tail split-K, handed in by the caller with every launch (nothing is retained between calls):
-// [256 ints | slabs of 256 x 256 fp32]
+// slabs of 256 x 256 fp32, no initialisation needed
 struct GemmWorkspace {
-  int* counters = nullptr;
   float* slabs = nullptr;
   int64_t n_slabs = 0;
 };
@@ -588,11 +616,10 @@ struct GemmWorkspace {
 int num_cus() { return flexam_num_cus(); }
 
 // Tail split-K plan: `rem` = tiles of the last, partial round of the CUs.  Cutting each of them into S K slices turns that
-// round into ceil(rem*S/G) passes of 1/S of a tile, and every pass pays the hand-off: parking 256 KiB of partial sums and the
-// arrival atomic (~15 us), then ONE workgroup re-reads S slabs at the ~25 GB/s a single CU can pull (~10 us per slab) --
-// in K blocks of main loop (1.15 us each): 13 + 9 S.  S (<= 8, slabs must fit the workspace) minimises the sum; with
-// K = 3072 (48 K blocks) the hand-off eats the gain and nothing is split, with K = 14336 the tail shrinks to ~0.5 tile
-// times.  `cost` = resulting length of the tail in tile times (1.0 without a split).
+// round into ceil(rem*S/G) passes of 1/S of a tile; every pass parks 256 KiB of partial sums per workgroup (~4 K blocks of main
+// loop), and the finish launch costs a kernel boundary plus rem * S slabs read chip-wide (~4 + 0.03 * rem * S K blocks).  S (<= 8,
+// slabs must fit the workspace) minimises the sum; with K = 3072 (48 K blocks) the hand-off eats most of the gain, with
+// K = 14336 the tail shrinks to ~0.4 tile times.  `cost` = resulting length of the tail in tile times (1.0 without a split).
 void plan_split(const GemmWorkspace& g_ws, int tiles, int nk, int& S, int& rem, double* cost = nullptr) {
   const int G = num_cus();
   static const int enabled = [] { const char* e = getenv("FLEXAM_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
@@ -602,7 +629,7 @@ void plan_split(const GemmWorkspace& g_ws, int tiles, int nk, int& S, int& rem, 
   if (enabled && g_ws.slabs && rem) {
     for (int s = 2; s <= 8 && s <= nk / 8 && (int64_t)rem * s <= g_ws.n_slabs; ++s) {
       const int passes = (rem * s + G - 1) / G;
-      const double c = passes * (1.0 / s + (13.0 + 9.0 * s) / nk);
+      const double c = passes * (1.0 / s + 4.0 / nk) + (4.0 + 0.03 * rem * s) / nk;
       if (c < best - 0.05) { best = c; S = s; }
     }
   }
@@ -628,12 +655,25 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
   p.split_full = split_s > 1 ? tiles - rem : tiles;
   p.units = p.split_full + (split_s > 1 ? rem * split_s : 0);
   p.ws = g_ws.slabs;
-  p.counters = g_ws.counters;
-  const int nwg = p.units;
-  int grid = (nwg + 7) / 8 * 8;                          // a multiple of 8 so that blockIdx & 7 is the XCD
   static const int persist = [] { const char* e = getenv("FLEXAM_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
-  if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (144 / 160 KiB of LDS each)
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, p, a_koff);
+  auto grid_for_units = [&](int nwg) {
+    int grid = (nwg + 7) / 8 * 8;                        // a multiple of 8 so that blockIdx & 7 is the XCD
+    if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (144 / 160 KiB of LDS each)
+    return grid;
+  };
+  if (p.split_full > 0) hipLaunchKernelGGL(kern, dim3(grid_for_units(p.split_full)), dim3(512), smem, s, p, a_koff);
+  if (split_s > 1) {
+    // the K slices of the tail tiles, then (stream-ordered) their sum in slice order + the epilogue
+    auto tail = gemm_bf16_kernel<EPI_NONE, float, MT, M32, true>;
+    static bool tail_attr[FLEXAM_MAX_DEVICES] = {};
+    if (!tail_attr[dev]) {
+      if (hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
+      tail_attr[dev] = true;
+    }
+    hipLaunchKernelGGL(tail, dim3(grid_for_units(rem * split_s)), dim3(512), smem, s, p, a_koff);
+    hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI, OutT, MT, M32>), dim3(rem * (M32 ? MT / 2 : MT)), dim3(512), 0, s, p);
+  }
   return flexam_check_launch("flexam_gemm_bf16");
 }
 
@@ -671,10 +711,9 @@ int pick_mt(const GemmWorkspace& g_ws, int M, int tiles_n, int nk) {
 // caller's scratch -> workspace view; too small or NULL = no split-K
 GemmWorkspace make_ws(void* ws, int64_t bytes) {
   GemmWorkspace g;
-  if (ws && bytes >= 1024 + (int64_t)256 * BN * 4) {
-    g.counters = (int*)ws;                                // 256 ints, zero on entry (the kernels leave them zero)
-    g.slabs = (float*)((char*)ws + 1024);
-    g.n_slabs = (bytes - 1024) / ((int64_t)256 * BN * 4);
+  if (ws && bytes >= (int64_t)256 * BN * 4) {
+    g.slabs = (float*)ws;
+    g.n_slabs = bytes / ((int64_t)256 * BN * 4);
   }
   return g;
 }

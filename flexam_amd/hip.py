@@ -120,16 +120,16 @@ def device_check():
 
 # ----------------------------------------------------------------------------- GEMM
 _GEMM_WS = {}
-GEMM_WS_BYTES = 1024 + 256 * 256 * 256 * 4          # FLEXAM_GEMM_WS_BYTES
+GEMM_WS_BYTES = 256 * 256 * 256 * 4                 # FLEXAM_GEMM_WS_BYTES
 
 
 def _gemm_workspace(device, stream: int):
-    """Tail split-K scratch (64 MiB + zeroed arrival counters) handed to every GEMM call: one buffer per
-    (device, stream), so launches that can run concurrently never share slabs or counters."""
+    """Tail split-K scratch (64 MiB of partial-sum slabs) handed to every GEMM call: one buffer per (device, stream),
+    so launches that can run concurrently never share slabs."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
     buf = _GEMM_WS.get(key)
     if buf is None:
-        buf = _GEMM_WS[key] = torch.zeros(GEMM_WS_BYTES, device=device, dtype=torch.uint8)
+        buf = _GEMM_WS[key] = torch.empty(GEMM_WS_BYTES, device=device, dtype=torch.uint8)
     return buf
 
 

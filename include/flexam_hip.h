@@ -46,13 +46,13 @@ int flexam_device_check(void);          /* FLEXAM_E_ARCH unless the current devi
  * device): element offset added to every A row base for K block kb instead of kb*64 -- the
  * implicit-GEMM form of the VAE's causal convolutions (one entry per (tap, 64-channel slice)).
  * ws / ws_bytes (optional): scratch for the tail split-K -- the tiles of the last, partial round of the CUs are cut along K so
- * that all CUs work; partial sums are reduced in a fixed order by the slice that finishes last (deterministic).  Device
- * memory, 16-byte aligned, first 1 KiB ZEROED once by the caller (arrival counters; every launch leaves them zero), then
- * slabs of 256 KiB; FLEXAM_GEMM_WS_BYTES covers every shape.  NULL / too small: the GEMM never splits.  The buffer is used
- * only by this launch (stream-ordered): launches that may run concurrently (other streams, other devices) need their own.
+ * that all CUs work; the slices' partial sums are parked in `ws` and a second launch on the same stream adds them up in slice
+ * order (deterministic) and runs the epilogue.  Device memory, 16-byte aligned, slabs of 256 KiB, no initialisation needed;
+ * FLEXAM_GEMM_WS_BYTES covers every shape.  NULL / too small: the GEMM never splits.  The buffer is used only by this call
+ * (stream-ordered): calls that may run concurrently (other streams, other devices) need their own.
  * Replaces nn.Linear -> cuBLAS (+ its workspace): FlexAM/models/wan_transformer3d_FlexAM.py:242-244,261,363-365,
  * 370,415-416,487,626-636 and Conv3d/Conv2d -> cuDNN: FlexAM/models/wan_vae3_8.py:39-47,94,99. */
-#define FLEXAM_GEMM_WS_BYTES (1024 + 256 * 262144)
+#define FLEXAM_GEMM_WS_BYTES (256 * 262144)
 int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int epilogue, int out_f32, const int64_t* a_koff, void* ws,
                      int64_t ws_bytes, void* stream);

@@ -72,7 +72,7 @@ def test_full_width_block_vs_oracle(grid):
         stats(out, want_b, f"block module L={L} (vs oracle on the bf16-rounded weights)", rel_max=1.0e-2)
         # ... and with a plain per-token tensor (no compact rows attached)
         out2 = blk(x.cuda(), e=e0.cuda(), **kw)
-        stats(out2, out, "per-token e tensor vs compact rows", rel_max=1e-5, psnr_min=90.0)
+        stats(out2, out, "per-token e tensor vs compact rows", rel_max=1e-6, psnr_min=120.0)   # same kernels, same table values: identical
     # (2) the engine's fused block body (GEMM epilogues: GELU, fp32 gated residual, split-K tails) on the same problem
     pk = blk.packed()
     B = 2
@@ -167,7 +167,8 @@ def test_gemm_gate_residual_exact_at_ffn2_shape_with_tail_split_k():
     from flexam_amd import hip
     g = torch.Generator().manual_seed(92)
     m, n, k = 23296, 3072, 14336
-    a = torch.randint(-1, 2, (m, k), generator=g, dtype=torch.int8).float()
+    # sparse +-1 rows keep |a.w^T + b| < 256: integers that bf16 holds exactly, so the epilogue's rounding of y changes nothing
+    a = (torch.randint(-1, 2, (m, k), generator=g, dtype=torch.int8) * (torch.randint(0, 16, (m, k), generator=g, dtype=torch.int8) == 0)).float()
     w = torch.randint(-1, 2, (n, k), generator=g, dtype=torch.int8).float()
     b = torch.randint(-8, 9, (n,), generator=g).float()
     gate = torch.randint(-2, 3, (4, n), generator=g).float()
@@ -182,7 +183,7 @@ def test_gemm_gate_residual_exact_at_ffn2_shape_with_tail_split_k():
     assert torch.equal(xs[0], xs[1])
     rows = torch.cat([torch.arange(0, 256), torch.arange(m - 256, m), torch.randint(256, m - 256, (1024,), generator=g)])
     y = (a[rows] @ w.t() + b)
-    assert float(y.abs().max()) < 256.0                       # |y| < 256: integers that bf16 holds exactly -> no rounding in the epilogue
+    assert float(y.abs().max()) < 256.0
     want = x0[rows] + y * gate[grow[rows].long()]
     assert torch.equal(xs[0][rows.cuda()].cpu(), want)
     # all rows: per-gate-row column checksums of (x - x0) / gate are exact integer sums
