@@ -9,9 +9,12 @@ Workload (BASELINE config 2): Wan2.2-Fun-5B-FLEXAM DiT (dim 3072, 24 
 (448 reference-image tokens + 11200 video tokens), CFG pair (B = 2), flow-match Euler, 50-step schedule,
 synthetic seeded conditioning.  One *step* = one iteration of the reference loop
 (pipeline_wan2_2_fun_control_FlexAM.py:844-949): two DiT sample-forwards + CFG + Euler + masked blend.
-N > 1: one process per GPU; the two CFG rows are split first (independent until the guidance combine), then
-the token sequence into N/2 contiguous chunks whose K/V are all-gathered per block over RCCL/xGMI
-(strong scaling of ONE clip).
+N > 1: one process per GPU (strong scaling of ONE clip).  Default layout: the two CFG rows are split
+first (independent until the guidance combine: no per-block traffic), then the token sequence into N/2 contiguous chunks whose
+post-norm K|V are all-gathered per block over RCCL/xGMI while the rank attends to its local chunk ("allgather", the collective
+BASELINE.json's north_star names).  FLEXAM_SP_MODE=ulysses selects the all-to-all-over-heads exchange instead (then N >= 4 runs
+N-way token chunks with the CFG pair batched), FLEXAM_SP_OVERLAP=0 the all-gather without local-chunk-first attention,
+FLEXAM_CFG_PARALLEL=0/1 overrides the CFG split; `config.parallelism` names what ran.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the self-attention flash kernel, timed
 live with events on the launch stream) and `cpu_baseline` (the fp32 oracle on the host cores, one of the
@@ -96,7 +99,7 @@ def kernel_rooflines(eng, B, L, lc):
     if eng.sp_size > 1 and eng.sp_mode == "ulysses":
         # this rank's attention: all L tokens of nh / sp heads (the q|k|v it received in the last block's all-to-all)
         hg = nh // eng.sp_size
-        full = ws["a2a_recv"].view(1, L, 3, hg, hd) if B == 1 else ws["a2a_full"]
+        full = ws["a2a_recv"].view(B, L, 3, hg, hd)
         t = time_kernel(lambda: hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"], prescaled=True), iters=8)
         out["attn_self"] = dict(flops=4.0 * B * L * L * hg * hd, sec=t)
     else:
@@ -225,7 +228,8 @@ def main():
     cfg = dict(WAN22_FUN_5B_FLEXAM, num_layers=args.layers)
     model = build_model(cfg, device)
     if world > 1:
-        model.enable_multi_gpus_inference()
+        cp = os.environ.get("FLEXAM_CFG_PARALLEL")
+        model.enable_multi_gpus_inference(cfg_parallel=None if cp is None else cp == "1")
     pipe = Wan2_2FunControlPipeline_FlexAM(transformer=model)
     inp = synthetic_inputs(args.frames, args.height, args.width, cfg["text_dim"])
     cond = LatentConditioning(control_latents=inp["control"], additional_control=inp["additional"], masked_video_latents=inp["masked"],
@@ -269,6 +273,11 @@ def main():
         base = cpu_baseline(L, cfg)
 
     eng_cfg, eng_sp, eng_mode = eng.cfg_size, eng.sp_size, getattr(eng, "sp_mode", "-")
+    if eng_mode == "allgather":
+        eng_mode = ("K|V all-gather per block, overlapped with the Q projection and the attention to the local chunk (partial softmaxes merged)"
+                    if getattr(eng, "sp_overlap", False) else "K|V all-gather per block, overlapped with the Q projection only")
+    elif eng_mode == "ulysses":
+        eng_mode = "all-to-all over heads (q|k|v out, attention output back)"
     vae_sec = enc_sec = enc_stream_sec = None
     if rank == 0 and world == 1 and not args.no_vae:
         del pipe, model, eng
@@ -289,10 +298,10 @@ def main():
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
                                    f"random-init bf16 weights, synthetic conditioning (BASELINE configs[1])",
                        "parallelism": ((f"cfg{eng_cfg} x sp{eng_sp}: one CFG row per rank" + (", no per-block traffic" if eng_sp == 1 else
-                                        f", token-chunk sequence parallel inside each half, {eng_mode} exchange around self-attention (RCCL)"))
+                                        f", token-chunk sequence parallel inside each half; exchange around self-attention (RCCL): {eng_mode}"))
                                        if eng_cfg == 2 else
-                                       f"cfg1 x sp{eng_sp}: CFG pair batched on every rank, token-chunk sequence parallel over all ranks, "
-                                       f"{eng_mode} exchange around self-attention (RCCL)") if world > 1 else "single GPU",
+                                       f"cfg1 x sp{eng_sp}: CFG pair batched on every rank, token-chunk sequence parallel over all ranks; "
+                                       f"exchange around self-attention (RCCL): {eng_mode}") if world > 1 else "single GPU",
                        "layers": cfg["num_layers"]},
             "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
             "vae_decode_sec": vae_sec, "vae_encode_sec_per_stream": enc_stream_sec, "conditioning_encode_sec_8_streams": enc_sec,

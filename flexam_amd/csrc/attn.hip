@@ -46,8 +46,12 @@ struct AttnParams {
   // un-normalised O (fp32) and (running max, row sum) to the workspace; attn_merge_kernel combines the splits
   int kv_splits, tiles_per_split;
   int unit0, n_units;   // this launch covers work units (q block, head, batch) unit0 .. unit0 + n_units - 1
-  float* ws_o;          // [S][n_units][256 rows][128]
-  float* ws_ml;         // [S][n_units][256 rows][2]
+  float* ws_o;          // [slots][n_units][256 rows][128]
+  float* ws_ml;         // [slots][n_units][256 rows][2]
+  // partial: write un-normalised O and (reference, row sum) to workspace slot slot0 + split even with one key range (the keys of
+  // this call are only PART of the softmax: local-chunk-first attention under a sequence-parallel K|V all-gather);
+  // n_slots: slots the merge kernel adds up
+  int partial, slot0, n_slots;
 };
 
 // byte offset of 16-byte chunk `ch` (0..15) of key row `row` in a [64][128] bf16 tile, image (b)
@@ -419,9 +423,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   // ---- epilogue: O[q][32dt + 8i + 4h + (0..3)] = o_acc[dt][4i + (0..3)] / l
   const float l_tot = pair_sum(l_run);
   const int qi = q0 + r;
-  if (p.kv_splits > 1) {                   // partial result of this key range; attn_merge_kernel finishes the softmax
+  if (p.partial) {                         // partial result of this key range; attn_merge_kernel finishes the softmax
     if (qi < p.Lq) {
-      const int64_t row = ((int64_t)split * p.n_units + ul) * QBLK + wave * 32 + r;
+      const int64_t row = ((int64_t)(p.slot0 + split) * p.n_units + ul) * QBLK + wave * 32 + r;
       float* orow = p.ws_o + row * HD;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -463,10 +467,10 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
     const int q = qb * QBLK + rr;
     if (q >= p.Lq) continue;
     float m = -INFINITY;
-    for (int s = 0; s < p.kv_splits; ++s) m = fmaxf(m, p.ws_ml[(s * rows + row) * 2]);
+    for (int s = 0; s < p.n_slots; ++s) m = fmaxf(m, p.ws_ml[(s * rows + row) * 2]);
     float l = 0.f;
     f32x2 acc = {0.f, 0.f};
-    for (int s = 0; s < p.kv_splits; ++s) {
+    for (int s = 0; s < p.n_slots; ++s) {
       const f32x2 ml = *(const f32x2*)(p.ws_ml + (s * rows + row) * 2);
       const float w = __builtin_amdgcn_exp2f((ml[0] - m) * (p.prescaled ? 1.0f : p.scale_log2e));
       l += w * ml[1];
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
 
 int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
              int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk, int head_dim, float softmax_scale,
-             int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream) {
-  FX_REQUIRE(q && k && v && o, FLEXAM_E_ARG, "attn_fwd: null pointer");
+             int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream, int partial_slot0 = -1) {
+  FX_REQUIRE(q && k && v && (o || partial_slot0 >= 0), FLEXAM_E_ARG, "attn_fwd: null pointer");
   FX_REQUIRE(head_dim == HD, FLEXAM_E_SHAPE, "attn_fwd: head_dim %d unsupported (128 only)", head_dim);
   FX_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, FLEXAM_E_SHAPE, "attn_fwd: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
   FX_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 4 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 &&
@@ -494,7 +498,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   FX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, FLEXAM_E_ARG, "attn_fwd: misaligned pointer");
   const int tiles_all = (Lk + KVBLK - 1) / KVBLK;
   FX_REQUIRE(kv_splits >= 1 && kv_splits <= tiles_all, FLEXAM_E_ARG, "attn_fwd: %d key splits for %d key tiles", kv_splits, tiles_all);
-  FX_REQUIRE(kv_splits == 1 || (ws_o && ws_ml), FLEXAM_E_ARG, "attn_fwd: split-KV needs both workspaces");
+  FX_REQUIRE((kv_splits == 1 && partial_slot0 < 0) || (ws_o && ws_ml), FLEXAM_E_ARG, "attn_fwd: split-KV needs both workspaces");
   AttnParams p;
   p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o;
   p.q_bs = q_bs; p.q_rs = q_rs; p.k_bs = k_bs; p.k_rs = k_rs; p.v_bs = v_bs; p.v_rs = v_rs; p.o_bs = o_bs; p.o_rs = o_rs;
@@ -505,6 +509,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.tiles_per_split = (tiles_all + kv_splits - 1) / kv_splits;
   p.kv_splits = (tiles_all + p.tiles_per_split - 1) / p.tiles_per_split;     // drop empty trailing splits
   p.ws_o = ws_o; p.ws_ml = ws_ml;
+  p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits;
   FX_REQUIRE((int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB
@@ -527,8 +532,15 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
     p.unit0 = 0; p.n_units = split_from_unit; p.kv_splits = 1; p.tiles_per_split = tiles_all;
     hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);
   }
+  if (partial_slot0 >= 0) {                // every unit, this call's keys only: partials into slots slot0 .. slot0 + S - 1, no merge
+    FX_REQUIRE(S == kv_splits, FLEXAM_E_ARG, "attn_fwd_partial: %d key ranges requested but %d key tiles give %d (use ceil(tiles / ceil(tiles / S)))",
+               kv_splits, tiles_all, S);
+    p.unit0 = 0; p.n_units = units; p.kv_splits = S; p.tiles_per_split = tps; p.partial = 1; p.slot0 = partial_slot0;
+    hipLaunchKernelGGL(kern, dim3(p.n_units * S), dim3(NT), smem, (hipStream_t)stream, p);
+    return flexam_check_launch("flexam_attn_fwd_partial");
+  }
   if (split_from_unit < units) {           // the rest: S key ranges each, then the merge
-    p.unit0 = split_from_unit; p.n_units = units - split_from_unit; p.kv_splits = S; p.tiles_per_split = tps;
+    p.unit0 = split_from_unit; p.n_units = units - split_from_unit; p.kv_splits = S; p.tiles_per_split = tps; p.partial = 1; p.n_slots = S;
     hipLaunchKernelGGL(kern, dim3(p.n_units * S), dim3(NT), smem, (hipStream_t)stream, p);
     const int64_t g = ((int64_t)p.n_units * QBLK + 3) / 4;
     hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, p);
@@ -551,4 +563,29 @@ extern "C" int flexam_attn_fwd_splitkv(const void* q, int64_t q_bs, int64_t q_rs
                                        float* ws_o, float* ws_ml, void* stream) {
   return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, kv_splits,
                   split_from_unit, ws_o, ws_ml, stream);
+}
+
+extern "C" int flexam_attn_fwd_partial(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                                       const void* v, int64_t v_bs, int64_t v_rs, int B, int H, int Lq, int Lk, int head_dim,
+                                       float softmax_scale, int kv_splits, int slot0, float* ws_o, float* ws_ml, void* stream) {
+  FX_REQUIRE(slot0 >= 0, FLEXAM_E_ARG, "attn_fwd_partial: negative slot");
+  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, 0, 0, B, H, Lq, Lk, head_dim, softmax_scale, kv_splits, 0, ws_o,
+                  ws_ml, stream, slot0);
+}
+
+extern "C" int flexam_attn_merge(void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int head_dim, float softmax_scale,
+                                 int n_slots, const float* ws_o, const float* ws_ml, void* stream) {
+  FX_REQUIRE(o && ws_o && ws_ml, FLEXAM_E_ARG, "attn_merge: null pointer");
+  FX_REQUIRE(head_dim == HD && B > 0 && H > 0 && Lq > 0 && n_slots >= 1, FLEXAM_E_SHAPE, "attn_merge: bad sizes");
+  FX_REQUIRE(o_rs % 4 == 0 && o_bs % 4 == 0 && (uintptr_t)o % 8 == 0, FLEXAM_E_SHAPE, "attn_merge: output rows must keep 8-byte alignment");
+  AttnParams p{};
+  p.o = (bf16*)o; p.o_bs = o_bs; p.o_rs = o_rs; p.B = B; p.H = H; p.Lq = Lq;
+  p.prescaled = softmax_scale < 0.f;
+  p.scale_log2e = p.prescaled ? 1.0f : softmax_scale * 1.4426950408889634f;
+  p.q_blocks = (Lq + QBLK - 1) / QBLK;
+  p.unit0 = 0; p.n_units = B * H * p.q_blocks; p.n_slots = n_slots;
+  p.ws_o = const_cast<float*>(ws_o); p.ws_ml = const_cast<float*>(ws_ml);
+  const int64_t g = ((int64_t)p.n_units * QBLK + 3) / 4;
+  hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, p);
+  return flexam_check_launch("flexam_attn_merge");
 }

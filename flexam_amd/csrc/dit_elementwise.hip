@@ -181,21 +181,38 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(float* __restrict__ 
 //   identity rows for pass-through tokens; null -> no rotation (cross-attention q).
 // ------------------------------------------------------------------------------------------
 struct RmsRopeArgs {
-  const bf16* in[2];
-  bf16* out[2];
-  const float* w[2];
-  int64_t ld_in[2], ld_out[2];
+  const bf16* in[3];
+  bf16* out[3];
+  const float* w[3];
+  int64_t ld_in[3], ld_out[3];
+  // SCATTER instance (sequence-parallel send layout): element (m, col) of tensor `which` goes to
+  //   out[which] + (m / tokens_per_batch) * out_bs + (m % tokens_per_batch) * ld_out[which] + (col / col_block) * block_stride + col % col_block
+  // i.e. the row is cut into column blocks (one per destination rank's head group) that land block_stride apart; tensor 2 (v) is
+  // copied through without a norm
+  int64_t out_bs, block_stride;
+  int col_block;
+  int map[3];              // blockIdx.y -> tensor slot
 };
 
-template <int VPT>
+template <int VPT, bool SCATTER>
 __global__ __launch_bounds__(RT) void rmsnorm_rope_kernel(RmsRopeArgs a, int C, float eps, const float* __restrict__ cs,
                                                           const float* __restrict__ sn, int64_t tokens_per_batch,
                                                           int64_t token_offset, int head_dim) {
   __shared__ float red[8];
-  const int which = blockIdx.y;
+  const int which = SCATTER ? a.map[blockIdx.y] : (int)blockIdx.y;
   const int64_t m = blockIdx.x;
   const bf16* xr = a.in[which] + m * a.ld_in[which];
   const int nvec = C >> 3;
+  if constexpr (SCATTER) {
+    if (which == 2) {                                   // v: plain copy into the scattered layout
+      bf16* ob = a.out[2] + (m / tokens_per_batch) * a.out_bs + (m % tokens_per_batch) * a.ld_out[2];
+      for (int vec = threadIdx.x; vec < nvec; vec += RT) {
+        const int c = vec * 8;
+        *(bf16x8*)(ob + (int64_t)(c / a.col_block) * a.block_stride + c % a.col_block) = *(const bf16x8*)(xr + c);
+      }
+      return;
+    }
+  }
   bf16x8 v[VPT];
   float s = 0.f;
 #pragma unroll
@@ -212,7 +229,8 @@ __global__ __launch_bounds__(RT) void rmsnorm_rope_kernel(RmsRopeArgs a, int C, 
   }
   const float r = __builtin_amdgcn_rsqf(row_sum(s, red) / (float)C + eps);
   const float* w = a.w[which];
-  bf16* orow = a.out[which] + m * a.ld_out[which];
+  bf16* orow = SCATTER ? a.out[which] + (m / tokens_per_batch) * a.out_bs + (m % tokens_per_batch) * a.ld_out[which]
+                       : a.out[which] + m * a.ld_out[which];
   const int half = head_dim >> 1;
   const int64_t tok = token_offset + (m % tokens_per_batch);
 #pragma unroll
@@ -241,7 +259,8 @@ __global__ __launch_bounds__(RT) void rmsnorm_rope_kernel(RmsRopeArgs a, int C, 
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = f2bf(y[j]);
-    *(bf16x8*)(orow + c) = o;
+    if constexpr (SCATTER) *(bf16x8*)(orow + (int64_t)(c / a.col_block) * a.block_stride + c % a.col_block) = o;
+    else *(bf16x8*)(orow + c) = o;
   }
 }
 
@@ -536,14 +555,44 @@ extern "C" int flexam_rmsnorm_rope(const void* q_in, int64_t ldq_in, void* q_out
   FX_REQUIRE(!rope_cos || (head_dim % 8 == 0 && C % head_dim == 0 && tokens_per_batch > 0), FLEXAM_E_SHAPE,
              "rmsnorm_rope: head_dim %d must divide C %d and be a multiple of 8", head_dim, C);
   if (k_in) FX_REQUIRE(k_out && wk && ldk_in % 8 == 0 && ldk_out % 8 == 0, FLEXAM_E_ARG, "rmsnorm_rope: bad k arguments");
-  RmsRopeArgs a;
+  RmsRopeArgs a{};
   a.in[0] = (const bf16*)q_in; a.out[0] = (bf16*)q_out; a.w[0] = wq; a.ld_in[0] = ldq_in; a.ld_out[0] = ldq_out;
   a.in[1] = (const bf16*)k_in; a.out[1] = (bf16*)k_out; a.w[1] = wk; a.ld_in[1] = ldk_in; a.ld_out[1] = ldk_out;
   if (tokens_per_batch <= 0) tokens_per_batch = M;
   if (head_dim <= 0) head_dim = 8;
-  DISPATCH_VPT(C, hipLaunchKernelGGL(rmsnorm_rope_kernel<VPT>, dim3((unsigned)M, k_in ? 2 : 1), dim3(RT), 0, (hipStream_t)stream, a,
+  DISPATCH_VPT(C, hipLaunchKernelGGL((rmsnorm_rope_kernel<VPT, false>), dim3((unsigned)M, k_in ? 2 : 1), dim3(RT), 0, (hipStream_t)stream, a,
                                      C, eps, rope_cos, rope_sin, tokens_per_batch, token_offset, head_dim));
   return flexam_check_launch("flexam_rmsnorm_rope");
+}
+
+extern "C" int flexam_rmsnorm_rope_scatter(const void* q_in, int64_t ldq_in, const float* wq, const void* k_in, int64_t ldk_in,
+                                           const float* wk, const void* v_in, int64_t ldv_in, void* q_out, void* k_out, void* v_out,
+                                           int64_t ld_out, int64_t out_bs, int col_block, int64_t block_stride, int64_t M, int C,
+                                           float eps, const float* rope_cos, const float* rope_sin, int64_t tokens_per_batch,
+                                           int64_t token_offset, int head_dim, void* stream) {
+  FX_REQUIRE(M > 0 && C > 0 && tokens_per_batch > 0, FLEXAM_E_ARG, "rmsnorm_rope_scatter: empty problem");
+  FX_REQUIRE((q_in == nullptr) == (q_out == nullptr) && (k_in == nullptr) == (k_out == nullptr) && (v_in == nullptr) == (v_out == nullptr),
+             FLEXAM_E_ARG, "rmsnorm_rope_scatter: every input needs its output");
+  FX_REQUIRE(k_in && (!q_in || wq) && wk, FLEXAM_E_ARG, "rmsnorm_rope_scatter: k (and its weight) is mandatory, q needs its weight");
+  FX_REQUIRE(C % 8 == 0 && ldq_in % 8 == 0 && ldk_in % 8 == 0 && ldv_in % 8 == 0 && ld_out % 8 == 0 && out_bs % 8 == 0 &&
+                 block_stride % 8 == 0 && col_block > 0 && col_block % 8 == 0 && C % col_block == 0,
+             FLEXAM_E_SHAPE, "rmsnorm_rope_scatter: widths, strides and the column block must be multiples of 8 (col_block divides C)");
+  FX_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), FLEXAM_E_ARG, "rmsnorm_rope_scatter: cos and sin go together");
+  FX_REQUIRE(!rope_cos || (head_dim % 8 == 0 && C % head_dim == 0), FLEXAM_E_SHAPE, "rmsnorm_rope_scatter: head_dim %d must divide C %d", head_dim, C);
+  // tensor slots of the kernel: 0 = first normed tensor, 1 = second normed tensor, 2 = copied tensor; with q absent k takes slot 0
+  RmsRopeArgs a{};
+  int n = 0;
+  if (q_in) { a.in[n] = (const bf16*)q_in; a.out[n] = (bf16*)q_out; a.w[n] = wq; a.ld_in[n] = ldq_in; a.ld_out[n] = ld_out; ++n; }
+  a.in[n] = (const bf16*)k_in; a.out[n] = (bf16*)k_out; a.w[n] = wk; a.ld_in[n] = ldk_in; a.ld_out[n] = ld_out; ++n;
+  a.in[2] = (const bf16*)v_in; a.out[2] = (bf16*)v_out; a.ld_in[2] = ldv_in; a.ld_out[2] = ld_out;
+  a.out_bs = out_bs; a.block_stride = block_stride; a.col_block = col_block;
+  if (head_dim <= 0) head_dim = 8;
+  int gy = 0;                                            // grid.y: the normed tensors, then the copied one
+  for (int i = 0; i < n; ++i) a.map[gy++] = i;
+  if (v_in) a.map[gy++] = 2;
+  DISPATCH_VPT(C, hipLaunchKernelGGL((rmsnorm_rope_kernel<VPT, true>), dim3((unsigned)M, gy), dim3(RT), 0, (hipStream_t)stream, a, C, eps,
+                                     rope_cos, rope_sin, tokens_per_batch, token_offset, head_dim));
+  return flexam_check_launch("flexam_rmsnorm_rope_scatter");
 }
 
 extern "C" int flexam_mod_table(const float* mod, const float* e, const float* mdens, const float* dens, float* out, int nblk,

@@ -6,11 +6,14 @@ Design: one process per GPU, contiguous token chunks per rank (L/N t
 full 3-D so chunks need not be frame aligned, RoPE rows are looked up by the *global* token index),
 weights replicated, every op token-local except self-attention, which needs all keys/values.  Two
 exchange schemes per block (DiTEngine.sp_mode):
-  * "ulysses" (default when the heads divide over the ranks): all-to-all of the post-norm, post-RoPE q|k|v
-    so that every rank holds ALL tokens of H/N heads, attention, all-to-all of the output back to token
-    chunks -- (N-1)/N of 4 C elements per token leave a rank, each peer link carries 1/N of it;
-  * "allgather": one all-gather of K|V ([B, L/N, 2C] bf16 per rank), attention of the local queries against
-    all keys -- (N-1) x 2 C elements per token arrive, i.e. N/2 times the all-to-all volume.
+  * "allgather" (default; the collective BASELINE.json's north_star names): all-gather of the post-norm, post-RoPE K|V
+    ([L/N, 2C] bf16 per CFG row and rank), started as soon as K|V exist; underneath it the rank projects Q and attends
+    to its LOCAL K/V chunk (flexam_attn_fwd_partial), then to the gathered chunks, and merges the partial softmaxes
+    (flexam_attn_merge) -- (N-1) x 2 C elements per token arrive;
+  * "ulysses" (FLEXAM_SP_MODE=ulysses; the heads must divide over the ranks): all-to-all of q|k|v so that every rank holds
+    ALL tokens of H/N heads, attention, all-to-all of the output back to token chunks -- (N-1)/N of 4 C elements per
+    token leave a rank, each peer link carries 1/N of it.  q|k|v are written in the send layout by the RMSNorm+RoPE kernel
+    and the returning blocks are read in place by the output projection (per-K-block A offsets): no pack / unpack passes.
 Plus one all-gather of the head output per step.
 
 These helpers are backend-agnostic torch.distributed code (RCCL on GPUs; the CPU tests run them
@@ -79,6 +82,22 @@ def all_to_all_chunks(out: torch.Tensor, inp: torch.Tensor, group=None, async_op
     everything = torch.empty((world,) + tuple(inp.shape), device=inp.device, dtype=inp.dtype)
     dist.all_gather_into_tensor(everything.view(world * inp.shape[0], *inp.shape[1:]), inp.contiguous(), group=group)
     out.copy_(everything[:, rank])
+    return None
+
+
+def all_to_all_blocks(outs, ins, group=None):
+    """ins[j] (contiguous) goes to rank j, outs[i] (contiguous, anywhere in memory) receives rank i's block: the list form lets
+    every received block land where the consumer wants it (no unpack pass).  RCCL: one grouped send/recv (dist.all_to_all);
+    other backends (the gloo runs of the tests): the same result from an all-gather of every rank's stacked blocks."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        return dist.all_to_all(list(outs), list(ins), group=group)
+    rank = dist.get_rank(group)
+    mine = torch.stack([t.contiguous() for t in ins])                      # [dst, ...]
+    everything = torch.empty((world,) + tuple(mine.shape), device=mine.device, dtype=mine.dtype)
+    dist.all_gather_into_tensor(everything.view(world * mine.shape[0], *mine.shape[1:]), mine, group=group)
+    for i, o in enumerate(outs):
+        o.copy_(everything[i, rank])
     return None
 
 

@@ -153,10 +153,12 @@ class DiTEngine:
         """Parallel layout of this rank: token chunk `sp_rank` of `sp_size` inside `sp_group`; with cfg_size = 2 the
         world is two such groups, one per CFG row (world rank = cfg_row * sp_size + sp_rank)."""
         self.sp_group, self.sp_rank, self.sp_size = sp_group, sp_rank, sp_size
-        mode = os.environ.get("FLEXAM_SP_MODE", "ulysses")
+        mode = os.environ.get("FLEXAM_SP_MODE", "allgather")
         if mode not in ("ulysses", "allgather"):
             raise ValueError(f"FLEXAM_SP_MODE={mode!r}: expected 'ulysses' or 'allgather'")
         self.sp_mode = mode if (mode == "allgather" or self.nh % max(sp_size, 1) == 0) else "allgather"
+        # local-chunk-first attention under the K|V all-gather (0: wait for the gather, then one attention call)
+        self.sp_overlap = os.environ.get("FLEXAM_SP_OVERLAP", "1") != "0"
         self.world_group = world_group if cfg_size > 1 else sp_group
         self.world_size = world_size if world_size is not None else sp_size
         self.cfg_size, self.cfg_row = cfg_size, cfg_row
@@ -372,29 +374,23 @@ class DiTEngine:
                 T = tab[i]
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
             if sp > 1 and self.sp_mode == "ulysses":
-                # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back (flexam_amd/dist.py)
+                # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
+                # returned blocks in place (flexam_amd/dist.py)
                 hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
-                hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
-                                 tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
-                self._ulysses_attention(qkv, ao, B, lc)
+                a_o, koff_o = self._ulysses_attention(qkv, p, B, lc, tok0)
+                hip.gemm_gate_residual(a_o, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb, a_koff=koff_o)
             elif sp > 1:
-                # K|V projection + K norm/RoPE first, all-gather them asynchronously (RCCL over xGMI) and run the
-                # Q projection + Q norm/RoPE underneath the collective
+                # K|V projection + K norm/RoPE first, written straight into the send buffer; their all-gather (RCCL over xGMI)
+                # runs under the Q projection, the Q norm/RoPE and the attention to the LOCAL chunk
                 hip.gemm(hbuf, p["wqkv"][d:], p["bqkv"][d:], out=qkv[:, d:])
-                hip.rmsnorm_rope(qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc,
-                                 token_offset=tok0, head_dim=hdim)
-                gather = self._gather_kv_start(qkv, B, lc)
-                hip.gemm(hbuf, p["wqkv"][:d], p["bqkv"][:d], out=qkv[:, 0:d])
-                hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc,
-                                 token_offset=tok0, head_dim=hdim)
-                kv = gather.finish()
-                hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
+                self._allgather_attention(qkv, hbuf, p, ao4, q4, B, lc, tok0)
+                hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             else:
                 hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
                 hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
                                  tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
                 hip.attn_fwd(q4, k4, v4, out=ao4, prescaled=True)
-            hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
+                hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             # cross-attention on the text context (K/V precomputed per clip)
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
             qc = qkv[:, 0:d]
@@ -467,48 +463,94 @@ class DiTEngine:
         return calc
 
     # ------------------------------------------------------------------ sequence parallel
-    def _ulysses_attention(self, qkv, ao, B, lc):
-        """qkv [B*lc, 3C] (this rank's tokens, all heads) -> ao [B*lc, C].  Head group j = heads j*H/sp .. goes to rank j."""
-        from .dist import all_to_all_chunks
-        sp, nh, hd, d = self.sp_size, self.nh, self.hd, self.dim
+    def _ulysses_attention(self, qkv, p, B, lc, tok0):
+        """qkv [B*lc, 3C] (this rank's tokens, all heads, straight from the projection) -> (A base view, per-K-block A offsets)
+        of the attention output for the o-projection.  Head group j = heads j*H/sp .. goes to rank j.
+        Send layout [B, sp, lc, 3*G] (G = H/sp * head_dim): written by the RMSNorm+RoPE launch itself (q, k normed + rotated, v
+        copied), block (b, j) goes to rank j.  Receive layout [B, sp, lc, 3*G] = [B, L, 3*G]: rank-major blocks ARE the token
+        order, so attention addresses it with plain strides.  Its output [B, L, G] is cut into the sp token chunks that go back;
+        rank j's block returns to [j, B, lc, G], which the o-projection reads as A[m, j*G + c] through its K-block offsets."""
+        from .dist import all_to_all_blocks
+        sp, nh, hd, d, dev = self.sp_size, self.nh, self.hd, self.dim, self.device
         hg = nh // sp
+        G = hg * hd
+        W = 3 * G
         ws = self._ws[(B, lc)]
         if "a2a_send" not in ws:
-            dev = self.device
-            ws["a2a_send"] = torch.empty(sp, B, lc, 3, hg * hd, device=dev, dtype=BF16)
-            ws["a2a_recv"] = torch.empty(sp, B, lc, 3, hg * hd, device=dev, dtype=BF16)
-            ws["a2a_full"] = torch.empty(B, sp * lc, 3, hg, hd, device=dev, dtype=BF16) if B > 1 else None
+            ws["a2a_send"] = torch.empty(B, sp, lc, W, device=dev, dtype=BF16)
+            ws["a2a_recv"] = torch.empty(B, sp, lc, W, device=dev, dtype=BF16)
             ws["a2a_out"] = torch.empty(B, sp * lc, hg, hd, device=dev, dtype=BF16)
-            ws["a2a_send2"] = torch.empty(sp, B, lc, hg * hd, device=dev, dtype=BF16)
-            ws["a2a_recv2"] = torch.empty(sp, B, lc, hg * hd, device=dev, dtype=BF16)
-        ws["a2a_send"].copy_(qkv.view(B, lc, 3, sp, hg * hd).permute(3, 0, 1, 2, 4))          # pack by destination (re-layout)
-        all_to_all_chunks(ws["a2a_recv"], ws["a2a_send"], self.sp_group)
-        if B == 1:
-            full = ws["a2a_recv"].view(1, sp * lc, 3, hg, hd)                                   # rank-major chunks ARE the token order
-        else:
-            full = ws["a2a_full"]
-            full.view(B, sp, lc, 3, hg * hd).copy_(ws["a2a_recv"].permute(1, 0, 2, 3, 4))
-        hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=ws["a2a_out"], prescaled=True)
-        if B == 1:
-            send2 = ws["a2a_out"].view(sp, 1, lc, hg * hd)
-        else:
-            send2 = ws["a2a_send2"]
-            send2.copy_(ws["a2a_out"].view(B, sp, lc, hg * hd).permute(1, 0, 2, 3))
-        all_to_all_chunks(ws["a2a_recv2"], send2, self.sp_group)
-        ao.view(B, lc, sp, hg * hd).copy_(ws["a2a_recv2"].permute(1, 2, 0, 3))                 # head group j -> columns j*hg*hd ..
+            ws["a2a_recv2"] = torch.empty(sp, B, lc, G, device=dev, dtype=BF16)
+            ws["a2a_koff"] = torch.tensor([(kb * 64 // G) * (B * lc * G) + (kb * 64) % G for kb in range(d // 64)], dtype=I64, device=dev)
+        cd = self.cond
+        send, recv, out, recv2 = ws["a2a_send"], ws["a2a_recv"], ws["a2a_out"], ws["a2a_recv2"]
+        flat = send.view(-1)
+        hip.rmsnorm_rope_scatter(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], qkv[:, 2 * d:], flat, flat[G:], flat[2 * G:],
+                                 ld_out=W, out_bs=sp * lc * W, col_block=G, block_stride=lc * W, eps=self.eps, rope_cos=cd["cos"],
+                                 rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
+        for b in range(B):
+            all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group)
+        full = recv.view(B, sp * lc, 3, hg, hd)
+        hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=out, prescaled=True)
+        chunks = out.view(B, sp, lc, G)
+        for b in range(B):
+            all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group)
+        return recv2.view(sp * B * lc, G), ws["a2a_koff"]
 
-    def _gather_kv_start(self, qkv, B, lc):
-        """Starts the all-gather of this block's post-norm, post-RoPE K|V over the sequence-parallel group (RCCL over
-        xGMI, flexam_amd/dist.py); .finish() returns [B, L, 2C] with heads packed along the row."""
-        from .dist import SeqGather
-        d, sp = self.dim, self.sp_size
+    @staticmethod
+    def _splits_for(units: int, tiles: int, n_cu: int = 256) -> int:
+        """Key ranges per work unit for a partial-attention call: fill whole rounds of the CUs, every range >= 8 key tiles."""
+        best, best_cost = 1, float(-(-units // n_cu))
+        for s in range(2, 9):
+            if tiles // s < 8:
+                break
+            cost = -(-units * s // n_cu) / s + 0.04
+            if cost < best_cost * 0.97:
+                best, best_cost = s, cost
+        return best
+
+    def _allgather_attention(self, qkv, hbuf, p, ao4, q4, B, lc, tok0):
+        """K|V of this rank's tokens are in qkv[:, C:] (projected, not yet normed).  The RMSNorm+RoPE launch writes K (normed,
+        rotated) and V into the send buffer [B, lc, 2C]; one all-gather per CFG row assembles [B, L, 2C] in token order (no
+        re-layout pass); while it is in flight: Q projection, Q norm/RoPE, attention of the local queries to the LOCAL chunk
+        (partial softmax); then the chunks before / after the local one; one merge (reference call sites of the missing
+        exchange: wan_transformer3d_FlexAM.py:801-815, 970-975)."""
+        import torch.distributed as dist
+        sp, nh, hd, d, dev, rank = self.sp_size, self.nh, self.hd, self.dim, self.device, self.sp_rank
         ws = self._ws[(B, lc)]
+        L = sp * lc
         if "kv_send" not in ws:
-            ws["kv_send"] = torch.empty(B, lc, 2 * d, device=self.device, dtype=BF16)
-            ws["kv_full"] = torch.empty(sp * B, lc, 2 * d, device=self.device, dtype=BF16)
-            ws["kv_cat"] = torch.empty(B, sp * lc, 2 * d, device=self.device, dtype=BF16)
-        ws["kv_send"].copy_(qkv.view(B, lc, 3 * d)[:, :, d:])
-        return SeqGather(ws["kv_send"], self.sp_group, out=ws["kv_cat"], scratch=ws["kv_full"])
+            ws["kv_send"] = torch.empty(B, lc, 2 * d, device=dev, dtype=BF16)
+            ws["kv_cat"] = torch.empty(B, L, 2 * d, device=dev, dtype=BF16)
+            units = B * nh * ((lc + 255) // 256)
+            ranges = [lc, tok0, L - tok0 - lc]                                            # local, before, after
+            ws["kv_splits"] = [self._splits_for(units, (n + 63) // 64) if n else 0 for n in ranges]
+            ws["kv_part"] = hip.attn_partial_workspace(B, nh, lc, sum(hip.attn_effective_splits(n, s) for n, s in zip(ranges, ws["kv_splits"]) if n), dev)
+        cd = self.cond
+        send, cat = ws["kv_send"], ws["kv_cat"]
+        flat = send.view(-1)
+        hip.rmsnorm_rope_scatter(None, None, qkv[:, d:2 * d], p["nk"], qkv[:, 2 * d:], None, flat, flat[d:], ld_out=2 * d, out_bs=lc * 2 * d,
+                                 col_block=d, block_stride=0, eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc,
+                                 token_offset=tok0, head_dim=hd)
+        works = [dist.all_gather_into_tensor(cat[b], send[b], group=self.sp_group, async_op=True) for b in range(B)]
+        hip.gemm(hbuf, p["wqkv"][:d], p["bqkv"][:d], out=qkv[:, 0:d])
+        hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0,
+                         head_dim=hd)
+        heads = lambda t: t.unflatten(2, (nh, hd))
+        if not self.sp_overlap:
+            for w in works:
+                w.wait()
+            hip.attn_fwd(q4, heads(cat[:, :, 0:d]), heads(cat[:, :, d:]), out=ao4, prescaled=True)
+            return
+        s_loc, s_before, s_after = ws["kv_splits"]
+        n = hip.attn_fwd_partial(q4, heads(send[:, :, 0:d]), heads(send[:, :, d:]), ws["kv_part"], 0, s_loc, prescaled=True)
+        for w in works:
+            w.wait()
+        if tok0 > 0:
+            n += hip.attn_fwd_partial(q4, heads(cat[:, :tok0, 0:d]), heads(cat[:, :tok0, d:]), ws["kv_part"], n, s_before, prescaled=True)
+        if tok0 + lc < L:
+            n += hip.attn_fwd_partial(q4, heads(cat[:, tok0 + lc:, 0:d]), heads(cat[:, tok0 + lc:, d:]), ws["kv_part"], n, s_after, prescaled=True)
+        hip.attn_merge(ao4, ws["kv_part"], n, prescaled=True)
 
     def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
         """All-gather of the head output [B, Lc, 192] -> [B, L, 192] (the reference's one collective,

@@ -26,9 +26,12 @@ _SIGNATURES = {
     "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
     "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
+    "flexam_attn_fwd_partial": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
+    "flexam_attn_merge": ([_P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
     "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
     "flexam_rmsnorm_rope": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
+    "flexam_rmsnorm_rope_scatter": ([_P, _L, _P, _P, _L, _P, _P, _L, _P, _P, _P, _L, _L, _I, _L, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
     "flexam_mod_table": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
     "flexam_small_linear_f32": ([_P, _L, _P, _I, _L, _P, _P, _L, _I, _I, _I, _I, _P], c_int),
     "flexam_sinusoid_embed": ([_P, _P, _I, _I, _P], c_int),
@@ -239,6 +242,49 @@ def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_u
     return out
 
 
+def attn_effective_splits(lk: int, splits: int) -> int:
+    """Key ranges a request for `splits` really gives: ranges hold whole 64-key tiles, empty trailing ranges are dropped."""
+    tiles = (lk + 63) // 64
+    splits = max(1, min(int(splits), tiles))
+    per = -(-tiles // splits)
+    return -(-tiles // per)
+
+
+def attn_partial_workspace(B, H, Lq, n_slots, device):
+    units = B * H * ((Lq + 255) // 256)
+    return (torch.empty(n_slots, units, 256, 128, device=device, dtype=F32), torch.empty(n_slots, units, 256, 2, device=device, dtype=F32))
+
+
+def attn_fwd_partial(q, k, v, ws, slot0, kv_splits=1, softmax_scale=None, prescaled=False):
+    """Partial softmax of q against THESE keys into workspace slots slot0 .. slot0 + kv_splits - 1 (see flexam_hip.h);
+    returns the number of slots written."""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != D:
+            raise RuntimeError("attn_fwd_partial: heads must be packed along the row (stride(2) == head_dim, stride(3) == 1)")
+    S = attn_effective_splits(Lk, kv_splits)
+    ws_o, ws_ml = ws
+    if slot0 + S > ws_o.shape[0] or ws_o.shape[1] != B * H * ((Lq + 255) // 256):
+        raise RuntimeError("attn_fwd_partial: workspace too small for these slots / this query shape")
+    scale = ATTN_PRESCALED if prescaled else (softmax_scale if softmax_scale is not None else D ** -0.5)
+    _check(lib().flexam_attn_fwd_partial(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1),
+                                         _ptr(v, BF16), v.stride(0), v.stride(1), B, H, Lq, Lk, D, scale, S, slot0,
+                                         _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()), "flexam_attn_fwd_partial")
+    return S
+
+
+def attn_merge(out, ws, n_slots, softmax_scale=None, prescaled=False):
+    """out [B, Lq, H, 128] bf16 = the softmax over the union of the key sets of workspace slots 0 .. n_slots - 1."""
+    B, Lq, H, D = out.shape
+    if out.stride(3) != 1 or out.stride(2) != D:
+        raise RuntimeError("attn_merge: heads must be packed along the row")
+    scale = ATTN_PRESCALED if prescaled else (softmax_scale if softmax_scale is not None else D ** -0.5)
+    _check(lib().flexam_attn_merge(_ptr(out, BF16), out.stride(0), out.stride(1), B, H, Lq, D, scale, n_slots, _ptr(ws[0], F32),
+                                   _ptr(ws[1], F32), _stream()), "flexam_attn_merge")
+    return out
+
+
 # ----------------------------------------------------------------------------- DiT row kernels
 def ln_modulate(x, out=None, eps=1e-6, shift=None, scale=None, row_index=None, rows_per_batch=0, ln_w=None, ln_b=None):
     M, C, ldx = _rows(x)
@@ -273,6 +319,19 @@ def rmsnorm_rope(q, wq, k=None, wk=None, eps=1e-6, rope_cos=None, rope_sin=None,
                                      M, C, eps, _ptr(rope_cos, F32), _ptr(rope_sin, F32), tokens_per_batch, token_offset,
                                      head_dim, _stream()), "flexam_rmsnorm_rope")
     return q_out, k_out
+
+
+def rmsnorm_rope_scatter(q, wq, k, wk, v, q_out, k_out, v_out, ld_out, out_bs, col_block, block_stride, eps=1e-6, rope_cos=None,
+                         rope_sin=None, tokens_per_batch=0, token_offset=0, head_dim=128):
+    """q/k/v: 2-D bf16 views [M, C] (q, v optional); *_out: bf16 tensors whose data pointers are the bases of the scattered
+    layout described in flexam_hip.h (element (m, col) -> (m // tpb) * out_bs + (m % tpb) * ld_out + (col // col_block) *
+    block_stride + col % col_block)."""
+    M, C, ldk = _rows(k)
+    _check(lib().flexam_rmsnorm_rope_scatter(_ptr(q, BF16), q.stride(0) if q is not None else 0, _ptr(wq, F32), _ptr(k, BF16), ldk,
+                                             _ptr(wk, F32), _ptr(v, BF16), v.stride(0) if v is not None else 0, _ptr(q_out, BF16),
+                                             _ptr(k_out, BF16), _ptr(v_out, BF16), ld_out, out_bs, col_block, block_stride, M, C, eps,
+                                             _ptr(rope_cos, F32), _ptr(rope_sin, F32), tokens_per_batch, token_offset, head_dim,
+                                             _stream()), "flexam_rmsnorm_rope_scatter")
 
 
 def mod_table(mod, e, out, rows_per_batch, scale_mask, mdens=None, dens=None, dens_slots=-1):

@@ -89,6 +89,19 @@ int flexam_attn_fwd_splitkv(const void* q, int64_t q_bs, int64_t q_rs, const voi
                             int head_dim, float softmax_scale, int kv_splits, int split_from_unit, float* ws_o, float* ws_ml,
                             void* stream);
 
+/* Attention over a PART of the keys, finished later: flexam_attn_fwd_partial leaves, for every query row, the un-normalised
+ * output and (reference, row sum) of the softmax over the keys it was given -- cut into kv_splits ranges, workspace slots slot0 ..
+ * slot0 + kv_splits - 1 (kv_splits must equal ceil(tiles / ceil(tiles / kv_splits)), tiles = ceil(Lk / 64)); any number of such
+ * calls on disjoint key sets may fill the slots, in any order; flexam_attn_merge combines n_slots of them into o.  Lets a
+ * sequence-parallel rank attend to its LOCAL K/V chunk while the all-gather of the other ranks' chunks is still in flight
+ * (the exchange the reference delegates to the missing FlexAM/dist, wan_transformer3d_FlexAM.py:801-815).
+ * ws_o: fp32 [n_slots, units, 256, 128], ws_ml: fp32 [n_slots, units, 256, 2], units = B * H * ceil(Lq / 256). */
+int flexam_attn_fwd_partial(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
+                            int64_t v_bs, int64_t v_rs, int B, int H, int Lq, int Lk, int head_dim, float softmax_scale,
+                            int kv_splits, int slot0, float* ws_o, float* ws_ml, void* stream);
+int flexam_attn_merge(void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int head_dim, float softmax_scale, int n_slots,
+                      const float* ws_o, const float* ws_ml, void* stream);
+
 /* out_bf16[m,:] = LN(x_f32[m,:]; eps) [* ln_w + ln_b] [* scale[row(m),:] + shift[row(m),:]]
  * row(m) = row_index[m] if row_index else m / rows_per_batch; scale rows already hold (1+scale),
  * shift rows already hold shift + density shift (flexam_mod_table).  Replaces WanLayerNorm +
@@ -110,6 +123,18 @@ int flexam_rmsnorm_rope(const void* q_in, int64_t ldq_in, void* q_out, int64_t l
                         int64_t ldk_in, void* k_out, int64_t ldk_out, const float* wk, int64_t M, int C, float eps,
                         const float* rope_cos, const float* rope_sin, int64_t tokens_per_batch, int64_t token_offset,
                         int head_dim, void* stream);
+
+/* Same arithmetic, written straight into a sequence-parallel SEND layout (no pack copy): q and k are normed + rotated, v is
+ * copied through; element (m, col) of each goes to
+ *   *_out + (m / tokens_per_batch) * out_bs + (m % tokens_per_batch) * ld_out + (col / col_block) * block_stride + col % col_block
+ * so a row is cut into column blocks (one per destination rank's group of heads) that land block_stride elements apart, and the
+ * three tensors interleave through their base pointers (q_out, k_out = q_out + col_block, ...).  q / v may be NULL (the K|V
+ * all-gather layout norms only k).  Replaces the missing FlexAM/dist exchange plumbing behind wan_transformer3d_FlexAM.py:801-815. */
+int flexam_rmsnorm_rope_scatter(const void* q_in, int64_t ldq_in, const float* wq, const void* k_in, int64_t ldk_in, const float* wk,
+                                const void* v_in, int64_t ldv_in, void* q_out, void* k_out, void* v_out, int64_t ld_out,
+                                int64_t out_bs, int col_block, int64_t block_stride, int64_t M, int C, float eps,
+                                const float* rope_cos, const float* rope_sin, int64_t tokens_per_batch, int64_t token_offset,
+                                int head_dim, void* stream);
 
 /* out[blk][r][j][:] = mod[blk][j][:] + e[r][j][:] + ((scale_mask>>j)&1) + density terms, where slot
  * s = (dens_slots >> 4j) & 0xF (0xF = none) adds mdens[blk][s][:] + dens[r / rows_per_batch][s][:].

@@ -172,3 +172,76 @@ def _parallel_decode_gather(rank, world):
 
 def test_parallel_vae_decode_assembles_row_bands():
     assert all(run_world(_parallel_decode_gather, 2))
+
+
+def _a2a_blocks_and_layouts(rank, world):
+    """The all-to-all exchange of the head-parallel mode, with the send / receive layouts the engine uses:
+    send [B, sp, lc, 3G] (block (b, j) -> rank j), receive [B, sp, lc, 3G] = [B, L, 3G] in token order, output chunks back to
+    [sp, B, lc, G], read as A[m, j*G + c] through per-K-block offsets."""
+    from flexam_amd.dist import all_to_all_blocks
+    B, lc, G, C = 2, 3, 64, 64 * world
+    L = lc * world
+    g = torch.Generator().manual_seed(11)
+    full = torch.randn(B, L, 3, C, generator=g)                                   # q|k|v of every token, all heads
+    mine = full[:, rank * lc:(rank + 1) * lc]                                     # this rank's tokens
+    send = torch.empty(B, world, lc, 3 * G)
+    for j in range(world):                                                        # what rmsnorm_rope_scatter writes
+        send[:, j] = mine[:, :, :, j * G:(j + 1) * G].reshape(B, lc, 3 * G)
+    recv = torch.empty(B, world, lc, 3 * G)
+    for b in range(B):
+        all_to_all_blocks([recv[b, i] for i in range(world)], [send[b, j] for j in range(world)])
+    got = recv.view(B, L, 3, G)
+    ok = bool(torch.equal(got, full[:, :, :, rank * G:(rank + 1) * G]))         # all tokens of MY head group, token order
+    out = got[:, :, 0] * 2 + 1                                                    # stand-in for attention: [B, L, G]
+    recv2 = torch.empty(world, B, lc, G)
+    chunks = out.view(B, world, lc, G)
+    for b in range(B):
+        all_to_all_blocks([recv2[j, b] for j in range(world)], [chunks[b, i] for i in range(world)])
+    koff = [(kb * 64 // G) * (B * lc * G) + (kb * 64) % G for kb in range(C // 64)]
+    flat = recv2.reshape(-1)
+    a = torch.stack([torch.cat([flat[m * G + koff[kb]: m * G + koff[kb] + 64] for kb in range(C // 64)]) for m in range(B * lc)])
+    want = (mine[:, :, 0] * 2 + 1).reshape(B * lc, C)                             # my tokens, ALL head groups
+    return ok and bool(torch.equal(a, want))
+
+
+def test_all_to_all_block_layouts_need_no_pack_or_unpack():
+    assert all(run_world(_a2a_blocks_and_layouts, 2))
+
+
+def _local_first_merge(rank, world):
+    """K|V all-gather mode: softmax over {local chunk} U {chunks before} U {chunks after} merged from partial
+    (un-normalised O, reference, row sum) triples equals attention over all keys."""
+    import math
+    from flexam_amd.dist import chunk_bounds
+    g = torch.Generator().manual_seed(5)
+    L, H, D = 24, 2, 16
+    q, k, v = (torch.randn(1, L, H, D, generator=g) for _ in range(3))
+    s, e = chunk_bounds(L, rank, world)
+    ql = q[:, s:e]
+    kv = torch.cat([k, v], dim=-1).flatten(2)                                     # [1, L, 2*H*D]
+    send = kv[:, s:e].contiguous()
+    cat = torch.empty(1, L, kv.shape[2])
+    dist.all_gather_into_tensor(cat[0], send[0])                                  # one gather per CFG row, token order
+    assert torch.equal(cat, kv)
+
+    def partial(keys, vals):
+        sc = torch.einsum("blhd,bmhd->bhlm", ql, keys) / math.sqrt(D) * math.log2(math.e)
+        ref = sc.max(dim=-1).values
+        p = torch.exp2(sc - ref.unsqueeze(-1))
+        return torch.einsum("bhlm,bmhd->blhd", p, vals), ref, p.sum(-1)
+    parts = [partial(k[:, s:e], v[:, s:e])]
+    if s > 0:
+        parts.append(partial(k[:, :s], v[:, :s]))
+    if e < L:
+        parts.append(partial(k[:, e:], v[:, e:]))
+    m = torch.stack([p[1] for p in parts]).max(dim=0).values
+    acc = sum(p[0] * torch.exp2(p[1] - m).permute(0, 2, 1).unsqueeze(-1) for p in parts)
+    l = sum(p[2] * torch.exp2(p[1] - m) for p in parts)
+    got = acc / l.permute(0, 2, 1).unsqueeze(-1)
+    want = O.attention(ql, k, v)
+    return float((got - want).abs().max())
+
+
+def test_local_chunk_first_partial_softmax_merge():
+    errs = run_world(_local_first_merge, 2)
+    assert max(errs) < 1e-5, errs

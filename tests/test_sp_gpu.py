@@ -1,8 +1,9 @@
-"""GPU: the sequence-parallel DiT engine (token chunks per rank, K/V all-gather per block, RoPE at
-global token offsets, final token all-gather) with TWO processes sharing the single test GPU.  The
-process group is gloo (RCCL refuses two ranks on one device); the engine/HIP code path is the one
-RCCL drives on an 8-GPU node.  Result must equal the single-process HIP result (same kernels, only
-the attention key order per tile changes -> fp32-rounding differences) and the reference golden."""
+"""GPU: the sequence-parallel DiT engine (token chunks per rank, K|V all-gather with local-chunk-first attention or
+all-to-all over heads per block, RoPE at global token offsets, final token all-gather) with 2 / 4 processes sharing the
+single test GPU.  The process group is gloo (RCCL refuses two ranks on one device); the engine/HIP code path is the one
+RCCL drives on an 8-GPU node (tests/test_nccl_gpu.py runs it under RCCL when the box has >= 2 GPUs).  Result must equal
+the single-process HIP result (same kernels; the partial-softmax merge / key order change only fp32 rounding) and the
+reference golden."""
 import os
 import socket
 
@@ -21,10 +22,15 @@ def _wide_cfg():
     return dict(O.DIT_TINY, dim=512, num_heads=4)
 
 
-def _worker(rank, world, port, ret, cfg_parallel, wide=False):
+def _worker(rank, world, port, ret, cfg_parallel, wide=False, backend="gloo"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    devname = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
     try:
         from flexam_amd import Wan2_2FunControlPipeline_FlexAM, Wan2_2Transformer3DModel_FlexAM
         from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
@@ -33,12 +39,12 @@ def _worker(rank, world, port, ret, cfg_parallel, wide=False):
         kw.pop("eps")
         m = Wan2_2Transformer3DModel_FlexAM(**kw)
         m.load_state_dict(C.dit_weights(cfg, 7), strict=True)
-        m = m.to("cuda:0")
+        m = m.to(devname)
         m.enable_multi_gpus_inference(cfg_parallel=cfg_parallel)
         if wide:
             assert m.engine().sp_mode == "ulysses" and m.engine().sp_size == world and m.engine().cfg_size == 1
         case = C.dit_case(cfg, 41, per_token_t=True)                    # L = 192 + 64 = 256 -> 128 tokens per rank
-        d = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+        d = {k: ([u.to(devname) for u in v] if isinstance(v, list) else (v.to(devname) if torch.is_tensor(v) else v)) for k, v in case.items()}
         out = m(**d).float().cpu()
         sc = C.sampler_case(cfg)
         pipe = Wan2_2FunControlPipeline_FlexAM(transformer=m)
@@ -51,15 +57,18 @@ def _worker(rank, world, port, ret, cfg_parallel, wide=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cfg_parallel,mode", [(2, False, "ulysses"), (2, False, "allgather"), (2, True, "ulysses"),
-                                                     (4, True, "ulysses"), (4, True, "allgather"), (4, False, "ulysses"),
-                                                     (4, None, "ulysses"), (2, None, "ulysses")])
+@pytest.mark.parametrize("world,cfg_parallel,mode", [(2, False, "ulysses"), (2, False, "allgather"), (2, False, "allgather-wait"),
+                                                     (2, True, "allgather"), (4, True, "ulysses"), (4, True, "allgather"),
+                                                     (4, False, "allgather"), (4, False, "allgather-wait"), (4, None, "allgather"),
+                                                     (2, None, "allgather")])
 def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel, mode, monkeypatch):
     """(2, False): pure sequence parallel (CFG pair batched, B = 2 per rank); (2, True): CFG-parallel, no per-block traffic;
-    (4, True): 2 CFG rows x 2 token chunks; (4, False): four token chunks, CFG pair batched -- what the default (None)
-    picks at 4 and 8 GPUs with the all-to-all exchange, while two ranks default to the CFG split.  mode: the exchange
-    around self-attention -- "ulysses" (all-to-all over heads, the default) or "allgather" (K|V all-gather)."""
-    monkeypatch.setenv("FLEXAM_SP_MODE", mode)             # inherited by the spawned ranks
+    (4, True): 2 CFG rows x 2 token chunks -- what the default (None) picks at 4 and 8 GPUs, while two ranks default to the
+    CFG split; (4, False): four token chunks, CFG pair batched (ranks 1, 2 have remote chunks on both sides of theirs).
+    mode: the exchange around self-attention -- "allgather" (K|V all-gather with local-chunk-first attention, the default),
+    "allgather-wait" (the same gather, one attention call after it: FLEXAM_SP_OVERLAP=0) or "ulysses" (all-to-all over heads)."""
+    monkeypatch.setenv("FLEXAM_SP_MODE", mode.split("-")[0])             # inherited by the spawned ranks
+    monkeypatch.setenv("FLEXAM_SP_OVERLAP", "0" if mode.endswith("-wait") else "1")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -97,11 +106,12 @@ def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel, mo
     assert bool(torch.isfinite(lat0).all())
 
 
-def test_four_ranks_default_layout_is_pure_ulysses_and_matches_single_process(monkeypatch):
-    """Four heads, four ranks, default layout: pure sequence parallelism with the all-to-all exchange and the CFG pair batched on
-    every rank (what bench.py runs at 4 and 8 GPUs).  No reference golden for this width: the check is against the single-process
-    HIP result of the same model and inputs, for the DiT forward and a 2-step sampler run."""
-    monkeypatch.delenv("FLEXAM_SP_MODE", raising=False)
+def test_four_ranks_pure_ulysses_matches_single_process(monkeypatch):
+    """Four heads, four ranks, FLEXAM_SP_MODE=ulysses: pure sequence parallelism with the all-to-all exchange and the CFG pair
+    batched on every rank (send layout written by the RMSNorm+RoPE launch, returned blocks read in place by the o-projection).
+    No reference golden for this width: the check is against the single-process HIP result of the same model and inputs, for the
+    DiT forward and a 2-step sampler run."""
+    monkeypatch.setenv("FLEXAM_SP_MODE", "ulysses")
     world = 4
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -109,7 +119,7 @@ def test_four_ranks_default_layout_is_pure_ulysses_and_matches_single_process(mo
     s.close()
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, None, True)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, False, True)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
