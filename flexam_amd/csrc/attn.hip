@@ -527,17 +527,17 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   const int units = B * H * p.q_blocks;
   FX_REQUIRE(split_from_unit >= 0 && split_from_unit <= units, FLEXAM_E_ARG, "attn_fwd: split_from_unit %d of %d units", split_from_unit, units);
   const int S = p.kv_splits, tps = p.tiles_per_split;
-  if (S == 1) split_from_unit = units;
-  if (split_from_unit > 0) {               // units [0, split_from_unit): one pass over all keys
-    p.unit0 = 0; p.n_units = split_from_unit; p.kv_splits = 1; p.tiles_per_split = tiles_all;
-    hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);
-  }
   if (partial_slot0 >= 0) {                // every unit, this call's keys only: partials into slots slot0 .. slot0 + S - 1, no merge
     FX_REQUIRE(S == kv_splits, FLEXAM_E_ARG, "attn_fwd_partial: %d key ranges requested but %d key tiles give %d (use ceil(tiles / ceil(tiles / S)))",
                kv_splits, tiles_all, S);
     p.unit0 = 0; p.n_units = units; p.kv_splits = S; p.tiles_per_split = tps; p.partial = 1; p.slot0 = partial_slot0;
     hipLaunchKernelGGL(kern, dim3(p.n_units * S), dim3(NT), smem, (hipStream_t)stream, p);
     return flexam_check_launch("flexam_attn_fwd_partial");
+  }
+  if (S == 1) split_from_unit = units;
+  if (split_from_unit > 0) {               // units [0, split_from_unit): one pass over all keys
+    p.unit0 = 0; p.n_units = split_from_unit; p.kv_splits = 1; p.tiles_per_split = tiles_all;
+    hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);
   }
   if (split_from_unit < units) {           // the rest: S key ranges each, then the merge
     p.unit0 = split_from_unit; p.n_units = units - split_from_unit; p.kv_splits = S; p.tiles_per_split = tps; p.partial = 1; p.n_slots = S;

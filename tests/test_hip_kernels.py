@@ -231,6 +231,62 @@ def test_attention_split_kv_matches_oracle(H, splits, b, h, lq, lk):
     assert_bf16_close(out, one.float().cpu(), ulps=2.0, atol=4e-3, msg="split vs single pass")
 
 
+@pytest.mark.parametrize("prescaled", [False, True])
+def test_attention_partial_calls_over_disjoint_key_sets_merge_to_the_full_softmax(H, prescaled):
+    """flexam_attn_fwd_partial + flexam_attn_merge: the keys are visited as (local chunk), (chunks before), (chunks after) in
+    separate calls with their own range counts -- the sequence-parallel local-chunk-first pattern -- and merged once."""
+    g = torch.Generator().manual_seed(91)
+    b, h, lq, lk = 2, 3, 300, 1456
+    c = 128 ** -0.5 * math.log2(math.e)
+    q0 = torch.randn(b, lq, h, 128, generator=g)
+    q = bf(q0 * c) if prescaled else bf(q0)
+    k = bf(torch.randn(b, lk, h, 128, generator=g))
+    v = bf(torch.randn(b, lk, h, 128, generator=g))
+    qd, kd, vd = q.to(dev()), k.to(dev()), v.to(dev())
+    lo, hi = 364, 728                                          # the "local" chunk (not tile aligned: 364 = 5.69 tiles)
+    ws = H.attn_partial_workspace(b, h, lq, 8, dev())
+    n = H.attn_fwd_partial(qd, kd[:, lo:hi], vd[:, lo:hi], ws, 0, 1, prescaled=prescaled)
+    n += H.attn_fwd_partial(qd, kd[:, :lo], vd[:, :lo], ws, n, 1, prescaled=prescaled)
+    n += H.attn_fwd_partial(qd, kd[:, hi:], vd[:, hi:], ws, n, 3, prescaled=prescaled)
+    assert n == 1 + 1 + H.attn_effective_splits(lk - hi, 3)
+    out = torch.empty(b, lq, h, 128, device=dev(), dtype=BF)
+    H.attn_merge(out, ws, n, prescaled=prescaled)
+    ref = _attn_ref(q / c if prescaled else q, k, v) if not prescaled else None
+    one = H.attn_fwd(qd, kd, vd, prescaled=prescaled)
+    assert_bf16_close(out, one.float().cpu(), ulps=2.0, atol=4e-3, msg="partial calls + merge vs single pass")
+    if ref is not None:
+        assert_bf16_close(out, ref, ulps=2.0, atol=6e-3, msg="partial calls + merge vs oracle")
+    with pytest.raises(RuntimeError):                          # more slots than the workspace holds
+        H.attn_fwd_partial(qd, kd, vd, ws, 7, 4)
+
+
+def test_rmsnorm_rope_scatter_writes_the_exchange_layouts(H):
+    """flexam_rmsnorm_rope_scatter: q, k normed + rotated and v copied straight into the sequence-parallel send layouts --
+    [B, sp, lc, 3G] of the all-to-all mode and [B, lc, 2C] (k | v only) of the all-gather mode -- bit-identical to the in-place
+    kernel followed by the pack copies it replaces."""
+    from flexam_amd.rope import rope_tables
+    g = torch.Generator().manual_seed(23)
+    c, hd, sp, B, lc, tok0 = 512, 128, 2, 2, 37, 74
+    G, L = c // sp, 148
+    qkv = bf(torch.randn(B * lc, 3 * c, generator=g)).to(dev())
+    wq, wk = (1 + 0.1 * torch.randn(c, generator=g)).to(dev()), (1 + 0.1 * torch.randn(c, generator=g)).to(dev())
+    cos, sin = (t.to(dev()) for t in rope_tables((1, 1, L), L, hd))
+    ref = qkv.clone()
+    H.rmsnorm_rope(ref[:, 0:c], wq, ref[:, c:2 * c], wk, rope_cos=cos, rope_sin=sin, tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
+    W = 3 * G
+    send = torch.zeros(B, sp, lc, W, device=dev(), dtype=BF)
+    flat = send.view(-1)
+    H.rmsnorm_rope_scatter(qkv[:, 0:c], wq, qkv[:, c:2 * c], wk, qkv[:, 2 * c:], flat, flat[G:], flat[2 * G:], ld_out=W, out_bs=sp * lc * W,
+                           col_block=G, block_stride=lc * W, rope_cos=cos, rope_sin=sin, tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
+    want = ref.view(B, lc, 3, sp, G).permute(0, 3, 1, 2, 4).reshape(B, sp, lc, W)
+    assert torch.equal(send, want)
+    kv = torch.zeros(B, lc, 2 * c, device=dev(), dtype=BF)
+    fk = kv.view(-1)
+    H.rmsnorm_rope_scatter(None, None, qkv[:, c:2 * c], wk, qkv[:, 2 * c:], None, fk, fk[c:], ld_out=2 * c, out_bs=lc * 2 * c, col_block=c,
+                           block_stride=0, rope_cos=cos, rope_sin=sin, tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
+    assert torch.equal(kv.view(B * lc, 2 * c), ref[:, c:])
+
+
 def test_attention_tail_split_matches_single_pass(H):
     """Only the work units of the last, partial round are split: units before `split_from_unit` take the one-pass kernel."""
     g = torch.Generator().manual_seed(77)
