@@ -38,7 +38,7 @@ for f in glob.glob(root + "/**/*kernel_stats.csv", recursive=True):
         dur[demangle(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]))
 table = {}
 for k, cs in sorted(agg.items()):
-    if not any(t in k for t in ("anonymous namespace", "flexam", "_GLOBAL__N_")) or "at::native" in k:
+    if not any(t in k for t in ("anonymous namespace", "flexam", "_GLOBAL__N_", "gemm_", "attn_")) or "at::native" in k:
         continue
     m = {c: sum(v) / len(v) for c, v in cs.items()}
     row = dict(counters={c: round(v, 1) for c, v in sorted(m.items())})
