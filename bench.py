@@ -122,7 +122,30 @@ def kernel_rooflines(eng, B, L, lc):
     out["gemm_oproj_residual"] = dict(flops=2.0 * M * d * d, sec=t)
     for v in out.values():
         v["tflops"] = v["flops"] / v["sec"] / 1e12
+    # bandwidth-bound kernels: ALGORITHMIC bytes / live time, against the 8 TB/s HBM3E peak
+    T = torch.randn(4, 6, d, device=qkv.device)
+    rows = (torch.arange(M, device=qkv.device) % 2).to(torch.int32)
+    t = time_kernel(lambda: hip.ln_modulate(xs, out=hbuf, shift=T[:, 0], scale=T[:, 1], row_index=rows))
+    out["ln_modulate"] = dict(bytes=M * d * 6.0, sec=t)                       # read fp32 x, write bf16
+    cd = eng.cond
+    if eng.sp_size == 1:
+        t = time_kernel(lambda: hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], rope_cos=cd["cos"], rope_sin=cd["sin"],
+                                                 tokens_per_batch=lc, head_dim=hd))
+        out["rmsnorm_rope_qk"] = dict(bytes=M * d * 8.0, sec=t)               # q and k: read + write bf16
     return out
+
+
+def sampler_step_roofline(pipe):
+    """The fused CFG + Euler + blend launch on the clip's latents (26 MB algorithmic: two head-token rows, latents r/w, known, mask)."""
+    from flexam_amd import hip
+    st = pipe._state
+    c, f, h, w = st["shape"]
+    L = st["ref_len"] + f * (h // 2) * (w // 2)
+    tok = torch.randn(2, L, 4 * c, device=st["latents"].device)
+    lat = st["latents"].clone()
+    t = time_kernel(lambda: hip.cfg_euler_blend(tok[0], tok[1], st["ref_len"], 6.0, -0.01, lat, st["known"], st["mask"]))
+    n = c * f * h * w
+    return dict(bytes=4.0 * (2 * n + 2 * n + n + n / c), sec=t)
 
 
 def cpu_baseline(L, cfg):
@@ -149,6 +172,42 @@ def cpu_baseline(L, cfg):
     return dict(value=steps_per_sec, unit="denoise-steps/sec", cores=torch.get_num_threads(), kind="port",
                 sample=f"1 of the 60 block-forwards of one step (oracle/dit.py block_forward, fp32, L={L}, d={d}) "
                        f"took {sec:.1f} s; value = 1/(60 x that), extrapolated", block_seconds=sec)
+
+
+def cpu_baseline_legs(cfg, layers=3):
+    """The other two legs of SURVEY 8(d)'s CPU baseline, each a bounded sample on the host cores (fp32 oracle):
+    (i)  BASELINE config 1 end to end -- 9x256x256 (latent [1,48,3,16,16], L = 256), 4 Euler steps, CFG pair -- with `layers` of
+         the 30 layers of the 5B-width model (the weights of 30 would be 20 GB of fp32), block time extrapolated to 30;
+    (ii) the Wan2.2 VAE decoder at its true widths on a 1/16-area latent [1,48,2,8,14] (first chunk + one cached 4-frame chunk),
+         extrapolated x16 in area and to the 25 latent frames of a 97-frame clip."""
+    from oracle import cases as C
+    from oracle import dit as O
+    from oracle import sampler as S
+    from oracle import vae as OV
+    c1 = dict(cfg, num_layers=layers)
+    sd = C.dit_weights(c1, 5)
+    sc = C.sampler_case(c1)
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        S.denoise_loop(lambda **k: O.dit_forward(sd, c1, **k), S.FlowMatchEulerSchedule(1000, 5.0), 4, sc["latents"], sc["context_uncond"],
+                       sc["context_cond"], sc["control_latents"], sc["additional_control"], ml, sc["masked_video_latents"],
+                       sc["ref_latents"], mask, pinned, 0.1, 6.0)
+    sec1 = time.perf_counter() - t0
+    del sd
+    v = dict(z_dim=48, dec_dim=256, dim_mult=(1, 2, 4, 4), temporal_up=(True, True, False))
+    vsd = C.vae_weights(v, seed=61, prefix="model.")
+    z = C.vae_case(seed=62, frames=2, h=8, w=14)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        OV.vae_decode(vsd, z, v["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
+    sec2 = time.perf_counter() - t0
+    return {
+        "config1_4_steps": dict(seconds=sec1, layers_run=layers, sample=f"9x256x256, 4 Euler steps, CFG pair, {layers} of 30 layers at d=3072 (oracle loop + dit_forward)",
+                                extrapolated_seconds_30_layers=sec1 * 30.0 / layers),
+        "vae_decode_chunk": dict(seconds=sec2, sample="true-width decoder, latent [1,48,2,8,14] (1/16 area): first chunk + one 4-frame chunk",
+                                 extrapolated_seconds_97x512x896=sec2 / 5.0 * 97.0 * 16.0),
+    }
 
 
 def time_vae(device, frames, height, width):
@@ -197,6 +256,7 @@ def main():
     ap.add_argument("--width", type=int, default=896)
     ap.add_argument("--layers", type=int, default=30, help="debug only: fewer layers makes the number INVALID")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-legs", action="store_true", help="skip the config-1 and VAE-chunk CPU baseline legs (keep the one-block leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     args = ap.parse_args()
@@ -268,9 +328,13 @@ def main():
     lc = L // eng.sp_size
     b_local = 1 if eng.cfg_size == 2 else B
     kern = None if args.no_kernel_timing else kernel_rooflines(eng, b_local, L, lc)
+    if kern is not None and pipe._state.get("known") is not None:
+        kern["cfg_euler_blend"] = sampler_step_roofline(pipe)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(L, cfg)
+        if not args.no_cpu_legs:
+            base["legs"] = cpu_baseline_legs(cfg)
 
     eng_cfg, eng_sp, eng_mode = eng.cfg_size, eng.sp_size, getattr(eng, "sp_mode", "-")
     if eng_mode == "allgather":
@@ -316,19 +380,25 @@ def main():
         if kern is not None:
             a = kern["attn_self"]
             traffic = None                       # HBM bytes per launch from the committed PMC passes (not collected live)
-            tpath = os.path.join(ROOT, "profiles", "r1m_attn_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r2_attn_traffic.json")
+            if not os.path.exists(tpath):
+                tpath = os.path.join(ROOT, "profiles", "r1m_attn_traffic.json")
             if world == 1 and (args.frames, args.height, args.width) == (97, 512, 896) and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0, true> (self-attention, head_dim 128, q pre-scaled by its RMSNorm weight)", "achieved": a["tflops"],
                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
-                                  "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (profiles/r1m_pmc_attn_*)",
+                                  "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the launches of one call (" + os.path.basename(tpath) + ")",
                                   "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"],
                                   "launch_note": "one self-attention call = attn_fwd_kernel<0, true> over the full rounds of work units + "
                                                  "attn_fwd_kernel<0, true> over the last partial round with its keys cut in 3 + attn_merge_kernel; "
                                                  "launch_ms is the whole call, so rocprofv3 shows 2 attn_fwd_kernel<0, true> rows per call "
                                                  "(launch_ms = 2 x its AverageNs + the merge)"}
-            result["kernels"] = {k: {"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1),
-                                     "frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} for k, v in kern.items()}
+            result["kernels"] = {k: ({"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1), "bound": "mfma",
+                                      "frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} if "flops" in v else
+                                     {"ms": round(v["sec"] * 1e3, 4), "gbs": round(v["bytes"] / v["sec"] / 1e9, 1), "bound": "hbm",
+                                      "frac": round(v["bytes"] / v["sec"] / 1e9 / PEAK_HBM_GBS, 4)}) for k, v in kern.items()}
+            result["kernels_note"] = ("live per-launch timing at this run's shapes; mfma rows: algorithmic FLOPs / 2.5 PFLOP/s, hbm rows: "
+                                      "algorithmic bytes (SURVEY 8d) / 8 TB/s; counter-side traffic and MFMA-busy: profiles/r2*_block_kernels_pmc.*")
         if base is not None:
             result["cpu_baseline"] = base
         print(json.dumps(result))
