@@ -21,6 +21,7 @@ State-dict keys are the reference's (`model.encoder...`, `model.conv1...`, `mode
     normalisation are folded into the head conv's weights (exact in fp32, one GEMM fewer).
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -179,6 +180,14 @@ class _Conv:
         self.cp = _round_up(ci, 64)
         wp = torch.zeros(co, kt, kh, kw, self.cp, device=device, dtype=F32)
         wp[..., :ci] = w.permute(0, 2, 3, 4, 1)
+        # K order (dt, dh, channel block, dw, 64 channels): the kw taps of one image row are consecutive K blocks, and they read
+        # the same 64-channel slice of rows shifted by ONE position -- the second and third hit the L2 lines the first just
+        # brought in.  (With the tap-major order (dt, dh, dw, channel block) a shifted re-read comes cp/64 K blocks later, after
+        # the XCD's 32 workgroups have pulled 32 x cp/64 x 32 KiB through its 4 MiB L2: the 3x3x3 convs at 256 x 448 then fetch
+        # every activation ~9 times over the fabric.)  FLEXAM_VAE_KORDER=tap restores the tap-major order (A/B only).
+        self.k_rowmajor = os.environ.get("FLEXAM_VAE_KORDER", "row") != "tap"
+        if self.k_rowmajor:
+            wp = wp.view(co, kt, kh, kw, self.cp // 64, 64).permute(0, 1, 2, 4, 3, 5)
         self.weight = wp.reshape(co, kt * kh * kw * self.cp).to(BF16).contiguous()
         self.bias = bias.detach().to(device, F32).contiguous()
         self.hist = kt - 1
@@ -195,11 +204,13 @@ class _Conv:
             self.buf = torch.zeros(guard * 2 + frames * hp * wp * self.cp, device=self.device, dtype=BF16)
             self.img = self.buf[guard:guard + frames * hp * wp * self.cp].view(frames, hp, wp, self.cp)
             offs = []
+            tap = lambda dt, dh, dw: (dt * hp * wp + (dh - self.kh // 2) * wp + (dw - self.kw // 2)) * self.cp
             for dt in range(self.kt):
                 for dh in range(self.kh):
-                    for dw in range(self.kw):
-                        base = (dt * hp * wp + (dh - self.kh // 2) * wp + (dw - self.kw // 2)) * self.cp
-                        offs += [base + cb * 64 for cb in range(self.cp // 64)]
+                    if self.k_rowmajor:
+                        offs += [tap(dt, dh, dw) + cb * 64 for cb in range(self.cp // 64) for dw in range(self.kw)]
+                    else:
+                        offs += [tap(dt, dh, dw) + cb * 64 for dw in range(self.kw) for cb in range(self.cp // 64)]
             self._koff = torch.tensor(offs, dtype=I64, device=self.device)
             self.shape = (h, w)
         return self.img
@@ -251,6 +262,9 @@ class _ConvS2D:
         self.co, self.ci, self.cs = co, ci, _round_up(ci, 64)
         wp = torch.zeros(co, 3, 3, self.cs, device=device, dtype=F32)
         wp[..., :ci] = w.permute(0, 2, 3, 1)
+        self.k_rowmajor = os.environ.get("FLEXAM_VAE_KORDER", "row") != "tap"      # see _Conv: (dh, channel block, dw, 64)
+        if self.k_rowmajor:
+            wp = wp.view(co, 3, 3, self.cs // 64, 64).permute(0, 1, 3, 2, 4)
         self.weight = wp.reshape(co, 9 * self.cs).to(BF16).contiguous()
         self.bias = bias.detach().to(device, F32).contiguous()
         self.t_cap, self.device, self.shape = t_cap, device, None
@@ -263,10 +277,12 @@ class _ConvS2D:
             self.buf = torch.zeros(self.t_cap * hp * wp * c4 + guard, device=self.device, dtype=BF16)
             self.img = self.buf[:self.t_cap * hp * wp * c4].view(self.t_cap, hp, wp, c4)
             offs = []
+            tap = lambda dh, dw: (((dh >> 1) * wp + (dw >> 1)) * 4 + (dh & 1) * 2 + (dw & 1)) * self.cs
             for dh in range(3):
-                for dw in range(3):
-                    base = (((dh >> 1) * wp + (dw >> 1)) * 4 + (dh & 1) * 2 + (dw & 1)) * self.cs
-                    offs += [base + cb * 64 for cb in range(self.cs // 64)]
+                if self.k_rowmajor:
+                    offs += [tap(dh, dw) + cb * 64 for cb in range(self.cs // 64) for dw in range(3)]
+                else:
+                    offs += [tap(dh, dw) + cb * 64 for dw in range(3) for cb in range(self.cs // 64)]
             self._koff = torch.tensor(offs, dtype=I64, device=self.device)
             self.shape = (h2, w2)
         return self.img

@@ -5,6 +5,7 @@ import torch
 from flexam_amd.wan_vae3_8 import AutoencoderKLWan3_8
 torch.manual_seed(0)
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 25
+what = sys.argv[2] if len(sys.argv) > 2 else "all"          # all | decode | encode
 with torch.device("cuda:0"):
     vae = AutoencoderKLWan3_8(spatial_compression_ratio=16)
     for n, p in vae.named_parameters():
@@ -17,7 +18,7 @@ with torch.device("cuda:0"):
 vae = vae.to(torch.bfloat16)
 z = torch.randn(1, 48, frames, 32, 56, device="cuda:0")
 torch.cuda.synchronize()
-for it in range(2):
+for it in range(2 if what in ("all", "decode") else 0):
     t0 = time.perf_counter()
     out = vae.decode(z).sample
     torch.cuda.synchronize()
@@ -25,13 +26,14 @@ for it in range(2):
     print(f"decode {tuple(z.shape)} -> {tuple(out.shape)}: {dt:.3f} s, finite={bool(torch.isfinite(out.float()).all())}, "
           f"absmax={float(out.float().abs().max()):.3f}, mem={torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 tflop = 33.7 * (frames - 1) + 33.7 / 4
-print(f"~{tflop:.0f} TFLOP -> {tflop / dt:.0f} TFLOP/s")
+if what in ("all", "decode"):
+    print(f"~{tflop:.0f} TFLOP -> {tflop / dt:.0f} TFLOP/s")
 
 # ---- encode: [1,3,1+4(frames-1),512,896] -> [1,96,frames,32,56]
 pix = 1 + 4 * (frames - 1)
 x = torch.rand(1, 3, pix, 512, 896, device="cuda:0") * 2 - 1
 torch.cuda.reset_peak_memory_stats()
-for it in range(2):
+for it in range(2 if what in ("all", "encode") else 0):
     t0 = time.perf_counter()
     post = vae.encode(x).latent_dist
     torch.cuda.synchronize()
@@ -61,7 +63,10 @@ def enc_flops(frames_pix, h=256, w=448, dim=160):
 
 
 tf = enc_flops(pix) / 1e12
-print(f"encode ~{tf:.0f} TFLOP -> {tf / dt:.0f} TFLOP/s")
+if what in ("all", "encode"):
+    print(f"encode ~{tf:.0f} TFLOP -> {tf / dt:.0f} TFLOP/s")
+if what != "all":
+    sys.exit(0)
 
 # ---- row-band (parallel) decode: time of ONE rank's band for world = 2, 4, 8 (all ranks do the same amount of work)
 eng = vae.engine()
