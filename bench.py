@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0       # dense fp8 MFMA (block-scaled f8f6f4 instructions)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -120,8 +121,21 @@ def kernel_rooflines(eng, B, L, lc):
     out["gemm_ffn2_residual"] = dict(flops=2.0 * M * d * f, sec=t)
     t = time_kernel(lambda: hip.gemm_gate_residual(ao, p["wo"], p["bo"], xs))
     out["gemm_oproj_residual"] = dict(flops=2.0 * M * d * d, sec=t)
+    if getattr(eng, "fp8", False):
+        w8 = eng._fp8_w[0]
+        a8, sa = hip.quantize_rows_fp8(hbuf, ws["a8"][:, :d], ws["sa"])
+        t = time_kernel(lambda: hip.gemm_fp8(a8, sa, w8["wqkv"], w8["s_wqkv"], p["bqkv"], out=qkv))
+        out["gemm_fp8_qkv"] = dict(flops=2.0 * M * 3 * d * d, sec=t)
+        t = time_kernel(lambda: hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH))
+        out["gemm_fp8_ffn1_gelu"] = dict(flops=2.0 * M * f * d, sec=t)
+        a8f, saf = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
+        t = time_kernel(lambda: hip.gemm_fp8_gate_residual(a8f, saf, w8["w2"], w8["s_w2"], p["b2"], xs))
+        out["gemm_fp8_ffn2_residual"] = dict(flops=2.0 * M * d * f, sec=t)
+        t = time_kernel(lambda: hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"]))
+        out["quantize_rows_fp8_ffn"] = dict(bytes=M * f * 3.0, sec=t)
     for v in out.values():
-        v["tflops"] = v["flops"] / v["sec"] / 1e12
+        if "flops" in v:
+            v["tflops"] = v["flops"] / v["sec"] / 1e12
     # bandwidth-bound kernels: ALGORITHMIC bytes / live time, against the 8 TB/s HBM3E peak
     T = torch.randn(4, 6, d, device=qkv.device)
     rows = (torch.arange(M, device=qkv.device) % 2).to(torch.int32)
@@ -255,6 +269,7 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=896)
     ap.add_argument("--layers", type=int, default=30, help="debug only: fewer layers makes the number INVALID")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: QKV / FFN GEMMs on fp8 MFMA; a SEPARATE line (dtype fp8), never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-legs", action="store_true", help="skip the config-1 and VAE-chunk CPU baseline legs (keep the one-block leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -287,6 +302,8 @@ def main():
     from flexam_amd.configs import WAN22_FUN_5B_FLEXAM
     cfg = dict(WAN22_FUN_5B_FLEXAM, num_layers=args.layers)
     model = build_model(cfg, device)
+    if args.fp8:
+        model.enable_fp8_gemm(True)
     if world > 1:
         cp = os.environ.get("FLEXAM_CFG_PARALLEL")
         model.enable_multi_gpus_inference(cfg_parallel=None if cp is None else cp == "1")
@@ -357,10 +374,13 @@ def main():
         result = {
             "metric": "denoise-steps/sec", "value": steps_per_sec, "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"Wan2.2-Fun-5B-FLEXAM DiT denoise step, {args.frames}x{args.height}x{args.width}, "
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
-                                   f"random-init bf16 weights, synthetic conditioning (BASELINE configs[1])",
+                                   f"random-init bf16 weights, synthetic conditioning "
+                                   + ("(BASELINE configs[1])" if (args.frames, args.height, args.width) == (97, 512, 896) and not args.fp8 else
+                                      "(BASELINE configs[4] shape family: " + ("fp8 e4m3 QKV/FFN GEMMs with per-row / per-channel scales, everything else bf16/fp32" if args.fp8 else "bf16")
+                                      + "; not the headline)"),
                        "parallelism": ((f"cfg{eng_cfg} x sp{eng_sp}: one CFG row per rank" + (", no per-block traffic" if eng_sp == 1 else
                                         f", token-chunk sequence parallel inside each half; exchange around self-attention (RCCL): {eng_mode}"))
                                        if eng_cfg == 2 else
@@ -373,6 +393,7 @@ def main():
             "sec_per_clip": (enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
             "dit_block_tflops": step_block_flops * steps_per_sec / 1e12,
             "dit_block_mfma_frac": step_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "dit_block_mfma_frac_note": "against the 2.5 PFLOP/s bf16 peak" + (" (QKV / FFN ran on the 5 PFLOP/s fp8 pipe: not a roofline fraction)" if args.fp8 else ""),
             "finite": finite,
         }
         if one_device or backend != "nccl":
@@ -394,7 +415,8 @@ def main():
                                                  "launch_ms is the whole call, so rocprofv3 shows 2 attn_fwd_kernel<0, true> rows per call "
                                                  "(launch_ms = 2 x its AverageNs + the merge)"}
             result["kernels"] = {k: ({"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1), "bound": "mfma",
-                                      "frac": round(v["tflops"] / PEAK_BF16_TFLOPS, 4)} if "flops" in v else
+                                      "peak": PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS,
+                                      "frac": round(v["tflops"] / (PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS), 4)} if "flops" in v else
                                      {"ms": round(v["sec"] * 1e3, 4), "gbs": round(v["bytes"] / v["sec"] / 1e9, 1), "bound": "hbm",
                                       "frac": round(v["bytes"] / v["sec"] / 1e9 / PEAK_HBM_GBS, 4)}) for k, v in kern.items()}
             result["kernels_note"] = ("live per-launch timing at this run's shapes; mfma rows: algorithmic FLOPs / 2.5 PFLOP/s, hbm rows: "

@@ -103,6 +103,8 @@ class DiTEngine:
         # beyond this many bytes (masks with fractional edges: hundreds of distinct timesteps) ONE [R, 6, C] table is rebuilt
         # per layer instead -- the reference's own footprint is [B, L, 6, C] per step (wan_transformer3d_FlexAM.py:944)
         self.table_limit = int(os.environ.get("FLEXAM_ADALN_TABLE_BYTES", str(1 << 30)))
+        self.fp8 = False                            # BASELINE configs[4]: QKV / FFN GEMMs on fp8 MFMA (enable_fp8)
+        self._fp8_w = None
         self._pack()
 
     # ------------------------------------------------------------------ weights
@@ -162,6 +164,23 @@ class DiTEngine:
         self.world_group = world_group if cfg_size > 1 else sp_group
         self.world_size = world_size if world_size is not None else sp_size
         self.cfg_size, self.cfg_row = cfg_size, cfg_row
+        self._ws.clear()
+
+    def enable_fp8(self, on: bool = True):
+        """QKV and FFN projections on the fp8 (OCP e4m3) MFMA path: weights quantised once per output channel, activations per
+        row and per call (flexam_quantize_rows_fp8), fp32 accumulation, the same fused epilogues.  Attention, the output / cross
+        projections, norms, modulation and the residual stream are unchanged.  BASELINE.json configs[4] ("fp8 MFMA QKV/FFN
+        variant"); the reference's own fp8 mode only stores weights in fp8 (FlexAM/utils/fp8_optimization.py:1-57)."""
+        if on and not self.fused:
+            raise NotImplementedError("fp8 GEMMs run in the engine's fused block path (no replaced / re-bound blocks)")
+        if on and self._fp8_w is None:
+            self._fp8_w = []
+            for p in self.blocks:
+                q = {}
+                for name in ("wqkv", "w1", "w2"):
+                    q[name], q["s_" + name] = hip.quantize_rows_fp8(p[name])
+                self._fp8_w.append(q)
+        self.fp8 = bool(on)
         self._ws.clear()
 
     def set_sequence_parallel(self, group, rank: int, size: int):
@@ -264,6 +283,8 @@ class DiTEngine:
                 qkv=torch.empty(m, 3 * d, device=dev, dtype=BF16), ao=torch.empty(m, d, device=dev, dtype=BF16),
                 ffn=torch.empty(m, self.ffn, device=dev, dtype=BF16),
                 head=torch.empty(m, self.head_w.shape[0], device=dev, dtype=F32))}
+            if self.fp8:
+                self._ws[key].update(a8=torch.empty(m, self.ffn, device=dev, dtype=torch.uint8), sa=torch.empty(m, device=dev, dtype=F32))
         return self._ws[key]
 
     # ------------------------------------------------------------------ per-step
@@ -386,7 +407,12 @@ class DiTEngine:
                 self._allgather_attention(qkv, hbuf, p, ao4, q4, B, lc, tok0)
                 hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             else:
-                hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
+                if self.fp8:
+                    w8 = self._fp8_w[i]
+                    a8, sa = hip.quantize_rows_fp8(hbuf, ws["a8"][:, :d], ws["sa"])
+                    hip.gemm_fp8(a8, sa, w8["wqkv"], w8["s_wqkv"], p["bqkv"], out=qkv)
+                else:
+                    hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
                 hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
                                  tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
                 hip.attn_fwd(q4, k4, v4, out=ao4, prescaled=True)
@@ -401,8 +427,15 @@ class DiTEngine:
             hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
             # FFN
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
-            hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
-            hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
+            if self.fp8:
+                w8 = self._fp8_w[i]
+                a8, sa = hip.quantize_rows_fp8(hbuf, ws["a8"][:, :d], ws["sa"])
+                hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
+                a8, sa = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
+                hip.gemm_fp8_gate_residual(a8, sa, w8["w2"], w8["s_w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
+            else:
+                hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
+                hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
         if teacache is not None and calc:                  # residual = x_after_blocks - x_before (FX.py:1048-1051), kept on the GPU
             hip.axpby(ori, 1.0, xres, -1.0)
             setattr(teacache, key, ori)

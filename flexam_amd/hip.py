@@ -24,6 +24,9 @@ _SIGNATURES = {
     "flexam_device_check": ([], c_int),
     "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _L, _P], c_int),
     "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P], c_int),
+    "flexam_quantize_rows_fp8": ([_P, _L, _P, _L, _P, _L, _I, _P], c_int),
+    "flexam_gemm_fp8": ([_P, _L, _P, _P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P], c_int),
+    "flexam_gemm_fp8_gate_residual": ([_P, _L, _P, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
     "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_fwd_partial": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
@@ -171,6 +174,48 @@ def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0
     _check(lib().flexam_gemm_bf16_gate_residual(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(x, F32), ldx,
                                                 _ptr(gate, F32), gate_ld, _ptr(gate_row, I32), rows_per_batch, M, N, K,
                                                 _ptr(a_koff, I64), ws.data_ptr(), ws.numel(), st), "flexam_gemm_bf16_gate_residual")
+    return x
+
+
+# ----------------------------------------------------------------------------- fp8 GEMM (BASELINE configs[4])
+U8 = torch.uint8
+
+
+def quantize_rows_fp8(x, q=None, scale=None):
+    """x [M, K] bf16 rows -> (q [M, K] uint8 holding OCP e4m3 bytes, scale [M] fp32) with x ~ q * scale[:, None]."""
+    M, K, ldx = _rows(x)
+    if q is None:
+        q = torch.empty(M, K, device=x.device, dtype=U8)
+    if scale is None:
+        scale = torch.empty(M, device=x.device, dtype=F32)
+    _check(lib().flexam_quantize_rows_fp8(_ptr(x, BF16), ldx, _ptr(q, U8), q.stride(0), _ptr(scale, F32), M, K, _stream()),
+           "flexam_quantize_rows_fp8")
+    return q, scale
+
+
+def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, out=None, epilogue=EPI_NONE):
+    """out[M,N] bf16 = epi((a8 @ w8^T) * a_scale[:, None] * w_scale[None, :] + bias); a8 [M,K], w8 [N,K] e4m3 bytes."""
+    M, K, lda = _rows(a8)
+    N, wk, ldw = _rows(w8)
+    if wk != K:
+        raise RuntimeError(f"gemm_fp8: K mismatch a {K} vs w {wk}")
+    if out is None:
+        out = torch.empty(M, N, device=a8.device, dtype=BF16)
+    _check(lib().flexam_gemm_fp8(_ptr(a8, U8), lda, _ptr(a_scale, F32), _ptr(w8, U8), ldw, _ptr(w_scale, F32), _ptr(bias, F32),
+                                 _ptr(out, BF16), out.stride(0), M, N, K, epilogue, _stream()), "flexam_gemm_fp8")
+    return out
+
+
+def gemm_fp8_gate_residual(a8, a_scale, w8, w_scale, bias, x, gate=None, gate_row=None, rows_per_batch=0):
+    """x[M,N] (fp32, in place) += bf16((a8 @ w8^T) * scales + bias) * gate[row]."""
+    M, K, lda = _rows(a8)
+    N, wk, ldw = _rows(w8)
+    xm, xn, ldx = _rows(x)
+    if wk != K or xm != M or xn != N:
+        raise RuntimeError("gemm_fp8_gate_residual: shape mismatch")
+    _check(lib().flexam_gemm_fp8_gate_residual(_ptr(a8, U8), lda, _ptr(a_scale, F32), _ptr(w8, U8), ldw, _ptr(w_scale, F32), _ptr(bias, F32),
+                                               _ptr(x, F32), ldx, _ptr(gate, F32), gate.stride(0) if gate is not None else 0,
+                                               _ptr(gate_row, I32), rows_per_batch, M, N, K, _stream()), "flexam_gemm_fp8_gate_residual")
     return x
 
 

@@ -481,6 +481,8 @@ class WanTransformer3DModel_FlexAM(nn.Module):
             self._cond_key = None
             if self._parallel is not None:
                 self._engine.set_parallel(**self._parallel)
+            if getattr(self, "_fp8", False):
+                self._engine.enable_fp8(True)
         return self._engine
 
     def _conditioning_key(self, context, y, full_ref, additional_control, density, latent_shape):
@@ -517,6 +519,13 @@ class WanTransformer3DModel_FlexAM(nn.Module):
 
     def disable_cfg_skip(self):
         self.cfg_skip_ratio, self.current_steps, self.num_inference_steps = None, 0, None
+
+    def enable_fp8_gemm(self, on: bool = True):
+        """This build's extension (BASELINE.json configs[4]): QKV and FFN projections on fp8 (OCP e4m3) MFMA with per-row /
+        per-channel scales; see DiTEngine.enable_fp8.  Off by default; parity tolerance is the fp8 one (tests/test_fp8_gpu.py)."""
+        self._fp8 = bool(on)
+        if self._engine is not None:
+            self._engine.enable_fp8(self._fp8)
 
     def enable_riflex(self, k=6, L_test=66, L_test_scale=4.886):
         self._riflex = (k, L_test, L_test_scale)

@@ -67,6 +67,21 @@ int flexam_gemm_bf16_gate_residual(const void* A, int64_t lda, const void* W, in
                                    int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, const int64_t* a_koff,
                                    void* ws, int64_t ws_bytes, void* stream);
 
+/* fp8 variant of the two GEMMs above for the DiT's QKV / FFN projections (BASELINE.json configs[4]; selected explicitly, never
+ * the default).  A8 [M,K], W8 [N,K]: OCP e4m3 bytes, K contiguous, K % 128 == 0, lda / ldw % 16 == 0; a_scale [M], w_scale [N]
+ * fp32 row scales (value = byte * scale); fp32 accumulation on the block-scaled MFMA with unit block scales:
+ *   C = epi((A8 . W8^T) * a_scale[m] * w_scale[n] + bias[n])   (bf16 out; epilogue NONE | GELU_TANH)
+ *   X[m,n] += bf16(...)[m,n] * gate[row(m), n]                  (gate-residual form, as flexam_gemm_bf16_gate_residual)
+ * flexam_quantize_rows_fp8: q[m,:] = e4m3(x[m,:] / scale[m]), scale[m] = absmax(x[m,:]) / 448 (bf16 in); used for activations per
+ * call and for weights once.  The reference only STORES weights as float8_e4m3fn and upcasts them per call
+ * (FlexAM/utils/fp8_optimization.py:1-57); fp8 arithmetic is this build's addition. */
+int flexam_quantize_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t M, int K, void* stream);
+int flexam_gemm_fp8(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw, const float* w_scale,
+                    const float* bias, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, void* stream);
+int flexam_gemm_fp8_gate_residual(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw, const float* w_scale,
+                                  const float* bias, float* X, int64_t ldx, const float* gate, int64_t gate_ld,
+                                  const int32_t* gate_row, int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, void* stream);
+
 /* Flash attention forward, head_dim 128, non-causal, keys [0, Lk): o = softmax(q k^T * scale) v.
  * q/k/v/o are [B, L, H, 128] views given by batch stride `*_bs` and row stride `*_rs` (elements);
  * head h starts at column h*128 of a row.  bf16 in/out, fp32 softmax/accumulate.

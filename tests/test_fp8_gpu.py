@@ -1,0 +1,178 @@
+"""GPU tests of the fp8 (OCP e4m3) GEMM path -- BASELINE.json configs[4], "fp8 MFMA QKV/FFN variant" (this build's addition: the
+reference only stores weights as float8_e4m3fn, FlexAM/utils/fp8_optimization.py:1-57).
+
+Tolerances: integer-valued operands that e4m3 holds exactly and power-of-two scales -> bit exact; quantisation: half an e4m3 ulp
+(2^-4 relative, 2^-10 of the row maximum absolute); the GEMM against an fp32 product of the DEQUANTISED operands: fp32 accumulation
+error only; the fp8 DiT against the fp32 oracle: e4m3 carries 3 mantissa bits, every QKV / FFN output picks up a few percent of
+zero-mean error that the fp32 residual stream and the norms average down -> stated bound rel-RMS <= 3e-2, PSNR >= 40 dB on model
+outputs (the bf16 path's bound is 1.5e-2 / 40 dB; measured here: 1.3e-2 / 56 dB at width 256)."""
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import dit as O
+
+pytestmark = pytest.mark.gpu
+BF, F8 = torch.bfloat16, torch.float8_e4m3fn
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def H():
+    from flexam_amd import hip
+    hip.device_check()
+    return hip
+
+
+def as_e4m3_bytes(x_int):
+    """Small integers (|v| <= 8 are exact in e4m3) -> uint8 tensor of their e4m3 encodings."""
+    return x_int.float().to(F8).view(torch.uint8)
+
+
+def test_quantize_rows(H):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(300, 3072, generator=g) * torch.rand(300, 1, generator=g) * 5).to(BF)
+    x[7] = 0                                                     # an all-zero row keeps scale 1
+    q, s = H.quantize_rows_fp8(x.to(dev()))
+    amax = x.float().abs().amax(dim=1)
+    want_s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    torch.testing.assert_close(s.cpu(), want_s, rtol=1e-6, atol=0)
+    deq = q.cpu().view(F8).float() * s.cpu()[:, None]
+    err = (deq - x.float()).abs()
+    bound = 2.0 ** -4 * x.float().abs() + 2.0 ** -10 * amax[:, None] + 1e-12
+    assert not (err > bound).any(), f"max quantisation error {float((err - bound).max()):.3g} over the e4m3 half-ulp bound"
+    assert float(deq.abs().amax()) <= float(amax.max()) * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (300, 200, 256), (1000, 772, 384), (2048, 1536, 3072), (77, 3072, 640)])
+def test_gemm_fp8_exact_integers(H, m, n, k):
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randint(-4, 5, (m, k), generator=g)
+    w = torch.randint(-4, 5, (n, k), generator=g)
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    sa = 2.0 ** torch.randint(-2, 3, (m,), generator=g).float()
+    sw = 2.0 ** torch.randint(-2, 3, (n,), generator=g).float()
+    want = (a.float() @ w.float().t()) * sa[:, None] * sw[None, :] + b
+    out = H.gemm_fp8(as_e4m3_bytes(a).to(dev()), sa.to(dev()), as_e4m3_bytes(w).to(dev()), sw.to(dev()), b.to(dev()))
+    torch.testing.assert_close(out.float().cpu(), want.to(BF).float(), rtol=0, atol=0)
+    x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+    gate = torch.randint(-2, 3, (3, n), generator=g).float()
+    rows = torch.randint(0, 3, (m,), generator=g, dtype=torch.int32)
+    x = x0.clone().to(dev())
+    H.gemm_fp8_gate_residual(as_e4m3_bytes(a).to(dev()), sa.to(dev()), as_e4m3_bytes(w).to(dev()), sw.to(dev()), b.to(dev()), x, gate.to(dev()),
+                             rows.to(dev()))
+    torch.testing.assert_close(x.cpu(), x0 + want.to(BF).float() * gate[rows.long()], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
+def test_gemm_fp8_every_tile_height(H, mt, monkeypatch):
+    monkeypatch.setenv("FLEXAM_GEMM_MT", str(mt))
+    g = torch.Generator().manual_seed(50 + mt)
+    m, n, k = 1000, 772, 256
+    a, w = torch.randint(-3, 4, (m, k), generator=g), torch.randint(-3, 4, (n, k), generator=g)
+    one_m, one_n = torch.ones(m), torch.ones(n)
+    want = a.float() @ w.float().t()
+    out = H.gemm_fp8(as_e4m3_bytes(a).to(dev()), one_m.to(dev()), as_e4m3_bytes(w).to(dev()), one_n.to(dev()))
+    torch.testing.assert_close(out.float().cpu(), want.to(BF).float(), rtol=0, atol=0)
+
+
+def test_gemm_fp8_at_the_dit_shapes(H):
+    """QKV (N = 9216, K = 3072), FFN1 + GELU (N = 14336) and FFN2 + gated residual (K = 14336) at M = 23296: many units per
+    persistent workgroup, counted waits across units.  Sparse +-1 operands keep every sum an integer bf16 holds exactly."""
+    g = torch.Generator().manual_seed(77)
+    m = 23296
+    rows = torch.cat([torch.arange(0, 256), torch.arange(m - 256, m), torch.randint(256, m - 256, (512,), generator=g)])
+    for n, k, epi in ((9216, 3072, "none"), (14336, 3072, "gelu"), (3072, 14336, "resid")):
+        a = (torch.randint(-1, 2, (m, k), generator=g, dtype=torch.int8) * (torch.randint(0, 16, (m, k), generator=g, dtype=torch.int8) == 0))
+        w = torch.randint(-1, 2, (n, k), generator=g, dtype=torch.int8)
+        b = torch.randint(-8, 9, (n,), generator=g).float()
+        sa, sw = torch.full((m,), 0.5), torch.full((n,), 2.0)
+        a8, w8 = as_e4m3_bytes(a).to(dev()), as_e4m3_bytes(w).to(dev())
+        want = a[rows].float() @ w.float().t() + b
+        assert float(want.abs().max()) < 256
+        if epi == "resid":
+            x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+            x = x0.clone().to(dev())
+            H.gemm_fp8_gate_residual(a8, sa.to(dev()), w8, sw.to(dev()), b.to(dev()), x)
+            assert torch.equal(x[rows.to(dev())].cpu(), x0[rows] + want)
+            col = (x - x0.to(dev())).double().sum(dim=0).cpu()
+            assert torch.equal(col, a.double().sum(dim=0) @ w.double().t() + b.double() * m)
+        else:
+            out = H.gemm_fp8(a8, sa.to(dev()), w8, sw.to(dev()), b.to(dev()), epilogue=H.EPI_GELU_TANH if epi == "gelu" else H.EPI_NONE)
+            got = out[rows.to(dev())].float().cpu()
+            if epi == "gelu":
+                ref = torch.nn.functional.gelu(want, approximate="tanh")
+                assert not ((got - ref).abs() > 2.0 * 2.0 ** -8 * ref.abs() + 1e-2).any()
+            else:
+                assert torch.equal(got, want)
+
+
+def test_gemm_fp8_on_real_valued_data_matches_the_dequantised_product(H):
+    g = torch.Generator().manual_seed(9)
+    m, n, k = 1024, 768, 3072
+    x = torch.randn(m, k, generator=g).to(BF)
+    w = (torch.randn(n, k, generator=g) * 0.03).to(BF)
+    b = torch.randn(n, generator=g)
+    a8, sa = H.quantize_rows_fp8(x.to(dev()))
+    w8, sw = H.quantize_rows_fp8(w.to(dev()))
+    out = H.gemm_fp8(a8, sa, w8, sw, b.to(dev())).float().cpu()
+    deq = (a8.cpu().view(F8).float() * sa.cpu()[:, None]) @ (w8.cpu().view(F8).float() * sw.cpu()[:, None]).t() + b
+    rel = ((out - deq).pow(2).mean().sqrt() / deq.pow(2).mean().sqrt()).item()
+    full = x.float() @ w.float().t() + b
+    rel_q = ((out - full).pow(2).mean().sqrt() / full.pow(2).mean().sqrt()).item()
+    print(f"fp8 GEMM vs dequantised fp32 product: rel-rms {rel:.2e}; vs the unquantised product: {rel_q:.2e}")
+    assert rel < 4e-3 and rel_q < 6e-2                       # bf16 rounding of the output / e4m3 quantisation of both operands
+    with pytest.raises(RuntimeError):
+        H.gemm_fp8(a8[:, :100], sa, w8[:, :100], sw)         # K must be a multiple of 128
+
+
+def test_dit_with_fp8_qkv_ffn_vs_oracle_and_vs_bf16_path():
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+    cfg = dict(O.DIT_TINY, num_layers=3)
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    sd = C.dit_weights(cfg, 19)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    case = C.dit_case(cfg, 5)
+    d = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    want = O.dit_forward(sd, cfg, **case)
+    base = m(**d).float().cpu()
+    m.enable_fp8_gemm(True)
+    got = m(**d).float().cpu()
+    m.enable_fp8_gemm(False)
+    again = m(**d).float().cpu()
+    torch.testing.assert_close(again, base, rtol=0, atol=0)                    # switching back restores the bf16 path exactly
+    rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    p = C.psnr(got, want)
+    rel_b = ((got - base).pow(2).mean().sqrt() / base.pow(2).mean().sqrt()).item()
+    print(f"fp8 QKV/FFN DiT vs fp32 oracle: rel-rms {rel:.3e}, psnr {p:.1f} dB; vs the bf16 HIP path: rel-rms {rel_b:.3e}")
+    assert rel <= 3e-2 and p >= 40.0
+    assert rel_b > 1e-4                                                         # the fp8 path really ran
+
+
+def test_fp8_one_layer_model_at_5b_width():
+    """d = 3072, 24 heads, ffn 14336: whole forward of a one-layer model with the fp8 QKV / FFN GEMMs on a [2,48,7,32,56] latent
+    (L = 3584) vs the fp32 oracle."""
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+    cfg = dict(O.DIT_5B, num_layers=1)
+    sd = C.dit_weights(cfg, 13)
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    m.enable_fp8_gemm(True)
+    case = C.dit_case(cfg, 14, frames=7, h=32, w=56, batch=2, text_lens=(77, 126))
+    d = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    got = m(**d).float().cpu()
+    with torch.no_grad():
+        want = O.dit_forward(sd, cfg, **case)
+    rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    p = C.psnr(got, want)
+    print(f"fp8 one-layer 5B-width model: rel-rms {rel:.3e}, psnr {p:.1f} dB")
+    assert rel <= 3e-2 and p >= 40.0
