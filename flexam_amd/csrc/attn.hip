@@ -17,6 +17,8 @@
 //    v_permlane32_swap, and the bf16-packed P registers are directly the B operand of
 //    O^T += V^T.P^T (accumulator-as-operand with the permuted-k order of the guide);
 //  * softmax scale and log2(e) are folded into one FMA in front of v_exp_f32.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -52,6 +54,7 @@ struct AttnParams {
   // this call are only PART of the softmax: local-chunk-first attention under a sequence-parallel K|V all-gather);
   // n_slots: slots the merge kernel adds up
   int partial, slot0, n_slots;
+  int prio_young;       // tuning switch (FLEXAM_ATTN_PRIO=1): s_setprio 1 for waves 4-7, the arbitration losers of every segment (guide, two waves per SIMD, item 4)
 };
 
 // byte offset of 16-byte chunk `ch` (0..15) of key row `row` in a [64][128] bf16 tile, image (b)
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
+  if (p.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   const int nwg = p.n_units * p.kv_splits;
   int bid = blockIdx.x;
@@ -510,6 +514,10 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.kv_splits = (tiles_all + p.tiles_per_split - 1) / p.tiles_per_split;     // drop empty trailing splits
   p.ws_o = ws_o; p.ws_ml = ws_ml;
   p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits;
+  {
+    const char* e = getenv("FLEXAM_ATTN_PRIO");           // read per call: tools/ab_attn_prio.py flips it inside one process
+    p.prio_young = e ? atoi(e) : 0;
+  }
   FX_REQUIRE((int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB

@@ -17,12 +17,15 @@ __device__ __forceinline__ float row_sum(float v, float* red) { return block_sum
 // reductions are wave shuffles (no LDS, no barrier), four rows per 256-thread block.  The block-per-row form below spends
 // its time in two block reductions per 12 KiB row; this one keeps 6 x 32 B loads per lane in flight.
 // ------------------------------------------------------------------------------------------
-template <int NV8>
+// FP8: the output row is written as OCP e4m3 bytes with a per-row scale (absmax / 448) -- the A operand of flexam_gemm_fp8 -- instead
+// of bf16: the row is in registers anyway, so the quantiser costs one more wave reduction and no second pass over HBM.
+template <int NV8, bool FP8 = false>
 __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, float eps,
                                                                const float* __restrict__ shift, const float* __restrict__ scale,
                                                                int64_t tab_ld, const int32_t* __restrict__ row_index,
                                                                int64_t rows_per_batch, const float* __restrict__ ln_w,
-                                                               const float* __restrict__ ln_b, bf16* __restrict__ out, int64_t ldo) {
+                                                               const float* __restrict__ ln_b, bf16* __restrict__ out, int64_t ldo,
+                                                               float* __restrict__ row_scale = nullptr) {
   constexpr int C = 512 * NV8;
   const int lane = threadIdx.x & 63;
   const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -56,6 +59,40 @@ __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(const float* __re
     const int64_t r = row_index ? (int64_t)row_index[m] : m / rows_per_batch;
     sh = shift + r * tab_ld;
     sc = scale + r * tab_ld;
+  }
+  if constexpr (FP8) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = (i * 64 + lane) * 8 + h * 4;
+        f32x4 y = (v[i][h] - mean) * rstd;
+        if (ln_w) y = y * *(const f32x4*)(ln_w + c) + *(const f32x4*)(ln_b + c);
+        if (sh) y = y * *(const f32x4*)(sc + c) + *(const f32x4*)(sh + c);
+        v[i][h] = y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(y[j]));
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float qs = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / qs;
+    if (lane == 0) row_scale[m] = qs;
+    uint8_t* qrow = (uint8_t*)out + m * ldo;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      u32x2 o;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][h][0] * inv, v[i][h][1] * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][h][2] * inv, v[i][h][3] * inv, w, true);
+        o[h] = (unsigned)w;
+      }
+      *(u32x2*)(qrow + (i * 64 + lane) * 8) = o;
+    }
+    return;
   }
   bf16* orow = out + m * ldo;
 #pragma unroll
@@ -532,6 +569,27 @@ extern "C" int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C,
   DISPATCH_VPT(C, hipLaunchKernelGGL(ln_modulate_kernel<VPT>, dim3((unsigned)M), dim3(RT), 0, (hipStream_t)stream, x, ldx, C, eps,
                                      shift, scale, tab_ld, row_index, rows_per_batch, ln_w, ln_b, (bf16*)out, ldo));
   return flexam_check_launch("flexam_ln_modulate");
+}
+
+extern "C" int flexam_ln_modulate_fp8(const float* x, int64_t ldx, int64_t M, int C, float eps, const float* shift, const float* scale,
+                                      int64_t tab_ld, const int32_t* row_index, int64_t rows_per_batch, const float* ln_w,
+                                      const float* ln_b, void* q_out, int64_t ldq, float* row_scale, void* stream) {
+  FX_REQUIRE(x && q_out && row_scale && M > 0, FLEXAM_E_ARG, "ln_modulate_fp8: null pointer or empty");
+  FX_REQUIRE(C % 512 == 0 && C <= 4096, FLEXAM_E_SHAPE, "ln_modulate_fp8: row width %d must be a multiple of 512, at most 4096", C);
+  FX_REQUIRE(ldx % 4 == 0 && ldq % 8 == 0, FLEXAM_E_SHAPE, "ln_modulate_fp8: ldx%%4, ldq%%8 required");
+  FX_REQUIRE((shift == nullptr) == (scale == nullptr) && (ln_w == nullptr) == (ln_b == nullptr), FLEXAM_E_ARG,
+             "ln_modulate_fp8: shift / scale and ln_w / ln_b go together");
+  FX_REQUIRE(!shift || row_index || rows_per_batch > 0, FLEXAM_E_ARG, "ln_modulate_fp8: need row_index or rows_per_batch");
+  if (rows_per_batch <= 0) rows_per_batch = 1;
+  const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+#define LN_WAVE8(NV8_)                                                                                                                   \
+  case NV8_:                                                                                                                            \
+    hipLaunchKernelGGL((ln_modulate_wave_kernel<NV8_, true>), grid, block, 0, (hipStream_t)stream, x, ldx, M, eps, shift, scale, tab_ld, \
+                       row_index, rows_per_batch, ln_w, ln_b, (bf16*)q_out, ldq, row_scale);                                            \
+    break;
+  switch (C / 512) { LN_WAVE8(1) LN_WAVE8(2) LN_WAVE8(3) LN_WAVE8(4) LN_WAVE8(5) LN_WAVE8(6) LN_WAVE8(7) LN_WAVE8(8) }
+#undef LN_WAVE8
+  return flexam_check_launch("flexam_ln_modulate_fp8");
 }
 
 extern "C" int flexam_gate_residual(float* x, int64_t ldx, const void* y, int64_t ldy, const float* gate, int64_t gate_ld,

@@ -25,6 +25,59 @@ __device__ __forceinline__ float ld(const T* p) { return (float)*p; }
 //   mode 0: cast;  mode 1: F.normalize(x, channel) * sqrt(C) * gamma;  mode 2: mode 1 + SiLU.
 //   dst position: compact (t*H + h)*W + w  if dst_compact else padded ((t + t0)*Hp + h+1)*Wp + w+1
 // ------------------------------------------------------------------------------------------
+// Vector form (C % 4 == 0, C <= 1024 * ... any C): a lane owns 4 consecutive channels per 256-channel slab, loaded once with one
+// 16-byte (fp32) / 8-byte (bf16) access and kept in registers between the sum of squares and the write (8-byte bf16x4 stores);
+// the scalar form below remains for odd channel counts.  (r1's scalar form read every row twice with 2- / 4-byte accesses and
+// ran at ~2.5 TB/s: profiles/r2b_vae_notes.txt.)
+template <typename TI, int NSLAB>
+__global__ __launch_bounds__(256) void vae_prep_vec_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
+                                                           const float* __restrict__ gamma, int mode, bf16* __restrict__ dst, int Cp,
+                                                           int t0, int dst_compact) {
+  const int lane = threadIdx.x & 63;
+  const int Hp = H + 2, Wp = W + 2;
+  const int64_t npos = (int64_t)T * H * W;
+  for (int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pos < npos; pos += (int64_t)gridDim.x * 4) {
+    const int w = (int)(pos % W);
+    int64_t r = pos / W;
+    const int h = (int)(r % H);
+    const int t = (int)(r / H);
+    const TI* s = src + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * lds_;
+    bf16* d = dst + (dst_compact ? pos : (((int64_t)(t + t0) * Hp + h + 1) * Wp + w + 1)) * Cp;
+    f32x4 v[NSLAB];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NSLAB; ++i) {
+      const int c = i * 256 + lane * 4;
+      if (c < C) {
+        if constexpr (sizeof(TI) == 4) {
+          v[i] = *(const f32x4*)((const float*)s + c);
+        } else {
+          const bf16x4 b = *(const bf16x4*)((const bf16*)s + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = bf2f(b[j]);
+        }
+      } else {
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q += v[i][j] * v[i][j];
+    }
+    float scale = 1.f;
+    if (mode != 0) scale = sqrtf((float)C) / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < NSLAB; ++i) {
+      const int c = i * 256 + lane * 4;
+      if (c >= C) continue;
+      f32x4 y = v[i];
+      if (mode != 0) y = y * scale * *(const f32x4*)(gamma + c);
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(mode == 2 ? silu(y[j]) : y[j]);
+      *(bf16x4*)(d + c) = o;
+    }
+  }
+}
+
 template <typename TI>
 __global__ __launch_bounds__(256) void vae_prep_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
                                                        const float* __restrict__ gamma, int mode, bf16* __restrict__ dst, int Cp,
@@ -93,22 +146,29 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const TI* __restrict__ 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dupup_add_kernel(float* __restrict__ xm, int64_t ldm, int Co, int To, int Ho, int Wo,
                                                         const float* __restrict__ xin, int64_t ldi, int Ci, int ft, int drop) {
+  // 4 consecutive output channels per thread: one 16-byte read-modify-write of x_main, four gathered reads of x_in (neighbouring
+  // threads share its lines)
   const int H = Ho / 2, W = Wo / 2;
   const int Hp = H + 2, Wp = W + 2, Hop = Ho + 2, Wop = Wo + 2;
   const int repeats = Co * ft * 4 / Ci;
-  const int64_t total = (int64_t)To * Ho * Wo * Co;
+  const int cvec = Co >> 2;
+  const int64_t total = (int64_t)To * Ho * Wo * cvec;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Co);
-    int64_t r = i / Co;
+    const int co = (int)(i % cvec) * 4;
+    int64_t r = i / cvec;
     const int wo = (int)(r % Wo);
     r /= Wo;
     const int ho = (int)(r % Ho);
     const int to = (int)(r / Ho);
     const int tt = to + drop;
     const int t = tt / ft, st = tt - t * ft;
-    const int ci = ((co * ft + st) * 4 + (ho & 1) * 2 + (wo & 1)) / repeats;
-    const float v = xin[(((int64_t)t * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldi + ci];
-    xm[(((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + co] += v;
+    const float* xi = xin + (((int64_t)t * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldi;
+    const int sub = st * 4 + (ho & 1) * 2 + (wo & 1);
+    float* xo = xm + (((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + co;
+    f32x4 x = *(const f32x4*)xo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] += xi[((co + j) * ft * 4 + sub) / repeats];
+    *(f32x4*)xo = x;
   }
 }
 
@@ -270,10 +330,25 @@ extern "C" int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_s
   FX_REQUIRE(C > 0 && C <= Cp && C <= ld_src && T > 0 && H > 0 && W > 0, FLEXAM_E_SHAPE, "vae_prep_cl: bad shape");
   const int64_t npos = (int64_t)T * H * W;
   dim3 grid(grid_for(npos, 4)), block(256);
-  if (src_is_bf16)
-    hipLaunchKernelGGL(vae_prep_kernel<bf16>, grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact);
-  else
-    hipLaunchKernelGGL(vae_prep_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact);
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = C % 4 == 0 && C <= 1024 && ld_src % 4 == 0 && Cp % 4 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0 &&
+                   (!gamma || (uintptr_t)gamma % 16 == 0);
+#define PREP_VEC(TI_, NS_)                                                                                                         \
+  hipLaunchKernelGGL((vae_prep_vec_kernel<TI_, NS_>), grid, block, 0, st, (const TI_*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, \
+                     Cp, t0, dst_compact)
+  if (vec) {
+    const int ns = (C + 255) / 256;
+    if (src_is_bf16) {
+      if (ns == 1) PREP_VEC(bf16, 1); else if (ns == 2) PREP_VEC(bf16, 2); else if (ns == 3) PREP_VEC(bf16, 3); else PREP_VEC(bf16, 4);
+    } else {
+      if (ns == 1) PREP_VEC(float, 1); else if (ns == 2) PREP_VEC(float, 2); else if (ns == 3) PREP_VEC(float, 3); else PREP_VEC(float, 4);
+    }
+  } else if (src_is_bf16) {
+    hipLaunchKernelGGL(vae_prep_kernel<bf16>, grid, block, 0, st, (const bf16*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact);
+  } else {
+    hipLaunchKernelGGL(vae_prep_kernel<float>, grid, block, 0, st, (const float*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact);
+  }
+#undef PREP_VEC
   return flexam_check_launch("flexam_vae_prep_cl");
 }
 
@@ -293,7 +368,8 @@ extern "C" int flexam_dupup_add_cl(float* x_main, int64_t ld_main, int Co, int T
                                    int Ci, int ft, int drop, void* stream) {
   FX_REQUIRE(x_main && x_in, FLEXAM_E_ARG, "dupup_add_cl: null pointer");
   FX_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0 && (ft == 1 || ft == 2) && (Co * ft * 4) % Ci == 0, FLEXAM_E_SHAPE, "dupup_add_cl: bad shape");
-  hipLaunchKernelGGL(dupup_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * Co, 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
+  FX_REQUIRE(Co % 4 == 0 && ld_main % 4 == 0 && (uintptr_t)x_main % 16 == 0, FLEXAM_E_SHAPE, "dupup_add_cl: Co and ld_main must be multiples of 4");
+  hipLaunchKernelGGL(dupup_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
                      Co, To, Ho, Wo, x_in, ld_in, Ci, ft, drop);
   return flexam_check_launch("flexam_dupup_add_cl");
 }

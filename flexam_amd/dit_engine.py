@@ -393,7 +393,12 @@ class DiTEngine:
                 T = tab1[0]
             else:
                 T = tab[i]
-            hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
+            fp8_here = self.fp8 and sp == 1
+            if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
+                a8, sa = hip.ln_modulate_fp8(xres, ws["a8"][:, :d], ws["sa"], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index,
+                                             rows_per_batch=rpb)
+            else:
+                hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
             if sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
                 # returned blocks in place (flexam_amd/dist.py)
@@ -407,9 +412,8 @@ class DiTEngine:
                 self._allgather_attention(qkv, hbuf, p, ao4, q4, B, lc, tok0)
                 hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             else:
-                if self.fp8:
+                if fp8_here:
                     w8 = self._fp8_w[i]
-                    a8, sa = hip.quantize_rows_fp8(hbuf, ws["a8"][:, :d], ws["sa"])
                     hip.gemm_fp8(a8, sa, w8["wqkv"], w8["s_wqkv"], p["bqkv"], out=qkv)
                 else:
                     hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
@@ -426,14 +430,15 @@ class DiTEngine:
             hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
             hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
             # FFN
-            hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
             if self.fp8:
                 w8 = self._fp8_w[i]
-                a8, sa = hip.quantize_rows_fp8(hbuf, ws["a8"][:, :d], ws["sa"])
+                a8, sa = hip.ln_modulate_fp8(xres, ws["a8"][:, :d], ws["sa"], eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index,
+                                             rows_per_batch=rpb)
                 hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
                 a8, sa = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
                 hip.gemm_fp8_gate_residual(a8, sa, w8["w2"], w8["s_w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
             else:
+                hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
                 hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
                 hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
         if teacache is not None and calc:                  # residual = x_after_blocks - x_before (FX.py:1048-1051), kept on the GPU

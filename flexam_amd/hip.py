@@ -32,6 +32,7 @@ _SIGNATURES = {
     "flexam_attn_fwd_partial": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_merge": ([_P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
+    "flexam_ln_modulate_fp8": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P], c_int),
     "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
     "flexam_rmsnorm_rope": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
     "flexam_rmsnorm_rope_scatter": ([_P, _L, _P, _P, _L, _P, _P, _L, _P, _P, _P, _L, _L, _I, _L, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
@@ -342,6 +343,16 @@ def ln_modulate(x, out=None, eps=1e-6, shift=None, scale=None, row_index=None, r
                                     _ptr(row_index, I32), rows_per_batch, _ptr(ln_w, F32), _ptr(ln_b, F32), _ptr(out, BF16),
                                     out.stride(0), _stream()), "flexam_ln_modulate")
     return out
+
+
+def ln_modulate_fp8(x, q_out, row_scale, eps=1e-6, shift=None, scale=None, row_index=None, rows_per_batch=0, ln_w=None, ln_b=None):
+    """ln_modulate with the output written as e4m3 bytes q_out [M, C] (uint8, row stride free) + row_scale [M] fp32."""
+    M, C, ldx = _rows(x)
+    tab_ld = shift.stride(0) if shift is not None else 0
+    _check(lib().flexam_ln_modulate_fp8(_ptr(x, F32), ldx, M, C, eps, _ptr(shift, F32), _ptr(scale, F32), tab_ld, _ptr(row_index, I32),
+                                        rows_per_batch, _ptr(ln_w, F32), _ptr(ln_b, F32), _ptr(q_out, torch.uint8), q_out.stride(0),
+                                        _ptr(row_scale, F32), _stream()), "flexam_ln_modulate_fp8")
+    return q_out, row_scale
 
 
 def gate_residual(x, y, gate=None, row_index=None, rows_per_batch=0):

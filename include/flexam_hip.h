@@ -125,6 +125,12 @@ int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C, float eps,
                        int64_t tab_ld, const int32_t* row_index, int64_t rows_per_batch, const float* ln_w,
                        const float* ln_b, void* out, int64_t ldo, void* stream);
 
+/* The same row operation with the output quantised for flexam_gemm_fp8: q_out[m,:] = e4m3(y / row_scale[m]), row_scale[m] =
+ * absmax(y[m,:]) / 448 (C a multiple of 512, at most 4096): the fp8 variant's QKV / FFN1 inputs without a second pass. */
+int flexam_ln_modulate_fp8(const float* x, int64_t ldx, int64_t M, int C, float eps, const float* shift, const float* scale,
+                           int64_t tab_ld, const int32_t* row_index, int64_t rows_per_batch, const float* ln_w, const float* ln_b,
+                           void* q_out, int64_t ldq, float* row_scale, void* stream);
+
 /* x_f32[m,:] += y_bf16[m,:] * gate[row(m),:] (gate NULL = 1).  wan_transformer3d_FlexAM.py:456,461,468. */
 int flexam_gate_residual(float* x, int64_t ldx, const void* y, int64_t ldy, const float* gate, int64_t gate_ld,
                          const int32_t* row_index, int64_t rows_per_batch, int64_t M, int C, void* stream);

@@ -176,3 +176,26 @@ def test_fp8_one_layer_model_at_5b_width():
     p = C.psnr(got, want)
     print(f"fp8 one-layer 5B-width model: rel-rms {rel:.3e}, psnr {p:.1f} dB")
     assert rel <= 3e-2 and p >= 40.0
+
+
+def test_ln_modulate_fp8_equals_ln_modulate_then_quantise(H):
+    """The fused LN + modulate -> e4m3 launch against the two-pass form (bf16 LN output, then the row quantiser): the fused
+    form skips the intermediate rounding to bf16, so rows agree to half an e4m3 ulp of the row maximum and scales to 2^-8."""
+    g = torch.Generator().manual_seed(12)
+    m, c = 700, 3072
+    x = (torch.randn(m, c, generator=g) * 3 + 0.5).to(dev())
+    tab = torch.randn(4, 2, c, generator=g).to(dev())
+    rows = torch.randint(0, 4, (m,), generator=g, dtype=torch.int32).to(dev())
+    ref = H.ln_modulate(x, shift=tab[:, 0], scale=tab[:, 1], row_index=rows)
+    q2, s2 = H.quantize_rows_fp8(ref)
+    q1 = torch.empty(m, c, device=dev(), dtype=torch.uint8)
+    s1 = torch.empty(m, device=dev(), dtype=torch.float32)
+    H.ln_modulate_fp8(x, q1, s1, shift=tab[:, 0], scale=tab[:, 1], row_index=rows)
+    torch.testing.assert_close(s1.cpu(), s2.cpu(), rtol=2.0 ** -7, atol=0)
+    d1 = q1.cpu().view(F8).float() * s1.cpu()[:, None]
+    d2 = q2.cpu().view(F8).float() * s2.cpu()[:, None]
+    amax = ref.float().abs().amax(dim=1).cpu()
+    err = (d1 - ref.float().cpu()).abs()
+    bound = 2.0 ** -4 * ref.float().abs().cpu() + 2.0 ** -7 * amax[:, None]
+    assert not (err > bound).any()
+    assert float((d1 - d2).abs().max()) <= float(amax.max()) * 2.0 ** -3
