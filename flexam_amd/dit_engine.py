@@ -183,6 +183,15 @@ class DiTEngine:
         self.fp8 = bool(on)
         self._ws.clear()
 
+    def _ln_fp8(self, xres, ws, hbuf, **kw):
+        """LN + modulate as the fp8 GEMMs' A operand: one launch at widths the wave-per-row kernel covers (multiples of 512, the 5B
+        model's 3072), the bf16 row kernel followed by the row quantiser otherwise."""
+        d = self.dim
+        if d % 512 == 0 and d <= 4096:
+            return hip.ln_modulate_fp8(xres, ws["a8"][:, :d], ws["sa"], eps=self.eps, **kw)
+        hip.ln_modulate(xres, out=hbuf, eps=self.eps, **kw)
+        return hip.quantize_rows_fp8(hbuf, ws["a8"][:, :d], ws["sa"])
+
     def set_sequence_parallel(self, group, rank: int, size: int):
         self.set_parallel(group, rank, size)
 
@@ -395,8 +404,7 @@ class DiTEngine:
                 T = tab[i]
             fp8_here = self.fp8 and sp == 1
             if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
-                a8, sa = hip.ln_modulate_fp8(xres, ws["a8"][:, :d], ws["sa"], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index,
-                                             rows_per_batch=rpb)
+                a8, sa = self._ln_fp8(xres, ws, hbuf, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
             else:
                 hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
             if sp > 1 and self.sp_mode == "ulysses":
@@ -432,8 +440,7 @@ class DiTEngine:
             # FFN
             if self.fp8:
                 w8 = self._fp8_w[i]
-                a8, sa = hip.ln_modulate_fp8(xres, ws["a8"][:, :d], ws["sa"], eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index,
-                                             rows_per_batch=rpb)
+                a8, sa = self._ln_fp8(xres, ws, hbuf, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
                 hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
                 a8, sa = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
                 hip.gemm_fp8_gate_residual(a8, sa, w8["w2"], w8["s_w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
