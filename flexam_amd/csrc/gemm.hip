@@ -88,25 +88,33 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // epilogue (gemm_splitk_finish_kernel runs it).  The TAIL = false instance runs the whole tiles only.  Two instances instead of
 // one kernel with both paths: with the slab stores between the K loop and the epilogues hipcc spills 30-50 registers in the
 // gate-residual epilogue and leaves a reload pending into the next unit's K loop.
-template <int EPI, typename OutT, int MT, bool M32, bool TAIL = false>
+// WMW x (8 / WMW) waves, NTW 16-wide n-tiles per wave: 2 x 4 waves x 4 n-tiles = the (32 MT) x 256 tile of the DiT shapes; 4 x 2
+// waves x 5 n-tiles = a (64 MT) x 160 tile for output widths that are multiples of 160 but not of 256 (the VAE encoder's 160 / 320 /
+// 640 channels, which fill 62.5 % / 62.5 % / 83 % of 256-wide tiles).  The 160-wide shape stores through the generic epilogue (its
+// 80-column wave rows do not fit the 128-byte LDS turn-around) and has no 32 x 32 form.
+template <int EPI, typename OutT, int MT, bool M32, bool TAIL = false, int WMW = 2, int NTW = 4>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
   static_assert(!M32 || MT % 2 == 0, "32 x 32 tiles need an even number of 16-row m-tiles per wave");
+  static_assert((WMW == 2 && NTW == 4) || (WMW == 4 && NTW == 5 && !M32 && MT <= 4), "supported wave layouts: 2 x 4 x 4 n-tiles, 4 x 2 x 5 n-tiles");
+  constexpr bool STD = WMW == 2 && NTW == 4;   // the 256-wide shape with LDS-staged epilogues
+  constexpr int WNW = 8 / WMW;              // waves along N
+  constexpr int BN_ = WNW * NTW * 16;       // columns of this tile shape
   constexpr int RT = M32 ? 32 : 16;         // rows per row tile
   constexpr int NRT = 16 * MT / RT;         // row tiles per wave
   constexpr int NG = 64 / RT;               // column groups (lane / RT)
-  constexpr int NV = 16 / NG;               // 4-column units per lane
+  constexpr int NV = NTW * 4 / NG;          // 4-column units per lane
   constexpr int STG_WAVE = RT * 128;        // epilogue staging per wave: one row tile of bf16 outputs (RT rows x 64 columns)
-  constexpr int NTW = 4;                    // 16-wide n-tiles per wave
-  constexpr int BM_ = 32 * MT;              // rows of this tile shape
-  constexpr int PA = (BM_ + 63) / 64;       // 64-row staging pieces per thread for A (W always 4)
-  constexpr int NP = PA + 4;                // LDS-DMA pieces per thread per K block
+  constexpr int BM_ = WMW * 16 * MT;        // rows of this tile shape
+  constexpr int PA = (BM_ + 63) / 64;       // 64-row staging pieces per thread for A
+  constexpr int PW = (BN_ + 63) / 64;       // ... and for W
+  constexpr int NP = PA + PW;               // LDS-DMA pieces per thread per K block
   constexpr int NF = NTW + MT;              // fragments per 32-deep K half
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][STG_WAVE] of epilogue staging
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WNW, wn = wave % WNW;
 
   // ---- persistent workgroups over an XCD-aware, grouped tile order: workgroup w lives on XCD w & 7 (round-robin
   // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
@@ -135,12 +143,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     const int gsz = min(p.tiles_m - first_m, GM);
     const int in_group = bid - group * per_group;
     m0 = (first_m + in_group % gsz) * BM_;
-    n0 = (in_group / gsz) * BN;
+    n0 = (in_group / gsz) * BN_;
   };
   // ---- staging addresses: thread -> (row = i*64 + tid/8, LDS slot = tid%8), source chunk = slot ^ swz(row).
   // Byte offsets from the tile's first row fit 32 bits (256 rows x row stride), so a piece's source is
   // (uniform 64-bit tile base + K offset) + one VGPR: the scalar-base form of global_load_lds.
-  uint32_t a_off[PA], w_off[4];
+  uint32_t a_off[PA], w_off[PW];
   const char *a_tile, *w_tile;
   auto stage_setup = [&](int m0, int n0) {
 #pragma unroll
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       const int row = i * 64 + (tid >> 3);
       const int chunk = (tid & 7) ^ ((row >> 1) & 7);
       if (i < PA) a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);   // edge tiles re-read their last row
-      w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
+      if (i < PW) w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
     }
     a_tile = (const char*)(p.A + (int64_t)m0 * p.lda);
     w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
@@ -246,9 +254,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     }
   };
   // fragments 2g, 2g+1 of a set
+  // (PER fragments per MFMA group so that the MT groups of a phase cover all NF: 2 for every 256-wide shape, 3 for the 160-wide one)
+  constexpr int PER = (NF + MT - 1) / MT > 2 ? (NF + MT - 1) / MT : 2;
   auto ld2 = [&](const char* buf, int hf, int g, bf16x8 (&f)[NF]) {
 #pragma unroll
-    for (int j = 2 * g; j < 2 * g + 2; ++j)
+    for (int j = PER * g; j < PER * g + PER; ++j)
       if (j < NF) f[j] = frag(buf, hf, j);
   };
   // MFMA group g (of MT per K half, 64 matrix-pipe cycles each) on fragment set f
@@ -296,10 +306,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (i < PA) asm volatile("" : "+v"(a_off[i]));
-    asm volatile("" : "+v"(w_off[i]));
+    if (i < PW) asm volatile("" : "+v"(w_off[i]));
   }
 #pragma unroll
-  for (int g = 0; g < (NF + 1) / 2; ++g) ld2(smem, 0, g, f0);
+  for (int g = 0; g < (NF + PER - 1) / PER; ++g) ld2(smem, 0, g, f0);
 
   auto block = [&](int kb, auto dma_c, auto rd_c, auto wait_c) {
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // last slice reducing with sc1 loads; at the production FFN2 shape and at the VAE's K = 27648 convolutions some lanes of the
   // reducing workgroup read zeros instead of another slice's sums: profiles/r2_splitk_handoff_bug.txt.)
   if constexpr (TAIL) {
-    constexpr int SLAB = 256 * BN;                     // floats per slab; 16-byte element of (row tile t, unit v) at ((t*NV+v)*512 + tid)*4
+    constexpr int SLAB = 256 * BN;                     // floats per slab (every tile shape fits); 16-byte element of (row tile t, unit v) at ((t*NV+v)*512 + tid)*4
     int te = tid;                                      // opaque copy (see `le` below): slab addresses stay out of the K loop's registers
     asm volatile("" : "+v"(te));
     const int tr = tile - p.split_full;
@@ -396,13 +406,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   auto stg_write = [&](int v, bf16x4 o) {
     *(bf16x4*)(stg + wr_row * 128 + ((((NG / 2) * v + (wr_g >> 1)) ^ (wr_row & 7)) << 4) + (wr_g & 1) * 8) = o;
   };
-  if constexpr (EPI == EPI_GATE_RESIDUAL) {
+  if constexpr (EPI == EPI_GATE_RESIDUAL && STD) {
     // Interior tiles (all but the last tile row / column): in the MFMA layout a lane's 16 bytes of X sit in RT different rows
     // per instruction (64-byte pieces).  The wave parks y (rounded to bf16, as the reference's Linear output is) in its LDS
     // slice, one row tile at a time, and walks X row-wise instead: 4 rows x 256 contiguous bytes per load / store instruction,
     // the loads of 32 rows in flight together.  (LDS serves a wave's operations in order: no wait between the y writes and
     // the reads behind them.)
-    if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
+    if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
       const int rr = le >> 4, cc = le & 15;            // row inside a group of 4, 16-byte piece of the 256-byte row
       const int mw = m0 + wm * (16 * MT);
       const int nw = n0 + wn * (16 * NTW) + cc * 4;
@@ -476,11 +486,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       continue;                                        // next tile of this persistent workgroup
     }
   }
-  if constexpr (EPI != EPI_GATE_RESIDUAL && sizeof(OutT) == 2) {
+  if constexpr (EPI != EPI_GATE_RESIDUAL && sizeof(OutT) == 2 && STD) {
     // Interior tiles, bf16 output: the MFMA layout gives a lane 4 columns of RT different rows, i.e. 32-byte pieces per store
     // instruction.  The wave turns its 16*MT x 64 outputs around in its LDS slice instead, one row tile at a time, and stores
     // whole 128-byte rows, 8 per instruction.
-    if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
+    if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
       const int rd_row = le >> 3, rd_c = le & 7;
       bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
 #pragma unroll
@@ -556,10 +566,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 // Second half of the tail split-K: one workgroup per (tail tile, row tile t).  Thread `te` owns the same 16-byte elements the
 // main kernel's thread `te` parked -- (row tile t, unit v) at ((t*NV+v)*512 + te)*4 of every slice's slab -- sums the slices in
 // slice order and applies the epilogue (bias, GELU-tanh, fp32 gated residual, bf16 / fp32 store) in the accumulator layout.
-template <int EPI, typename OutT, int MT, bool M32>
+template <int EPI, typename OutT, int MT, bool M32, int WMW = 2, int NTW = 4>
 __global__ __launch_bounds__(512) void gemm_splitk_finish_kernel(GemmParams p) {
-  constexpr int RT = M32 ? 32 : 16, NRT = 16 * MT / RT, NG = 64 / RT, NV = 16 / NG, NTW = 4, BM_ = 32 * MT, SLAB = 256 * BN;
-  const int te = threadIdx.x, lane = te & 63, wave = te >> 6, wm = wave >> 2, wn = wave & 3;
+  constexpr int WNW = 8 / WMW, BN_ = WNW * NTW * 16;
+  constexpr int RT = M32 ? 32 : 16, NRT = 16 * MT / RT, NG = 64 / RT, NV = NTW * 4 / NG, BM_ = WMW * 16 * MT, SLAB = 256 * BN;
+  const int te = threadIdx.x, lane = te & 63, wave = te >> 6, wm = wave / WNW, wn = wave % WNW;
   const int tr = blockIdx.x / NRT, t = blockIdx.x % NRT;
   const int tile = p.split_full + tr;
   int m0, n0;
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(512) void gemm_splitk_finish_kernel(GemmParams p) {
     const int GM = p.gm, per_group = GM * p.tiles_n, group = tile / per_group, first_m = group * GM;
     const int gsz = min(p.tiles_m - first_m, GM), in_group = tile - group * per_group;
     m0 = (first_m + in_group % gsz) * BM_;
-    n0 = (in_group / gsz) * BN;
+    n0 = (in_group / gsz) * BN_;
   }
   const int m = m0 + wm * (16 * MT) + t * RT + (lane & (RT - 1));
   if (m >= p.M) return;
@@ -636,9 +647,9 @@ void plan_split(const GemmWorkspace& g_ws, int tiles, int nk, int& S, int& rem, 
   if (cost) *cost = best;
 }
 
-template <int EPI, typename OutT, int MT, bool M32>
+template <int EPI, typename OutT, int MT, bool M32, int WMW = 2, int NTW = 4>
 int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
-  auto kern = gemm_bf16_kernel<EPI, OutT, MT, M32>;
+  auto kern = gemm_bf16_kernel<EPI, OutT, MT, M32, false, WMW, NTW>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};          // per device: the attribute belongs to the device's copy of the code object
   const int smem = 4 * TILE_BYTES + 8 * (M32 ? 32 : 16) * 128;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave
   const int dev = flexam_current_device();
@@ -647,7 +658,8 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
       return flexam_fail(FLEXAM_E_LAUNCH, "gemm: cannot raise dynamic LDS to %d bytes", smem);
     attr_set[dev] = true;
   }
-  p.tiles_m = (p.M + 32 * MT - 1) / (32 * MT);
+  p.tiles_m = (p.M + WMW * 16 * MT - 1) / (WMW * 16 * MT);
+  p.tiles_n = (p.N + (8 / WMW) * NTW * 16 - 1) / ((8 / WMW) * NTW * 16);
   const int tiles = p.tiles_m * p.tiles_n;
   int split_s, rem;
   plan_split(g_ws, tiles, p.K / BK, split_s, rem);
@@ -664,7 +676,7 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
   if (p.split_full > 0) hipLaunchKernelGGL(kern, dim3(grid_for_units(p.split_full)), dim3(512), smem, s, p, a_koff);
   if (split_s > 1) {
     // the K slices of the tail tiles, then (stream-ordered) their sum in slice order + the epilogue
-    auto tail = gemm_bf16_kernel<EPI_NONE, float, MT, M32, true>;
+    auto tail = gemm_bf16_kernel<EPI_NONE, float, MT, M32, true, WMW, NTW>;
     static bool tail_attr[FLEXAM_MAX_DEVICES] = {};
     if (!tail_attr[dev]) {
       if (hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -672,7 +684,7 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
       tail_attr[dev] = true;
     }
     hipLaunchKernelGGL(tail, dim3(grid_for_units(rem * split_s)), dim3(512), smem, s, p, a_koff);
-    hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI, OutT, MT, M32>), dim3(rem * (M32 ? MT / 2 : MT)), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI, OutT, MT, M32, WMW, NTW>), dim3(rem * (M32 ? MT / 2 : MT)), dim3(512), 0, s, p);
   }
   return flexam_check_launch("flexam_gemm_bf16");
 }
@@ -731,6 +743,15 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
   p.debug = dbg ? atoi(dbg) : 0;
 #endif
+  // output widths that are multiples of 160 but not of 256 (VAE encoder: 160, 320 channels): the 256 x 160 shape wastes nothing,
+  // a 256-wide tile 37.5 %; FLEXAM_GEMM_N160=0 keeps the 256-wide shape (A/B), =2 also takes N = 640 (83 % of 256-wide tiles)
+  {
+    const char* e = getenv("FLEXAM_GEMM_N160");
+    const int mode = e ? atoi(e) : 1;
+    const bool narrow = p.N <= 160;                      // one 160-wide tile column instead of a 256-wide one (VAE head convs: 12 / 96 channels)
+    const bool mult160 = p.N % 160 == 0 && p.N % 256 != 0 && (p.N <= 480 || mode == 2);
+    if (mode && (narrow || mult160)) return launch_shape<EPI, OutT, 4, false, 4, 5>(p, g_ws, a_koff, s);
+  }
   switch (pick_mt(g_ws, p.M, p.tiles_n, p.K / BK)) {
     case 7: return launch_mt<EPI, OutT, 7>(p, g_ws, a_koff, s);
     case 6: return launch_mt<EPI, OutT, 6>(p, g_ws, a_koff, s);

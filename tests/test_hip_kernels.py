@@ -128,6 +128,33 @@ def test_gemm_many_units_per_workgroup_exact(H, m, n, k):
         torch.testing.assert_close(x.cpu(), x0 + want.to(BF).float() * gate[rows.long()], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("m,n,k", [(1000, 160, 192), (4097, 320, 5184), (777, 480, 256), (2048, 640, 1728), (300, 160, 27648)])
+def test_gemm_160_wide_tile_shape_exact(H, m, n, k, monkeypatch):
+    """Output widths that are multiples of 160 but not of 256 (the VAE encoder's 160 / 320 / 640 channels) run on a 256 x 160 tile
+    (4 x 2 waves, 5 n-tiles per wave) instead of 62.5 %-filled 256-wide ones: integer data -> exact for the bf16, fp32 and
+    gated-residual outputs, with and without the tail split-K (K = 27648), identical to the 256-wide shape's results."""
+    monkeypatch.setenv("FLEXAM_GEMM_N160", "2")                 # also N = 640 (default: N <= 480 only)
+    g = torch.Generator().manual_seed(m + n + k)
+    lim = 2 if k < 20000 else 1
+    a = torch.randint(-lim, lim + 1, (m, k), generator=g).float()
+    w = torch.randint(-lim, lim + 1, (n, k), generator=g).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    want = a @ w.t() + b
+    ad, wd, bd = bf(a).to(dev()), bf(w).to(dev()), b.to(dev())
+    torch.testing.assert_close(H.gemm(ad, wd, bd, out_dtype=torch.float32).cpu(), want, rtol=0, atol=0)
+    torch.testing.assert_close(H.gemm(ad, wd, bd).float().cpu(), want.to(BF).float(), rtol=0, atol=0)
+    gate = torch.randint(-2, 3, (3, n), generator=g).float()
+    rows = torch.randint(0, 3, (m,), generator=g, dtype=torch.int32)
+    x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+    x = x0.clone().to(dev())
+    H.gemm_gate_residual(ad, wd, bd, x, gate.to(dev()), rows.to(dev()))
+    torch.testing.assert_close(x.cpu(), x0 + want.to(BF).float() * gate[rows.long()], rtol=0, atol=0)
+    ref16 = torch.nn.functional.gelu(want, approximate="tanh")
+    assert_bf16_close(H.gemm(ad, wd, bd, epilogue=H.EPI_GELU_TANH), ref16, ulps=2.0, atol=1e-2, msg="gelu, 160-wide shape")
+    monkeypatch.setenv("FLEXAM_GEMM_N160", "0")
+    torch.testing.assert_close(H.gemm(ad, wd, bd, out_dtype=torch.float32).cpu(), want, rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
 def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
     """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on
