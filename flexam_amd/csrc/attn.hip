@@ -81,10 +81,22 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
                : "memory");
 }
 
+// max of MFMA outputs as single instructions: fmaxf() makes hipcc put a canonicalising v_max_f32 x, x in front of every operand it
+// cannot prove quiet (each MFMA result), 4-5 extra vector instructions per half tile in a loop that is bound by vector issue
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float pair_max(float x) {
   float a = x, b = x;
   half_swap(a, b);
-  return fmaxf(a, b);
+  return vmax(a, b);
 }
 __device__ __forceinline__ float pair_sum(float x) {
   float a = x, b = x;
@@ -310,9 +322,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     mask_half(g, s_cur);             // keys past Lk -> -inf (uniform branch, only taken in the last tile)
     // ---- A: first half of S(g+1) on the matrix pipe | row maximum of S(g) on the VALU
     qk_part(IC<((g8 + 1) & 7)>{}, IC<0>{}, s_nxt);
-    float m = s_cur[0];
+    float m = vmax3(s_cur[0], s_cur[1], s_cur[2]);
 #pragma unroll
-    for (int e = 1; e < 16; ++e) m = fmaxf(m, s_cur[e]);
+    for (int e = 3; e < 15; e += 2) m = vmax3(m, s_cur[e], s_cur[e + 1]);
+    m = vmax(m, s_cur[15]);
     const float mx = pair_max(m);
     float psum = 0.f;
     bf16x8 pn[2];
