@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float pv = __builtin_amdgcn_exp2f(s_cur[e]);
-        psum += pv;
+        psum = e == 0 ? pv : psum + pv;                       // (0 + x is an instruction: x may be -0 as far as the compiler knows)
         pn[e >> 3][e & 7] = f2bf(pv);
       }
     } else {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], c, -mc));
-        psum += pv;
+        psum = e == 0 ? pv : psum + pv;
         pn[e >> 3][e & 7] = f2bf(pv);
       }
     }
