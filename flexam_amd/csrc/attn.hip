@@ -93,6 +93,13 @@ __device__ __forceinline__ float vmax(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// scalar-base form of the same DMA: uniform 64-bit base in SGPRs + one loop-invariant 32-bit per-lane offset, so a full tile's four
+// pieces cost no vector address arithmetic; M0 is written and not restored (nothing else in this kernel reads it: LDS instructions
+// on gfx9+ do not)
+__device__ __forceinline__ void lds_dma16_sbase(const char* sbase, unsigned voff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ float pair_max(float x) {
   float a = x, b = x;
   half_swap(a, b);
@@ -200,10 +207,12 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * KV_TILE_BYTES + wave * 1024);   // wave-uniform; K ring, V ring = + V_RING
     const int tg = t0 + t;
     if ((tg + 1) * KVBLK <= p.Lk) {
+      const char* kt = kbase + (size_t)((unsigned)tg * k_step);     // wave-uniform tile bases
+      const char* vt = vbase + (size_t)((unsigned)tg * v_step);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        lds_dma16(kbase + (k_go[i] + (unsigned)tg * k_step), slot + i * 8192);
-        lds_dma16(vbase + (v_go[i] + (unsigned)tg * v_step), slot + V_RING + i * 8192);
+        lds_dma16_sbase(kt, k_go[i], slot + i * 8192);
+        lds_dma16_sbase(vt, v_go[i], slot + V_RING + i * 8192);
       }
     } else {                                 // last, partial tile: rows past Lk re-read the last key (masked later)
 #pragma unroll
