@@ -88,6 +88,22 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// max of 8 values in ONE statement: between separate asm statements that feed each other hipcc pads an s_nop per dependency
+__device__ __forceinline__ float vmax8(float a, float b, float c, float d, float e, float f, float g, float h) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+      : "=&v"(r)
+      : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h));
+  return r;
+}
+// max(a, b) combined across the two lanes (l, l ^ 32) that hold one query row, one statement (wait states inside)
+__device__ __forceinline__ float pair_max2(float a, float b) {
+  float r, t;
+  asm("v_max_f32 %0, %2, %3\n\tv_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0\n\tv_max_f32 %0, %0, %1"
+      : "=&v"(r), "=&v"(t)
+      : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float vmax(float a, float b) {
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -245,15 +261,19 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   float ref = 0.f;
   // ds0 == 0 starts a new accumulation: from a literal-zero C operand (no register zeroing), or from -ref (PRE)
   // `ghalf` (half-tile index modulo 8) must be a compile-time constant at every call site
-  auto qk_part = [&](auto ghalf_c, auto ds0_c, f32x16& sacc) {      // 4 K fragments ds0 .. ds0+3 of half `ghalf`
+  // K fragments ds0 .. ds0+3 of half `ghalf` (a compile-time constant at every call site) -> registers
+  auto qk_read = [&](auto ghalf_c, auto ds0_c, bf16x8 (&kf)[4]) {
     constexpr int ghalf = decltype(ghalf_c)::value, ds0 = decltype(ds0_c)::value;
     constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
     constexpr int imm = slot * KV_TILE_BYTES + (ghalf & 1) * 8192;
-    bf16x8 kf[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(kaddr[ds0 + i] + imm);   // fragments first ...
+    for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(kaddr[ds0 + i] + imm);
+  };
+  // ... and their 4 MFMAs of the S^T chain
+  auto qk_mma = [&](auto ds0_c, const bf16x8 (&kf)[4], f32x16& sacc) {
+    constexpr int ds0 = decltype(ds0_c)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                                                             // ... then the MFMAs
+    for (int i = 0; i < 4; ++i) {
       const int ds = ds0 + i;
       if (ds == 0) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -264,6 +284,12 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       }
     }
   };
+  auto qk_part = [&](auto ghalf_c, auto ds0_c, f32x16& sacc) {      // fragments first, then the MFMAs
+    bf16x8 kf[4];
+    qk_read(ghalf_c, ds0_c, kf);
+    qk_mma(ds0_c, kf, sacc);
+  };
+  bf16x8 kf_pre[4];      // the first four K fragments of the NEXT half tile, read one step ahead (block A starts on the matrix pipe)
   auto mask_half = [&](int g, f32x16& sacc) {      // g: local half index; keys are global
     const int gg = 2 * t0 + g;
     if ((gg + 1) * 32 > p.Lk || g >= 2 * ntiles) {   // past the end of the keys, or of this split's range
@@ -317,6 +343,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   f32x16 s_a, s_b;         // scores of the current / next half, ping-ponged statically (no register copies)
   qk_part(IC<0>{}, IC<0>{}, s_a);
   qk_part(IC<0>{}, IC<4>{}, s_a);
+  qk_read(IC<1>{}, IC<0>{}, kf_pre);
 #pragma unroll
   for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -329,13 +356,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   auto step = [&](int g, auto g8_c, f32x16& s_cur, f32x16& s_nxt) {     // g8 = g mod 8 as a compile-time constant
     constexpr int g8 = decltype(g8_c)::value;
     mask_half(g, s_cur);             // keys past Lk -> -inf (uniform branch, only taken in the last tile)
-    // ---- A: first half of S(g+1) on the matrix pipe | row maximum of S(g) on the VALU
-    qk_part(IC<((g8 + 1) & 7)>{}, IC<0>{}, s_nxt);
-    float m = vmax3(s_cur[0], s_cur[1], s_cur[2]);
-#pragma unroll
-    for (int e = 3; e < 15; e += 2) m = vmax3(m, s_cur[e], s_cur[e + 1]);
-    m = vmax(m, s_cur[15]);
-    const float mx = pair_max(m);
+    // ---- A: first half of S(g+1) on the matrix pipe (fragments read during the previous step) | row maximum of S(g) on the VALU
+    qk_mma(IC<0>{}, kf_pre, s_nxt);
+    const float m0 = vmax8(s_cur[0], s_cur[1], s_cur[2], s_cur[3], s_cur[4], s_cur[5], s_cur[6], s_cur[7]);
+    const float m1 = vmax8(s_cur[8], s_cur[9], s_cur[10], s_cur[11], s_cur[12], s_cur[13], s_cur[14], s_cur[15]);
+    const float mx = pair_max2(m0, m1);
     float psum = 0.f;
     bf16x8 pn[2];
     if constexpr (PRE) {
@@ -364,6 +389,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
       qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
       pv_half(IC<((g8 + 7) & 7)>{});
+      qk_read(IC<((g8 + 2) & 7)>{}, IC<0>{}, kf_pre);          // for the next step's block A
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const float pv = __builtin_amdgcn_exp2f(s_cur[e]);
@@ -389,6 +415,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
       qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
       pv_half(IC<((g8 + 7) & 7)>{});
+      qk_read(IC<((g8 + 2) & 7)>{}, IC<0>{}, kf_pre);          // for the next step's block A
       const float mc = m_run * c;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
