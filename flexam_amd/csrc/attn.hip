@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     v_go[i] = (unsigned)(row * p.v_rs * 2 + ch * 16);
   }
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-  auto issue_tile = [&](int t) {
+  auto issue_tile = [&](int t, int parts = 3) {      // parts: 1 = K, 2 = V
     const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * KV_TILE_BYTES + wave * 1024);   // wave-uniform; K ring, V ring = + V_RING
     const int tg = t0 + t;
     if ((tg + 1) * KVBLK <= p.Lk) {
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       const char* vt = vbase + (size_t)((unsigned)tg * v_step);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        lds_dma16_sbase(kt, k_go[i], slot + i * 8192);
-        lds_dma16_sbase(vt, v_go[i], slot + V_RING + i * 8192);
+        if (parts & 1) lds_dma16_sbase(kt, k_go[i], slot + i * 8192);
+        if (parts & 2) lds_dma16_sbase(vt, v_go[i], slot + V_RING + i * 8192);
       }
     } else {                                 // last, partial tile: rows past Lk re-read the last key (masked later)
 #pragma unroll
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
         const int row = (tid + NT * i) >> 4;
         const int col = ((tid & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 16;
         const int key = min(tg * KVBLK + row, p.Lk - 1);
-        lds_dma16(kbase + ((int64_t)key * p.k_rs * 2 + col), slot + i * 8192);
-        lds_dma16(vbase + ((int64_t)key * p.v_rs * 2 + col), slot + V_RING + i * 8192);
+        if (parts & 1) lds_dma16(kbase + ((int64_t)key * p.k_rs * 2 + col), slot + i * 8192);
+        if (parts & 2) lds_dma16(vbase + ((int64_t)key * p.v_rs * 2 + col), slot + V_RING + i * 8192);
       }
     }
   };
@@ -449,8 +449,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (t + 2 < ntiles) issue_tile(t + 2);
+    // K pieces of tile t+2 now, its V pieces between the two half-tile steps: two short bursts of LDS-DMA issue per tile instead
+    // of one of four per wave right after the barrier (-1.2...-1.6 % time; placements inside the steps' MFMA blocks were slower)
+    if (t + 2 < ntiles) issue_tile(t + 2, 1);
     step(2 * t, IC<2 * t4>{}, s_a, s_b);
+    if (t + 2 < ntiles) issue_tile(t + 2, 2);
     step(2 * t + 1, IC<2 * t4 + 1>{}, s_b, s_a);
   };
   int t = 0;
