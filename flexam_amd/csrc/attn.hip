@@ -69,6 +69,9 @@ __device__ __forceinline__ int kv_off(int row, int ch) {
 __device__ __forceinline__ void half_swap(float& a, float& b) {
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+__device__ __forceinline__ void half_swap_u32(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 // 16-byte-per-lane LDS-DMA issued from inline asm: hipcc then does not know an LDS write is in flight and does
 // not put s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 intrinsic (it does for the builtin form,
 // which would drain the DMA in the middle of a tile).  Completion is tracked by hand: vmcnt(0) + s_barrier
@@ -496,19 +499,27 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     }
     return;
   }
+  // A lane holds 4 of the 8 columns of each 8-column group of its row, its partner (lane ^ 32) the other 4.  One half exchange
+  // per dword between the groups of a pair (lower lanes give their part of the odd group, upper lanes their part of the even
+  // one) leaves 16 contiguous bytes in every lane: 8 stores of 16 B instead of 16 of 8 B (the tail is store-issue bound).
   const float inv_l = 1.0f / l_tot;
-  if (qi < p.Lq) {
-    bf16* orow = p.o + (int64_t)b * p.o_bs + (int64_t)qi * p.o_rs + head * HD;
+  bf16* orow = p.o + (int64_t)b * p.o_bs + (int64_t)min(qi, p.Lq - 1) * p.o_rs + head * HD + 8 * h;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+  for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x4 ov;
+    for (int i = 0; i < 4; i += 2) {
+      bf16x4 even, odd;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = f2bf(o_acc[dt][4 * i + e] * inv_l);
-        *(bf16x4*)(orow + 32 * dt + 8 * i + 4 * h) = ov;
+      for (int e = 0; e < 4; ++e) {
+        even[e] = f2bf(o_acc[dt][4 * i + e] * inv_l);
+        odd[e] = f2bf(o_acc[dt][4 * i + 4 + e] * inv_l);
       }
-  }
+      const u32x2 ev = __builtin_bit_cast(u32x2, even), od = __builtin_bit_cast(u32x2, odd);
+      unsigned a0 = ev[0], a1 = ev[1], c0 = od[0], c1 = od[1];
+      half_swap_u32(a0, c0);
+      half_swap_u32(a1, c1);
+      if (qi < p.Lq) *(u32x4*)(orow + 32 * dt + 8 * i) = (u32x4){a0, a1, c0, c1};
+    }
 }
 
 // out[b][q][head][:] = sum_s w_s O_s / sum_s w_s l_s with w_s = exp2((m_s - max_s m_s) * scale_log2e) for the rows of the
@@ -548,10 +559,10 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   FX_REQUIRE(q && k && v && (o || partial_slot0 >= 0), FLEXAM_E_ARG, "attn_fwd: null pointer");
   FX_REQUIRE(head_dim == HD, FLEXAM_E_SHAPE, "attn_fwd: head_dim %d unsupported (128 only)", head_dim);
   FX_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, FLEXAM_E_SHAPE, "attn_fwd: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
-  FX_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 4 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 &&
-                 o_bs % 4 == 0,
+  FX_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 &&
+                 o_bs % 8 == 0,
              FLEXAM_E_SHAPE, "attn_fwd: strides must keep 16-byte alignment of head rows");
-  FX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)o % 8 == 0, FLEXAM_E_ARG, "attn_fwd: misaligned pointer");
+  FX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, FLEXAM_E_ARG, "attn_fwd: misaligned pointer");
   const int tiles_all = (Lk + KVBLK - 1) / KVBLK;
   FX_REQUIRE(kv_splits >= 1 && kv_splits <= tiles_all, FLEXAM_E_ARG, "attn_fwd: %d key splits for %d key tiles", kv_splits, tiles_all);
   FX_REQUIRE((kv_splits == 1 && partial_slot0 < 0) || (ws_o && ws_ml), FLEXAM_E_ARG, "attn_fwd: split-KV needs both workspaces");
