@@ -1,0 +1,31 @@
+"""Dev tool: per-call fixed cost of the attention launch(es): time at Lk and 2 Lk keys -> slope (main loop) and intercept (prologues,
+epilogues, launch turnaround, split-KV + merge of the last partial round), with and without the persistent item walk."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from flexam_amd import hip as H
+dev = torch.device("cuda:0"); BF = torch.bfloat16
+g = torch.Generator().manual_seed(0)
+for Lq in (11648, 12288):
+    q = (torch.randn(2, Lq, 24, 128, generator=g) * 0.5).to(BF).to(dev)
+    out = torch.empty_like(q)
+    for mode in ("persist", "one-item"):
+        if mode == "one-item":
+            os.environ["FLEXAM_ATTN_NO_PERSIST"] = "1"
+        else:
+            os.environ.pop("FLEXAM_ATTN_NO_PERSIST", None)
+        res = {}
+        for Lk in (5824, 11648, 23296):
+            k = (torch.randn(2, Lk, 24, 128, generator=g) * 0.5).to(BF).to(dev)
+            v = (torch.randn(2, Lk, 24, 128, generator=g) * 0.5).to(BF).to(dev)
+            ts = []
+            for r in range(5):
+                H.attn_fwd(q, k, v, out=out, prescaled=True); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    H.attn_fwd(q, k, v, out=out, prescaled=True)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / 5)
+            res[Lk] = sorted(ts)[2]
+        print(f"Lq {Lq} {mode:9s}: " + "  ".join(f"Lk {Lk}: {t * 1e3:.3f} ms ({4.0 * 2 * 24 * Lq * Lk * 128 / t / 1e12:.0f} TF/s)" for Lk, t in res.items())
+              + f"  | intercept {(2 * res[11648] - res[23296]) * 1e3:.3f} ms, asymptote {4.0 * 2 * 24 * Lq * 11648 * 128 / (res[23296] - res[11648]) / 1e12:.0f} TF/s")
