@@ -432,7 +432,9 @@ int pick_mt8(int M, int tiles_n) {
   int best = 8;
   double best_cost = 1e30;
   const int G = flexam_num_cus();
-  for (int mt = 8; mt >= 4; --mt) {
+  // 224-row tiles at most by default: the 256-row instance keeps 64 A + 32 W fragment registers next to 128 accumulators and spills
+  // (1.5-1.7 PF against 2.1-2.2 for MT = 7 at the FFN2 shapes, tools/fp8_ffn2_sweep.py)
+  for (int mt = 7; mt >= 4; --mt) {
     const int tiles = (int)((long)((M + 32 * mt - 1) / (32 * mt)) * tiles_n);
     const double cost = ((tiles + G - 1) / G) * (mt + 1.25);
     if (cost < best_cost * 0.97) { best_cost = cost; best = mt; }
@@ -461,7 +463,10 @@ int launch_shape8(Gemm8Params p, hipStream_t s) {
 
 template <int EPI>
 int launch8(Gemm8Params p, hipStream_t s) {
-  p.gm = 4;
+  {
+    const char* g = getenv("FLEXAM_GEMM_GM");
+    p.gm = g && atoi(g) >= 1 ? atoi(g) : 4;
+  }
   switch (pick_mt8(p.M, p.tiles_n)) {
     case 7: return launch_shape8<EPI, 7>(p, s);
     case 6: return launch_shape8<EPI, 6>(p, s);
