@@ -539,6 +539,14 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         if self._engine is not None:
             self._engine._angles = None
 
+    @staticmethod
+    def default_cfg_parallel(world: int, num_heads: int, sp_mode: str = "allgather") -> bool:
+        """Default layout of `world` ranks: split the CFG pair first (2 x world/2) unless the all-to-all exchange is selected and
+        the heads divide over all ranks (then world >= 4 runs world-way token chunks with the pair batched).  `sp_mode` is
+        FLEXAM_SP_MODE, whose default ("allgather") is DiTEngine's."""
+        a2a = sp_mode == "ulysses" and num_heads % world == 0
+        return world % 2 == 0 and (world == 2 or not a2a)
+
     def enable_multi_gpus_inference(self, group=None, cfg_parallel=None):
         """Multi-GPU inference over `group` (default: the world group).  Stands in for the reference's missing
         FlexAM/dist + xfuser USP (wan_transformer3d_FlexAM.py:801-815).  Layout (flexam_amd/dist.py):
@@ -554,8 +562,7 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         world = dist.get_world_size(group)
         rank = dist.get_rank(group)
         if cfg_parallel is None:
-            a2a = os.environ.get("FLEXAM_SP_MODE", "ulysses") == "ulysses" and self.num_heads % world == 0
-            cfg_parallel = world % 2 == 0 and (world == 2 or not a2a)
+            cfg_parallel = self.default_cfg_parallel(world, self.num_heads, os.environ.get("FLEXAM_SP_MODE", "allgather"))
         if cfg_parallel and world % 2:
             raise ValueError("cfg_parallel needs an even number of ranks")
         if cfg_parallel:

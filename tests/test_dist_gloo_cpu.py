@@ -245,3 +245,16 @@ def _local_first_merge(rank, world):
 def test_local_chunk_first_partial_softmax_merge():
     errs = run_world(_local_first_merge, 2)
     assert max(errs) < 1e-5, errs
+
+
+def test_default_layout_follows_the_exchange_mode():
+    """with the K|V all-gather (the default exchange) every even world size splits the CFG pair first, so N = 4 / 8
+    run 2 x 2 / 2 x 4; only the all-to-all exchange with heads that divide over the ranks runs N-way token chunks with the pair
+    batched; two ranks always take the CFG split (no per-block traffic), odd worlds cannot."""
+    from flexam_amd import Wan2_2Transformer3DModel_FlexAM as M
+    assert all(M.default_cfg_parallel(w, 24) for w in (2, 4, 8))                       # default mode = allgather
+    assert all(M.default_cfg_parallel(w, 24, "allgather") for w in (2, 4, 8))
+    assert M.default_cfg_parallel(2, 24, "ulysses")
+    assert not M.default_cfg_parallel(4, 24, "ulysses") and not M.default_cfg_parallel(8, 24, "ulysses")
+    assert M.default_cfg_parallel(4, 2, "ulysses")                                      # 2 heads do not divide over 4 ranks
+    assert not M.default_cfg_parallel(3, 24) and not M.default_cfg_parallel(1, 24)
