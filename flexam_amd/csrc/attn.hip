@@ -8,15 +8,14 @@
 // MFMA lane maps in section 3 of that guide):
 //  * one workgroup = 8 waves = 256 query rows of one (batch, head); each wave owns 32 rows and
 //    keeps its Q fragment (32 VGPRs) and the O^T accumulator (64 VGPRs) in registers;
-//  * K/V tiles of 64 keys are staged global -> registers -> LDS (issue early, write late) into
-//    a double buffer; the LDS image is the dual-use XOR-swizzled image "(b)" of the guide: the
-//    K tile is read row-wise with ds_read_b128, the V tile column-wise with
-//    ds_read_b64_tr_b16, both conflict-free (tools/lds_sim.py);
+//  * K/V tiles of 64 keys go global -> LDS by LDS-DMA into two 4-slot rings (details at the kernel); the LDS
+//    image is the dual-use XOR-swizzled image "(b)" of the guide: the K tile is read row-wise with
+//    ds_read_b128, the V tile column-wise with ds_read_b64_tr_b16, both conflict-free (tools/lds_sim.py);
 //  * QK^T is computed swapped, S^T = K.Q^T (v_mfma_f32_32x32x16_bf16, K fragment in the A slot)
 //    so a lane holds 32 scores of ONE query row: the row max / sum are in-register plus one
 //    v_permlane32_swap, and the bf16-packed P registers are directly the B operand of
 //    O^T += V^T.P^T (accumulator-as-operand with the permuted-k order of the guide);
-//  * softmax scale and log2(e) are folded into one FMA in front of v_exp_f32.
+//  * softmax scale and log2(e) are folded into one FMA in front of v_exp_f32, or (PRE) into q by its producer.
 #include <stdlib.h>
 
 #include <type_traits>

@@ -423,6 +423,27 @@ def test_attention_prescaled_full_size_properties_and_rows(H):
     assert_bf16_close(o[:, rows][:, :, heads], ref, ulps=2.0, atol=4e-3, msg="pre-scaled attention, full size rows")
 
 
+def test_attention_prescaled_rows_at_the_704x1280_shape(H):
+    """BASELINE configs[4]'s shape (97x704x1280 -> L = 22880 tokens, 358 key tiles, 90 q blocks per head: 4320 work units = 16 full rounds
+    + 224 units whose keys are cut): constant V comes back and spot-checked rows of three heads match the oracle; the (batch, head) K/V
+    panel spans 22880 x 3072 x 2 B x ... < 2 GiB, inside the kernel's 32-bit tile offsets."""
+    g = torch.Generator().manual_seed(9)
+    l, h = 22880, 24
+    c = 128 ** -0.5 * 1.4426950408889634
+    qs = bf(torch.randn(2, l, h, 128, generator=g) * c).to(dev())
+    k = bf(torch.randn(2, l, h, 128, generator=g)).to(dev())
+    ones = torch.ones(2, l, h, 128, dtype=BF, device=dev())
+    out = H.attn_fwd(qs, k, ones, prescaled=True)
+    torch.testing.assert_close(out.float(), torch.ones_like(out).float(), rtol=0, atol=2.0 ** -7)
+    del ones, out
+    v = bf(torch.randn(2, l, h, 128, generator=g)).to(dev())
+    o = H.attn_fwd(qs, k, v, prescaled=True).float()
+    rows = torch.cat([torch.arange(0, l, l // 40)[:40], torch.tensor([l - 1, l - 33, l - 97])])     # incl. the last, partial q block
+    heads = [0, 13, 23]
+    ref = _attn_ref(qs[:, rows][:, :, heads].float().cpu() / c, k[:, :, heads].cpu(), v[:, :, heads].cpu())
+    assert_bf16_close(o[:, rows][:, :, heads], ref, ulps=2.0, atol=4e-3, msg="pre-scaled attention, L = 22880 rows")
+
+
 # ----------------------------------------------------------------------------- row kernels
 def test_ln_modulate_two_row_table(H):
     from oracle import dit as O
