@@ -20,6 +20,7 @@ def _stale(obj, src):
         return True
     t = os.path.getmtime(obj)
     deps = [src, os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "flexam_hip.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
