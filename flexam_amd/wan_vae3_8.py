@@ -177,18 +177,33 @@ class _Conv:
             w = w.unsqueeze(2)
         co, ci, kt, kh, kw = w.shape
         self.co, self.ci, self.kt, self.kh, self.kw = co, ci, kt, kh, kw
-        self.cp = _round_up(ci, 64)
-        wp = torch.zeros(co, kt, kh, kw, self.cp, device=device, dtype=F32)
-        wp[..., :ci] = w.permute(0, 2, 3, 4, 1)
-        # K order (dt, dh, channel block, dw, 64 channels): the kw taps of one image row are consecutive K blocks, and they read
-        # the same 64-channel slice of rows shifted by ONE position -- the second and third hit the L2 lines the first just
-        # brought in.  (With the tap-major order (dt, dh, dw, channel block) a shifted re-read comes cp/64 K blocks later, after
-        # the XCD's 32 workgroups have pulled 32 x cp/64 x 32 KiB through its 4 MiB L2: the 3x3x3 convs at 256 x 448 then fetch
-        # every activation ~9 times over the fabric.)  FLEXAM_VAE_KORDER=tap restores the tap-major order (A/B only).
+        # Run packing (channel counts that are not multiples of 64: the encoder's 160-channel stage and its 12-channel input): the
+        # image keeps `ci` channels per pixel (rounded to 8: 16-byte pixels) instead of padding each pixel to 64, and the kw taps of one
+        # image row -- kw * cp CONTIGUOUS elements starting at pixel w - 1 -- are one K run, padded to 64 as a whole (3 * 160 = 480 ->
+        # 512 instead of 3 * 192 = 576; 3 * 16 = 48 -> 64 instead of 192).  The run's last K block reads a few channels of pixel w + 2:
+        # finite activations against zero weights.  FLEXAM_VAE_RUNPACK=0 restores per-pixel padding (A/B only).
+        self.run_pack = kw == 3 and ci % 64 != 0 and os.environ.get("FLEXAM_VAE_RUNPACK", "1") != "0"
         self.k_rowmajor = os.environ.get("FLEXAM_VAE_KORDER", "row") != "tap"
-        if self.k_rowmajor:
-            wp = wp.view(co, kt, kh, kw, self.cp // 64, 64).permute(0, 1, 2, 4, 3, 5)
-        self.weight = wp.reshape(co, kt * kh * kw * self.cp).to(BF16).contiguous()
+        if self.run_pack:
+            self.cp = _round_up(ci, 8)
+            self.krun = _round_up(kw * self.cp, 64)
+            taps = torch.zeros(co, kt, kh, kw, self.cp, device=device, dtype=F32)
+            taps[..., :ci] = w.permute(0, 2, 3, 4, 1)
+            wp = torch.zeros(co, kt, kh, self.krun, device=device, dtype=F32)
+            wp[..., :kw * self.cp] = taps.reshape(co, kt, kh, kw * self.cp)
+            self.weight = wp.reshape(co, kt * kh * self.krun).to(BF16).contiguous()
+        else:
+            self.cp = _round_up(ci, 64)
+            wp = torch.zeros(co, kt, kh, kw, self.cp, device=device, dtype=F32)
+            wp[..., :ci] = w.permute(0, 2, 3, 4, 1)
+            # K order (dt, dh, channel block, dw, 64 channels): the kw taps of one image row are consecutive K blocks, and they read
+            # the same 64-channel slice of rows shifted by ONE position -- the second and third hit the L2 lines the first just
+            # brought in.  (With the tap-major order (dt, dh, dw, channel block) a shifted re-read comes cp/64 K blocks later, after
+            # the XCD's 32 workgroups have pulled 32 x cp/64 x 32 KiB through its 4 MiB L2: the 3x3x3 convs at 256 x 448 then fetch
+            # every activation ~9 times over the fabric.)  FLEXAM_VAE_KORDER=tap restores the tap-major order (A/B only).
+            if self.k_rowmajor:
+                wp = wp.view(co, kt, kh, kw, self.cp // 64, 64).permute(0, 1, 2, 4, 3, 5)
+            self.weight = wp.reshape(co, kt * kh * kw * self.cp).to(BF16).contiguous()
         self.bias = bias.detach().to(device, F32).contiguous()
         self.hist = kt - 1
         self.t_cap = t_cap
@@ -200,14 +215,16 @@ class _Conv:
         if self.shape != (h, w):
             hp, wp = h + 2, w + 2
             frames = self.hist + self.t_cap
-            guard = (wp + 1) * self.cp
+            guard = _round_up((wp + 1) * self.cp + 64, 8)       # + the overrun of a packed run's last K block
             self.buf = torch.zeros(guard * 2 + frames * hp * wp * self.cp, device=self.device, dtype=BF16)
             self.img = self.buf[guard:guard + frames * hp * wp * self.cp].view(frames, hp, wp, self.cp)
             offs = []
             tap = lambda dt, dh, dw: (dt * hp * wp + (dh - self.kh // 2) * wp + (dw - self.kw // 2)) * self.cp
             for dt in range(self.kt):
                 for dh in range(self.kh):
-                    if self.k_rowmajor:
+                    if self.run_pack:
+                        offs += [tap(dt, dh, 0) + 64 * blk for blk in range(self.krun // 64)]
+                    elif self.k_rowmajor:
                         offs += [tap(dt, dh, dw) + cb * 64 for cb in range(self.cp // 64) for dw in range(self.kw)]
                     else:
                         offs += [tap(dt, dh, dw) + cb * 64 for dw in range(self.kw) for cb in range(self.cp // 64)]
