@@ -33,47 +33,66 @@ template <typename TI, int NSLAB>
 __global__ __launch_bounds__(256) void vae_prep_vec_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
                                                            const float* __restrict__ gamma, int mode, bf16* __restrict__ dst, int Cp,
                                                            int t0, int dst_compact) {
+  // PIX positions per wave and iteration, their loads issued together: with <= 256 channels a position is one 0.5-1 KB access per
+  // wave, too little in flight to cover the HBM latency (counters: 2.7 / 3.8 TB/s at 256 channels against 5.3 at 512)
+  constexpr int PIX = NSLAB == 1 ? 4 : NSLAB == 2 ? 2 : 1;
   const int lane = threadIdx.x & 63;
   const int Hp = H + 2, Wp = W + 2;
   const int64_t npos = (int64_t)T * H * W;
-  for (int64_t pos = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); pos < npos; pos += (int64_t)gridDim.x * 4) {
-    const int w = (int)(pos % W);
-    int64_t r = pos / W;
-    const int h = (int)(r % H);
-    const int t = (int)(r / H);
-    const TI* s = src + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * lds_;
-    bf16* d = dst + (dst_compact ? pos : (((int64_t)(t + t0) * Hp + h + 1) * Wp + w + 1)) * Cp;
-    f32x4 v[NSLAB];
-    float q = 0.f;
+  for (int64_t pos0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PIX; pos0 < npos; pos0 += (int64_t)gridDim.x * 4 * PIX) {
+    f32x4 v[PIX][NSLAB];
+    const TI* s[PIX];
+    bf16* d[PIX];
 #pragma unroll
-    for (int i = 0; i < NSLAB; ++i) {
-      const int c = i * 256 + lane * 4;
-      if (c < C) {
-        if constexpr (sizeof(TI) == 4) {
-          v[i] = *(const f32x4*)((const float*)s + c);
+    for (int p = 0; p < PIX; ++p) {
+      const int64_t pos = pos0 + p < npos ? pos0 + p : npos - 1;      // a clamped tail position is loaded, never stored
+      const int w = (int)(pos % W);
+      int64_t r = pos / W;
+      const int h = (int)(r % H);
+      const int t = (int)(r / H);
+      s[p] = src + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * lds_;
+      d[p] = dst + (dst_compact ? pos : (((int64_t)(t + t0) * Hp + h + 1) * Wp + w + 1)) * Cp;
+    }
+#pragma unroll
+    for (int p = 0; p < PIX; ++p)
+#pragma unroll
+      for (int i = 0; i < NSLAB; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < C) {
+          if constexpr (sizeof(TI) == 4) {
+            v[p][i] = *(const f32x4*)((const float*)s[p] + c);
+          } else {
+            const bf16x4 b = *(const bf16x4*)((const bf16*)s[p] + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[p][i][j] = bf2f(b[j]);
+          }
         } else {
-          const bf16x4 b = *(const bf16x4*)((const bf16*)s + c);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[i][j] = bf2f(b[j]);
+          v[p][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-      } else {
-        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q += v[i][j] * v[i][j];
-    }
-    float scale = 1.f;
-    if (mode != 0) scale = sqrtf((float)C) / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    for (int p = 0; p < PIX; ++p) {
+      float scale = 1.f;
+      if (mode != 0) {
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NSLAB; ++i) {
-      const int c = i * 256 + lane * 4;
-      if (c >= C) continue;
-      f32x4 y = v[i];
-      if (mode != 0) y = y * scale * *(const f32x4*)(gamma + c);
-      bf16x4 o;
+        for (int i = 0; i < NSLAB; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = f2bf(mode == 2 ? silu(y[j]) : y[j]);
-      *(bf16x4*)(d + c) = o;
+          for (int j = 0; j < 4; ++j) q += v[p][i][j] * v[p][i][j];
+        scale = sqrtf((float)C) / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+      }
+      if (pos0 + p >= npos) continue;
+#pragma unroll
+      for (int i = 0; i < NSLAB; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c >= C) continue;
+        f32x4 y = v[p][i];
+        if (mode != 0) y = y * scale * *(const f32x4*)(gamma + c);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf(mode == 2 ? silu(y[j]) : y[j]);
+        *(bf16x4*)(d[p] + c) = o;
+      }
     }
   }
 }
