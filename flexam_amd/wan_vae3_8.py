@@ -211,13 +211,20 @@ class _Conv:
         self.shape = None
         self._koff = None
 
+    # Causal convs keep their input frames in a ring of RING chunks: the window [history | current chunk] slides forward by the chunk
+    # length after every run, so the last `hist` frames of a chunk ARE the history of the next one where they lie; only when the
+    # window reaches the end of the buffer are those frames copied to its start (every RING-th chunk instead of after every chunk:
+    # the copies were 3 % of a decode and 5 % of an encode).  Border positions are zero everywhere and never written.
+    RING = max(1, int(os.environ.get("FLEXAM_VAE_RING", "4")))
+
     def image(self, h, w):
         if self.shape != (h, w):
             hp, wp = h + 2, w + 2
-            frames = self.hist + self.t_cap
+            frames = self.hist + self.t_cap * (self.RING if self.hist else 1)
             guard = _round_up((wp + 1) * self.cp + 64, 8)       # + the overrun of a packed run's last K block
             self.buf = torch.zeros(guard * 2 + frames * hp * wp * self.cp, device=self.device, dtype=BF16)
-            self.img = self.buf[guard:guard + frames * hp * wp * self.cp].view(frames, hp, wp, self.cp)
+            self.all = self.buf[guard:guard + frames * hp * wp * self.cp].view(frames, hp, wp, self.cp)
+            self.cur = 0                                         # first frame of the window
             offs = []
             tap = lambda dt, dh, dw: (dt * hp * wp + (dh - self.kh // 2) * wp + (dw - self.kw // 2)) * self.cp
             for dt in range(self.kt):
@@ -230,14 +237,17 @@ class _Conv:
                         offs += [tap(dt, dh, dw) + cb * 64 for dw in range(self.kw) for cb in range(self.cp // 64)]
             self._koff = torch.tensor(offs, dtype=I64, device=self.device)
             self.shape = (h, w)
+            self.img = self.all[:self.hist + self.t_cap]
         return self.img
 
     def reset(self):
         if self.shape is not None and self.hist:
+            self.cur = 0
+            self.img = self.all[:self.hist + self.t_cap]
             self.img[:self.hist].zero_()
 
     def run(self, t, h, w, out_dtype=F32, residual_into=None):
-        """Convolve the `t` current frames (image frames hist..hist+t); then roll the history."""
+        """Convolve the `t` current frames (window frames hist..hist+t); then slide the window."""
         rows = t * (h + 2) * (w + 2)
         a = self.img.view(-1, self.cp)
         if residual_into is not None:
@@ -248,10 +258,15 @@ class _Conv:
         return out
 
     def roll(self, t):
-        """The last `hist` frames become the history of the next chunk."""
+        """The last `hist` frames of the chunk become the history of the next one: the window moves on by t frames."""
         if self.hist:
-            src = self.img[t:t + self.hist]
-            self.img[:self.hist].copy_(src.clone() if t < self.hist else src)
+            win = self.hist + self.t_cap
+            self.cur += t
+            if self.cur + win > self.all.shape[0]:               # end of the ring: bring the history to the front
+                src = self.all[self.cur:self.cur + self.hist]
+                self.all[:self.hist].copy_(src.clone() if self.cur < self.hist else src)
+                self.cur = 0
+            self.img = self.all[self.cur:self.cur + win]
 
     def run_time_stride2(self, t, h, w, out_dtype=F32):
         """(3,1,1) conv with temporal stride 2 and one cached frame (Resample downsample3d, VAE.py:162-174):
