@@ -53,7 +53,6 @@ struct AttnParams {
   // this call are only PART of the softmax: local-chunk-first attention under a sequence-parallel K|V all-gather);
   // n_slots: slots the merge kernel adds up
   int partial, slot0, n_slots;
-  const int* redo;      // fix-up launch behind the experimental wide kernel: only units whose flag is set run (nullptr: all)
   int prio_young;       // tuning switch (FLEXAM_ATTN_PRIO=1): s_setprio 1 for waves 4-7, the arbitration losers of every segment (guide, two waves per SIMD, item 4)
 };
 
@@ -171,7 +170,6 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, local = bid >> 3;
     bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
   }
-  if (p.redo && p.redo[bid] == 0) return;         // (uniform per workgroup, in front of every barrier)
   // consecutive workgroups: the units of one split, i.e. q blocks of one head first -> same K/V range in L2
   const int split = bid / p.n_units;
   const int ul = bid - split * p.n_units;          // unit index inside this launch
@@ -523,8 +521,6 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
-#include "attn_wide.inc"
-
 // out[b][q][head][:] = sum_s w_s O_s / sum_s w_s l_s with w_s = exp2((m_s - max_s m_s) * scale_log2e) for the rows of the
 // launch's units; one wave per row, two columns per lane
 __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
@@ -579,7 +575,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.tiles_per_split = (tiles_all + kv_splits - 1) / kv_splits;
   p.kv_splits = (tiles_all + p.tiles_per_split - 1) / p.tiles_per_split;     // drop empty trailing splits
   p.ws_o = ws_o; p.ws_ml = ws_ml;
-  p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits; p.redo = nullptr;
+  p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits;
   {
     const char* e = getenv("FLEXAM_ATTN_PRIO");           // read per call: tools/ab_attn_prio.py flips it inside one process
     p.prio_young = e ? atoi(e) : 0;
@@ -611,27 +607,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   if (S == 1) split_from_unit = units;
   if (split_from_unit > 0) {               // units [0, split_from_unit): one pass over all keys
     p.unit0 = 0; p.n_units = split_from_unit; p.kv_splits = 1; p.tiles_per_split = tiles_all;
-    const char* wide = getenv("FLEXAM_ATTN_WIDE");
-    const int64_t ws_ml_bytes = (int64_t)S * (units - split_from_unit) * QBLK * 2 * 4;
-    if (wide && atoi(wide) && p.prescaled && !cross && ws_ml && (int64_t)p.n_units * 4 <= ws_ml_bytes) {
-      // EXPERIMENTAL: 4 waves x 64 rows (attn_wide.inc); units it flags are redone by the 8-wave kernel.  The flags borrow the
-      // head of the split-KV workspace, which the launches below only write after this pair.
-      static bool wide_attr[FLEXAM_MAX_DEVICES] = {};
-      if (!wide_attr[dev]) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_wide_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
-          return flexam_fail(FLEXAM_E_LAUNCH, "attn_fwd: cannot raise dynamic LDS to %d bytes", smem);
-        wide_attr[dev] = true;
-      }
-      int* flags = (int*)ws_ml;
-      if (hipMemsetAsync(flags, 0, (size_t)p.n_units * 4, (hipStream_t)stream) != hipSuccess)
-        return flexam_fail(FLEXAM_E_LAUNCH, "attn_fwd: memset of the redo flags failed");
-      hipLaunchKernelGGL(attn_fwd_wide_kernel<true>, dim3(p.n_units), dim3(NTW), smem, (hipStream_t)stream, p, flags);
-      p.redo = flags;
-      hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);
-      p.redo = nullptr;
-    } else {
-      hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);
-    }
+    hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);
   }
   if (split_from_unit < units) {           // the rest: S key ranges each, then the merge
     p.unit0 = split_from_unit; p.n_units = units - split_from_unit; p.kv_splits = S; p.tiles_per_split = tps; p.partial = 1; p.n_slots = S;
