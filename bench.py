@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- denoise-steps/sec of the FlexAM hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N rank processes, see launch_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --mask blob                           (BASELINE configs[3]: foreground_edit masks, its own JSON line)
 
 Workload (BASELINE config 2): Wan2.2-Fun-5B-FLEXAM DiT (dim 3072, 24 heads x 128, ffn 14336,
 30 layers, 5.03 B parameters, random-init bf16), 97x512x896 -> latent [1,48,25,32,56], L = 11648 tokens
@@ -42,7 +43,23 @@ def block_flops(L, d, f, T):
     return 8 * L * d * d + 4 * L * L * d + 4 * L * d * d + 4 * T * d * d + 4 * L * T * d + 4 * L * d * f
 
 
-def synthetic_inputs(frames, height, width, text_dim):
+def blob_mask_pixels(frames, height, width, mode):
+    """Pixel-space mask video [1,1,F,H,W] of the foreground_edit mode (demo.py:87-124: 1 = regenerate; frame 0 is always 0):
+    a disc that drifts and breathes over the frames.  "blob": demo.py's form (frame 0 kept -> PIPE.py:688-690 pins frame 0 and
+    sets every later frame to 1: two distinct per-token timesteps, like motion_transfer, but fractional mask latents and a
+    zeroed masked video);  "blob-open": the disc also covers frame 0 (not pinned: the trilinear latent mask has soft edges,
+    a dozen distinct timesteps per sample);  "soft": uniform random mask values (stress: hundreds of distinct timesteps)."""
+    if mode == "soft":
+        return torch.rand(1, 1, frames, height, width, generator=torch.Generator().manual_seed(3))
+    yy, xx = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32), indexing="ij")
+    m = torch.zeros(1, 1, frames, height, width)
+    for f in range(0 if mode == "blob-open" else 1, frames):
+        r = height * 0.22 * (1.0 + 0.2 * math.sin(0.2 * f))
+        m[0, 0, f] = (((yy - height * 0.5 - 0.5 * f) ** 2 + (xx - width * 0.4 - 1.5 * f) ** 2) < r * r).float()
+    return m
+
+
+def synthetic_inputs(frames, height, width, text_dim, mask_mode="motion"):
     """Seeded synthetic conditioning of SURVEY 8(d) (CPU generators -> identical on every rank)."""
     f, h, w = (frames - 1) // 4 + 1, height // 16, width // 16
     g0 = torch.Generator().manual_seed(1245644)          # demo.py seed
@@ -55,12 +72,20 @@ def synthetic_inputs(frames, height, width, text_dim):
     g2 = torch.Generator().manual_seed(2)
     ctx_u = [torch.randn(77, text_dim, generator=g2) * 0.1]
     ctx_c = [torch.randn(126, text_dim, generator=g2) * 0.1]
-    mask = torch.ones(1, 1, f, h, w)
-    mask[:, :, 0] = 0                                     # motion_transfer: frame 0 known
-    mask_latents = torch.zeros(1, 4, f, h, w)
-    mask_latents[:, :, 0] = 1                             # resize_mask(1 - mask_condition) for that mask
+    mask_pixels = None
+    if mask_mode == "motion":
+        mask = torch.ones(1, 1, f, h, w)
+        mask[:, :, 0] = 0                                 # motion_transfer: frame 0 known
+        mask_latents = torch.zeros(1, 4, f, h, w)
+        mask_latents[:, :, 0] = 1                         # resize_mask(1 - mask_condition) for that mask
+    else:                                                 # foreground_edit (BASELINE configs[3]): PIPE.py:675-690 builds both from the pixel mask
+        from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import prepare_masks
+        mask_pixels = blob_mask_pixels(frames, height, width, mask_mode)
+        ml, _, _ = prepare_masks(mask_pixels.clone(), (1, 48, f, h, w))
+        masked = masked * ml[:, :1]                       # the masked video is zero where the mask says "regenerate"
+        mask = mask_latents = None
     return dict(latents=latents, control=control, additional=additional, masked=masked, ref=ref, ctx_u=ctx_u, ctx_c=ctx_c,
-                mask=mask, mask_latents=mask_latents)
+                mask=mask, mask_latents=mask_latents, mask_pixels=mask_pixels)
 
 
 def build_model(cfg, device):
@@ -107,10 +132,18 @@ def kernel_rooflines(eng, B, L, lc):
         if eng.sp_size == 1:
             k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hd))
             v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hd))
+            t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd), prescaled=True), iters=8)
         else:
-            kv = ws["kv_cat"]                  # gathered K|V of the last block (same shape as every block's)
-            k4, v4 = kv[:, :, 0:d].unflatten(2, (nh, hd)), kv[:, :, d:].unflatten(2, (nh, hd))
-        t = time_kernel(lambda: hip.attn_fwd(q4, k4, v4, out=ao.view(B, lc, nh, hd), prescaled=True), iters=8)
+            kv = ws["kv_cat"]                  # gathered K|V pieces of the last block [G, B, L, 2C/G] (same shape in every block)
+            G = kv.shape[0]
+            cb, hg = d // G, nh // G
+            ao4 = ao.view(B, lc, nh, hd)
+
+            def all_groups():
+                for g in range(G):
+                    hip.attn_fwd(q4[:, :, g * hg:(g + 1) * hg], kv[g, :, :, 0:cb].unflatten(2, (hg, hd)), kv[g, :, :, cb:].unflatten(2, (hg, hd)),
+                                 out=ao4[:, :, g * hg:(g + 1) * hg], prescaled=True)
+            t = time_kernel(all_groups, iters=8)
         out["attn_self"] = dict(flops=4.0 * B * lc * L * d, sec=t)
     t = time_kernel(lambda: hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv))
     out["gemm_qkv"] = dict(flops=2.0 * M * 3 * d * d, sec=t)
@@ -260,6 +293,107 @@ def time_vae(device, frames, height, width):
     return sec, enc[0], enc[1], finite
 
 
+def multi_gpu_check(pipe, model, inp, cond, step_index, total_steps, world, rank):
+    """Self-validation of an N-rank run, AFTER the timed region.  Every rank applies the identical sampler update to the gathered
+    head output, so "all ranks hold the same latents" alone would also pass with a wrong K|V exchange.  Two checks:
+      (1) ranks_agree: checksum of every rank's latents == rank 0's (they are bit-identical by construction);
+      (2) rel_rms_vs_single_gpu: one more denoise step from the current latents on the N-rank layout, and the SAME step on this
+          rank alone (weights are replicated: a second engine with no parallel layout, full CFG pair, no collective); the two
+          latent updates must agree to the rounding of the partial-softmax merge (<= 1e-2 relative RMS of the update).
+    Returns the `check` object of the JSON line (rank 0's view + the worst rank)."""
+    import torch.distributed as dist
+    from flexam_amd import Wan2_2FunControlPipeline_FlexAM, hip
+    st = pipe._state
+    lat0 = st["latents"].clone()
+    pipe.denoise_step(step_index)
+    lat_multi = st["latents"].clone()
+    sums = [None] * world
+    dist.all_gather_object(sums, hip.checksum(lat_multi))
+    agree = all(tuple(c) == tuple(sums[0]) for c in sums)
+    layout = model._parallel
+    model._parallel, model._engine = None, None                 # a fresh engine: one GPU, no collective
+    solo = Wan2_2FunControlPipeline_FlexAM(transformer=model)
+    solo.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+    solo._state["latents"].copy_(lat0)
+    solo.denoise_step(step_index)
+    upd_s = (solo._state["latents"] - lat0).double()
+    upd_m = (lat_multi - lat0).double()
+    rel = float(((upd_m - upd_s).pow(2).mean().sqrt() / upd_s.pow(2).mean().sqrt().clamp_min(1e-30)).item())
+    model._parallel, model._engine = layout, None
+    rels = [None] * world
+    dist.all_gather_object(rels, rel)
+    worst = max(rels)
+    ok = bool(agree and worst <= 1e-2 and math.isfinite(worst))
+    return {"ok": ok, "ranks": world, "ranks_agree": bool(agree), "rel_rms_vs_single_gpu": rel, "worst_rank_rel_rms": worst, "tolerance": 1e-2,
+            "what": "latent update of one denoise step: N-rank layout vs the same step on one GPU (no collective), every rank; "
+                    "checksums of the N ranks' latents"}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: start the N ranks ourselves.
+
+    This parent never touches the GPU (no HIP call, no torch.cuda.is_available()): the ranks are FRESH child processes of
+    `python -m torch.distributed.run`, never an exec of a process that has initialised the device.  Rank 0's JSON line and the
+    launcher's exit code are forwarded.  The first attempt runs the default exchange; when its
+    self-check (`check.ok`, see multi_gpu_check) fails, it crashes or it hangs, ONE more attempt runs the conservative form of the
+    same exchange (FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0: one K|V all-gather per block, waited for before attention) and the line
+    says so in `launch.fallback` -- a wrong or dead overlap path must not cost the scaling measurement."""
+    import signal
+    import socket
+    import subprocess
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        return port
+
+    n_dev = torch.cuda.device_count()               # counting devices does not initialise the GPU on this image
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < args.gpus and env0.get("FLEXAM_BENCH_ONE_DEVICE") != "1":
+        raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible (FLEXAM_BENCH_ONE_DEVICE=1 FLEXAM_BENCH_BACKEND=gloo "
+                         f"runs the rank code path on one device for validation; such a line is marked invalid)")
+    attempts = [("default", {})]
+    if "FLEXAM_SP_OVERLAP" not in os.environ and "FLEXAM_SP_PIECES" not in os.environ and args.gpus > 2:
+        attempts.append(("FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0", {"FLEXAM_SP_PIECES": "1", "FLEXAM_SP_OVERLAP": "0"}))
+    limit = float(os.environ.get("FLEXAM_BENCH_ATTEMPT_TIMEOUT", "1500"))
+    last_rc, last_line, notes = 1, None, []
+    for name, extra in attempts:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        proc = subprocess.Popen(cmd, env={**env0, **extra}, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=limit)
+            rc = proc.returncode
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)      # the process group this launcher created, nothing else
+            out, _ = proc.communicate()
+            rc = 124
+        line = None
+        for ln in (out or "").splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+            else:
+                print(ln, file=sys.stderr)
+        ok = rc == 0 and line is not None
+        if ok:
+            res = json.loads(line)
+            chk = res.get("check")
+            ok = chk is None or bool(chk.get("ok"))
+            res["launch"] = {"spawned_by": "bench.py (parent made no GPU call)", "attempt": name, "earlier_attempts": notes or None,
+                             "fallback": name != "default"}
+            line = json.dumps(res)
+        last_rc, last_line = rc, line
+        if ok:
+            break
+        notes.append({"attempt": name, "rc": rc, "check": (json.loads(line).get("check") if line else None)})
+    if last_line is not None:
+        print(last_line, flush=True)
+    sys.exit(last_rc if last_rc != 0 else (0 if last_line is not None else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,8 +408,14 @@ def main():
     ap.add_argument("--no-cpu-legs", action="store_true", help="skip the config-1 and VAE-chunk CPU baseline legs (keep the one-block leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--mask", choices=["motion", "blob", "blob-open", "soft"], default="motion",
+                    help="motion: BASELINE configs[1] (motion_transfer, frame 0 known); blob: configs[3] foreground_edit as demo.py "
+                         "builds it; blob-open / soft: foreground masks that are not pinned (many per-token timesteps)")
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip the cross-rank / single-GPU self-check after the timed region")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)                      # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -308,9 +448,11 @@ def main():
         cp = os.environ.get("FLEXAM_CFG_PARALLEL")
         model.enable_multi_gpus_inference(cfg_parallel=None if cp is None else cp == "1")
     pipe = Wan2_2FunControlPipeline_FlexAM(transformer=model)
-    inp = synthetic_inputs(args.frames, args.height, args.width, cfg["text_dim"])
-    cond = LatentConditioning(control_latents=inp["control"], additional_control=inp["additional"], masked_video_latents=inp["masked"],
-                              ref_latents=inp["ref"], mask_latents=inp["mask_latents"], mask=inp["mask"])
+    def conditioning(mode):
+        i = synthetic_inputs(args.frames, args.height, args.width, cfg["text_dim"], mode)
+        return i, LatentConditioning(control_latents=i["control"], additional_control=i["additional"], masked_video_latents=i["masked"],
+                                     ref_latents=i["ref"], mask_latents=i["mask_latents"], mask=i["mask"], mask_pixels=i["mask_pixels"])
+    inp, cond = conditioning(args.mask)
     total_steps = 50
     pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
     torch.cuda.synchronize()
@@ -341,12 +483,35 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(pipe._state["latents"]).all())
+    rows_u = int(pipe._state["U"])
+
+    def timed(p):
+        for i in range(args.warmup):
+            p.denoise_step(i % total_steps)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            p.denoise_step((args.warmup + i) % total_steps)
+        sync()
+        return time.perf_counter() - t0
+    motion_elapsed = None
+    if args.mask != "motion" and world == 1:
+        # configs[3] next to configs[1]: the SAME steps on the motion_transfer conditioning, in this process (the delta is what
+        # the foreground masks cost: per-token timestep rows, AdaLN table size)
+        inp_m, cond_m = conditioning("motion")
+        pipe.prepare(inp_m["latents"], cond_m, inp_m["ctx_c"], inp_m["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+        motion_elapsed = timed(pipe)
+        pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+        del inp_m, cond_m
 
     lc = L // eng.sp_size
     b_local = 1 if eng.cfg_size == 2 else B
     kern = None if args.no_kernel_timing else kernel_rooflines(eng, b_local, L, lc)
     if kern is not None and pipe._state.get("known") is not None:
         kern["cfg_euler_blend"] = sampler_step_roofline(pipe)
+    check = None
+    if world > 1 and not args.no_check:
+        check = multi_gpu_check(pipe, model, inp, cond, (args.warmup + args.steps) % total_steps, total_steps, world, rank)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(L, cfg)
@@ -355,8 +520,10 @@ def main():
 
     eng_cfg, eng_sp, eng_mode = eng.cfg_size, eng.sp_size, getattr(eng, "sp_mode", "-")
     if eng_mode == "allgather":
-        eng_mode = ("K|V all-gather per block, overlapped with the Q projection and the attention to the local chunk (partial softmaxes merged)"
-                    if getattr(eng, "sp_overlap", False) else "K|V all-gather per block, overlapped with the Q projection only")
+        pcs = getattr(eng, "sp_pieces", 1)
+        eng_mode = (f"K|V all-gather per block in {pcs} head-group piece(s), " +
+                    ("each consumed as it lands: Q projection + local-chunk attention under piece 0 (partial softmaxes merged), piece g+1 under the attention of group g"
+                     if getattr(eng, "sp_overlap", False) else "waited for before attention (overlaps the Q projection only)"))
     elif eng_mode == "ulysses":
         eng_mode = "all-to-all over heads (q|k|v out, attention output back)"
     vae_sec = enc_sec = enc_stream_sec = None
@@ -378,7 +545,9 @@ def main():
             "config": {"workload": f"Wan2.2-Fun-5B-FLEXAM DiT denoise step, {args.frames}x{args.height}x{args.width}, "
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
                                    f"random-init bf16 weights, synthetic conditioning "
-                                   + ("(BASELINE configs[1])" if (args.frames, args.height, args.width) == (97, 512, 896) and not args.fp8 else
+                                   + (("(BASELINE configs[1])" if args.mask == "motion" else f"(BASELINE configs[3]: foreground_edit, mask '{args.mask}', "
+                                       f"{rows_u} distinct per-token timesteps per sample)")
+                                      if (args.frames, args.height, args.width) == (97, 512, 896) and not args.fp8 else
                                       "(BASELINE configs[4] shape family: " + ("fp8 e4m3 QKV/FFN GEMMs with per-row / per-channel scales, everything else bf16/fp32" if args.fp8 else "bf16")
                                       + "; not the headline)"),
                        "parallelism": ((f"cfg{eng_cfg} x sp{eng_sp}: one CFG row per rank" + (", no per-block traffic" if eng_sp == 1 else
@@ -395,7 +564,18 @@ def main():
             "dit_block_mfma_frac": step_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
             "dit_block_mfma_frac_note": "against the 2.5 PFLOP/s bf16 peak" + (" (QKV / FFN ran on the 5 PFLOP/s fp8 pipe: not a roofline fraction)" if args.fp8 else ""),
             "finite": finite,
+            "mask": args.mask, "timestep_rows_per_sample": rows_u,
         }
+        if motion_elapsed is not None:
+            result["configs1_same_process"] = {"ms_per_step": motion_elapsed / args.steps * 1e3, "value": args.steps / motion_elapsed,
+                                               "delta_pct": (elapsed / motion_elapsed - 1.0) * 100.0,
+                                               "note": "the same steps on the motion_transfer conditioning (BASELINE configs[1]) in this process"}
+        if check is not None:
+            result["check"] = check
+            result["rccl_ranks"] = world if backend == "nccl" else 0
+            result["ranks_agree"] = check["ranks_agree"]
+            if not check["ok"]:
+                result["invalid"] = "multi-GPU self-check failed: " + json.dumps(check)
         if one_device or backend != "nccl":
             result["invalid"] = f"code-path validation only: {world} ranks on one device / backend {backend}"
         if kern is not None:

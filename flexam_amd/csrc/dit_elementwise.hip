@@ -331,27 +331,34 @@ __global__ __launch_bounds__(256) void mod_table_kernel(const float* __restrict_
 // The time / density embedding MLPs run in fp32 in the reference (FX.py:928-955).
 // One wave per output column n; lanes stride K.
 // ------------------------------------------------------------------------------------------
-template <typename WT, int MAXM>
+template <typename WT, int MAXM, int NPW>
 __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, int64_t ldx, const WT* __restrict__ W,
                                                            int64_t ldw, const float* __restrict__ b, float* __restrict__ y,
                                                            int64_t ldy, int M, int N, int K, int silu_in) {
+  // one wave per NPW consecutive outputs n: every x element it loads feeds NPW weight rows (the x rows come from L2 once per
+  // wave, so NPW = 4 at M = 32 keeps that traffic below the weight stream's)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + wave;
-  if (n >= N) return;
-  float acc[MAXM];
+  const int n0 = (blockIdx.x * 4 + wave) * NPW;
+  if (n0 >= N) return;
+  float acc[MAXM][NPW];
 #pragma unroll
-  for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
-  const WT* wr = W + (int64_t)n * ldw;
+  for (int m = 0; m < MAXM; ++m)
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) acc[m][q] = 0.f;
   for (int k = lane * 4; k < K; k += 256) {
-    float w[4];
-    if constexpr (sizeof(WT) == 2) {
-      const bf16x4 t = *(const bf16x4*)(wr + k);
+    float w[NPW][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = bf2f(t[j]);
-    } else {
-      const f32x4 t = *(const f32x4*)(wr + k);
+    for (int q = 0; q < NPW; ++q) {
+      const WT* wr = W + (int64_t)min(n0 + q, N - 1) * ldw;
+      if constexpr (sizeof(WT) == 2) {
+        const bf16x4 t = *(const bf16x4*)(wr + k);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = t[j];
+        for (int j = 0; j < 4; ++j) w[q][j] = bf2f(t[j]);
+      } else {
+        const f32x4 t = *(const f32x4*)(wr + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[q][j] = t[j];
+      }
     }
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) {
@@ -361,16 +368,19 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) {
           float t = xv[j];
           if (silu_in) t = t / (1.0f + __expf(-t));
-          acc[m] += t * w[j];
+#pragma unroll
+          for (int q = 0; q < NPW; ++q) acc[m][q] += t * w[q][j];
         }
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < MAXM; ++m) {
-    const float t = wave_sum(acc[m]);
-    if (lane == 0 && m < M) y[(int64_t)m * ldy + n] = t + (b ? b[n] : 0.f);
-  }
+  for (int m = 0; m < MAXM; ++m)
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+      const float t = wave_sum(acc[m][q]);
+      if (lane == 0 && m < M && n0 + q < N) y[(int64_t)m * ldy + n0 + q] = t + (b ? b[n0 + q] : 0.f);
+    }
 }
 
 // sinusoidal_embedding_1d (FX.py:31-41): out[r][:half] = cos(t_r * f_i), out[r][half:] = sin(...), fp64 math
@@ -463,6 +473,53 @@ __global__ __launch_bounds__(256) void cfg_euler_blend_kernel(const float* __res
   }
 }
 
+// The same step with the token rows read ONCE, 16 bytes per lane: one workgroup per (frame, pair of latent rows) stages the
+// guided velocity of its W/2 tokens ([W/2][4C] fp32, row pitch 4C + 1 words: bank-conflict free for the transposed read) in
+// LDS, then writes the 2 x W x C latents it covers channel-major, W contiguous floats per (channel, row).  The gather form
+// above reads a 4-byte piece of a 768-byte token row per lane and fetched 13x the algorithmic bytes.
+__global__ __launch_bounds__(256) void cfg_euler_blend_tiled_kernel(const float* __restrict__ tok_u, const float* __restrict__ tok_c,
+                                                                    int64_t ldt, int64_t tok0, float guidance, float dt,
+                                                                    float* __restrict__ latents, const float* __restrict__ known,
+                                                                    const float* __restrict__ mask, int C, int F, int H, int W,
+                                                                    float* __restrict__ v_out) {
+  extern __shared__ float sm_v[];
+  const int W2 = W >> 1, NC = 4 * C, NCP = NC + 1, H2 = H >> 1;
+  const int f = blockIdx.x / H2, h2 = blockIdx.x - f * H2;
+  const int64_t tokbase = tok0 + (int64_t)f * H2 * W2 + (int64_t)h2 * W2;
+  const int nc4 = NC >> 2;
+  for (int idx = threadIdx.x; idx < W2 * nc4; idx += 256) {
+    const int tw = idx / nc4, c4 = idx - tw * nc4;
+    const int64_t off = (tokbase + tw) * ldt + c4 * 4;
+    f32x4 v = *(const f32x4*)(tok_u + off);
+    if (tok_c) {
+      const f32x4 c = *(const f32x4*)(tok_c + off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] + guidance * (c[j] - v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm_v[tw * NCP + c4 * 4 + j] = v[j];
+  }
+  __syncthreads();
+  const int64_t fhw = (int64_t)F * H * W;
+  for (int idx = threadIdx.x; idx < C * 2 * W; idx += 256) {
+    const int w = idx % W;
+    const int t = idx / W;
+    const int ph = t & 1, c = t >> 1;
+    const float v = sm_v[(w >> 1) * NCP + ((ph << 1) | (w & 1)) * C + c];
+    const int64_t i = (((int64_t)c * F + f) * H + 2 * h2 + ph) * W + w;
+    if (v_out) {
+      v_out[i] = v;
+      continue;
+    }
+    float x = latents[i] + dt * v;
+    if (mask) {
+      const float mk = mask[i % fhw];
+      x = (1.0f - mk) * known[i] + mk * x;
+    }
+    latents[i] = x;
+  }
+}
+
 // y = a*x + b*y over n fp32 elements (TeaCache residual bookkeeping, FX.py:1003-1051)
 __global__ __launch_bounds__(256) void axpby_kernel(float* __restrict__ y, float a, const float* __restrict__ x, float b, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -507,19 +564,31 @@ inline int grid_for(int64_t total, int block) {
 // Host logic uses it to recognise step-invariant conditioning that the reference sampler re-materialises with torch.cat on
 // every step (PIPE.py:850-886).  Integer sums: the order of the atomic adds does not matter.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long checksum_mix(unsigned long long x) {   // splitmix64 finaliser
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// out[0], out[1] += two independent 64-bit hashes of every (index, word) pair, summed: position-sensitive, order-independent in
+// the additions (integer atomics), so two buffers collide only if their multisets of (index, word) hashes sum alike.
 __global__ __launch_bounds__(256) void checksum_kernel(const uint32_t* __restrict__ w, int64_t n_words, const uint8_t* __restrict__ tail,
                                                        int n_tail, unsigned long long* __restrict__ out) {
   unsigned long long s0 = 0, s1 = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) {
-    const unsigned long long v = w[i];
-    s0 += v;
-    s1 += v * (unsigned long long)(i + 1);
+    const unsigned long long x = (unsigned long long)w[i] + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull;
+    s0 += checksum_mix(x);
+    s1 += checksum_mix(x ^ 0xD6E8FEB86659FD93ull);
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int j = 0; j < n_tail; ++j) {
-      s0 += tail[j];
-      s1 += (unsigned long long)tail[j] * (unsigned long long)(n_words + 1 + j);
+      const unsigned long long x = (unsigned long long)tail[j] + (unsigned long long)(n_words + 1 + j) * 0x9E3779B97F4A7C15ull;
+      s0 += checksum_mix(x);
+      s1 += checksum_mix(x ^ 0xD6E8FEB86659FD93ull);
     }
+    s0 += checksum_mix((unsigned long long)n_words * 4 + n_tail);      // the byte count is part of the key
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     s0 += __shfl_xor(s0, o, 64);
@@ -666,13 +735,22 @@ extern "C" int flexam_mod_table(const float* mod, const float* e, const float* m
 extern "C" int flexam_small_linear_f32(const float* x, int64_t ldx, const void* W, int w_is_bf16, int64_t ldw, const float* b,
                                        float* y, int64_t ldy, int M, int N, int K, int silu_in, void* stream) {
   FX_REQUIRE(x && W && y, FLEXAM_E_ARG, "small_linear: null pointer");
-  FX_REQUIRE(M >= 1 && M <= 8, FLEXAM_E_SHAPE, "small_linear: M=%d must be in 1..8", M);
+  FX_REQUIRE(M >= 1 && M <= 32, FLEXAM_E_SHAPE, "small_linear: M=%d must be in 1..32", M);
   FX_REQUIRE(K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0, FLEXAM_E_SHAPE, "small_linear: K, ldx, ldw must be multiples of 4");
-  dim3 grid((N + 3) / 4), block(256);
-  if (w_is_bf16)
-    hipLaunchKernelGGL((small_linear_kernel<bf16, 8>), grid, block, 0, (hipStream_t)stream, x, ldx, (const bf16*)W, ldw, b, y, ldy, M, N, K, silu_in);
-  else
-    hipLaunchKernelGGL((small_linear_kernel<float, 8>), grid, block, 0, (hipStream_t)stream, x, ldx, (const float*)W, ldw, b, y, ldy, M, N, K, silu_in);
+  dim3 block(256);
+  if (M <= 8) {                       // one output per wave (two distinct timesteps per sample in every demo mode)
+    dim3 grid((N + 3) / 4);
+    if (w_is_bf16)
+      hipLaunchKernelGGL((small_linear_kernel<bf16, 8, 1>), grid, block, 0, (hipStream_t)stream, x, ldx, (const bf16*)W, ldw, b, y, ldy, M, N, K, silu_in);
+    else
+      hipLaunchKernelGGL((small_linear_kernel<float, 8, 1>), grid, block, 0, (hipStream_t)stream, x, ldx, (const float*)W, ldw, b, y, ldy, M, N, K, silu_in);
+  } else {                            // soft foreground masks: hundreds of distinct timesteps, 32 rows per pass over the weights
+    dim3 grid((N + 15) / 16);
+    if (w_is_bf16)
+      hipLaunchKernelGGL((small_linear_kernel<bf16, 32, 4>), grid, block, 0, (hipStream_t)stream, x, ldx, (const bf16*)W, ldw, b, y, ldy, M, N, K, silu_in);
+    else
+      hipLaunchKernelGGL((small_linear_kernel<float, 32, 4>), grid, block, 0, (hipStream_t)stream, x, ldx, (const float*)W, ldw, b, y, ldy, M, N, K, silu_in);
+  }
   return flexam_check_launch("flexam_small_linear_f32");
 }
 
@@ -707,14 +785,26 @@ extern "C" int flexam_unpatchify(const float* tok, int64_t ldt, int64_t tok0, in
   return flexam_check_launch("flexam_unpatchify");
 }
 
+static int launch_cfg_euler_blend(const float* tok_u, const float* tok_c, int64_t ldt, int64_t tok0, float guidance, float dt, float* latents,
+                                  const float* known, const float* mask, int C, int F, int H, int W, float* v_out, hipStream_t st) {
+  const size_t lds = (size_t)(W / 2) * (4 * C + 1) * sizeof(float);
+  const bool vec = ldt % 4 == 0 && (uintptr_t)tok_u % 16 == 0 && (!tok_c || (uintptr_t)tok_c % 16 == 0) && lds <= 64 * 1024;
+  if (vec)
+    hipLaunchKernelGGL(cfg_euler_blend_tiled_kernel, dim3(F * (H / 2)), dim3(256), lds, st, tok_u, tok_c, ldt, tok0, guidance, dt, latents,
+                       known, mask, C, F, H, W, v_out);
+  else
+    hipLaunchKernelGGL(cfg_euler_blend_kernel, dim3(grid_for((int64_t)C * F * H * W, 256)), dim3(256), 0, st, tok_u, tok_c, ldt, tok0,
+                       guidance, dt, latents, known, mask, C, F, H, W, v_out);
+  return 0;
+}
+
 extern "C" int flexam_cfg_euler_blend(const float* tok_uncond, const float* tok_cond, int64_t ldt, int64_t tok0, float guidance,
                                       float dt, float* latents, const float* known, const float* mask, int C, int F, int H, int W,
                                       void* stream) {
   FX_REQUIRE(tok_uncond && latents, FLEXAM_E_ARG, "cfg_euler_blend: null pointer");
   FX_REQUIRE((mask == nullptr) == (known == nullptr), FLEXAM_E_ARG, "cfg_euler_blend: mask and known go together");
   FX_REQUIRE(H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "cfg_euler_blend: H, W must be even");
-  hipLaunchKernelGGL(cfg_euler_blend_kernel, dim3(grid_for((int64_t)C * F * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
-                     tok_uncond, tok_cond, ldt, tok0, guidance, dt, latents, known, mask, C, F, H, W, (float*)nullptr);
+  launch_cfg_euler_blend(tok_uncond, tok_cond, ldt, tok0, guidance, dt, latents, known, mask, C, F, H, W, nullptr, (hipStream_t)stream);
   return flexam_check_launch("flexam_cfg_euler_blend");
 }
 
@@ -722,9 +812,7 @@ extern "C" int flexam_cfg_velocity(const float* tok_uncond, const float* tok_con
                                    int C, int F, int H, int W, void* stream) {
   FX_REQUIRE(tok_uncond && v, FLEXAM_E_ARG, "cfg_velocity: null pointer");
   FX_REQUIRE(H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "cfg_velocity: H, W must be even");
-  hipLaunchKernelGGL(cfg_euler_blend_kernel, dim3(grid_for((int64_t)C * F * H * W, 256)), dim3(256), 0, (hipStream_t)stream,
-                     tok_uncond, tok_cond, ldt, tok0, guidance, 0.f, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, C, F,
-                     H, W, v);
+  launch_cfg_euler_blend(tok_uncond, tok_cond, ldt, tok0, guidance, 0.f, nullptr, nullptr, nullptr, C, F, H, W, v, (hipStream_t)stream);
   return flexam_check_launch("flexam_cfg_velocity");
 }
 

@@ -161,6 +161,12 @@ class DiTEngine:
         self.sp_mode = mode if (mode == "allgather" or self.nh % max(sp_size, 1) == 0) else "allgather"
         # local-chunk-first attention under the K|V all-gather (0: wait for the gather, then one attention call)
         self.sp_overlap = os.environ.get("FLEXAM_SP_OVERLAP", "1") != "0"
+        # the K|V gather is cut into `sp_pieces` groups of heads, one collective each: the attention of a group starts when ITS
+        # piece has landed, the later pieces travel underneath it (1: one gather per block and CFG row)
+        pieces = int(os.environ.get("FLEXAM_SP_PIECES", "2"))
+        if pieces < 1 or self.nh % pieces:
+            raise ValueError(f"FLEXAM_SP_PIECES={pieces}: must divide the {self.nh} heads")
+        self.sp_pieces = pieces if sp_size > 1 else 1
         self.world_group = world_group if cfg_size > 1 else sp_group
         self.world_size = world_size if world_size is not None else sp_size
         self.cfg_size, self.cfg_row = cfg_size, cfg_row
@@ -303,8 +309,9 @@ class DiTEngine:
         s = hip.sinusoid_embed(t_rows.to(self.device, F32), self.freq_dim)
         e = torch.empty(R, d, device=self.device, dtype=F32)
         e0 = torch.empty(R, 6 * d, device=self.device, dtype=F32)
-        for i in range(0, R, 8):
-            sl = slice(i, min(i + 8, R))
+        step = 8 if R <= 8 else 32                 # rows per pass over the 113 MB projection weight (results do not depend on it)
+        for i in range(0, R, step):
+            sl = slice(i, min(i + step, R))
             e1 = hip.small_linear(s[sl], *self.time[0])
             hip.small_linear(e1, *self.time[1], silu_in=True, out=e[sl])
             hip.small_linear(e[sl], *self.time[2], silu_in=True, out=e0[sl])
@@ -402,7 +409,7 @@ class DiTEngine:
                 T = tab1[0]
             else:
                 T = tab[i]
-            fp8_here = self.fp8 and sp == 1
+            fp8_here = self.fp8
             if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
                 a8, sa = self._ln_fp8(xres, ws, hbuf, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
             else:
@@ -410,21 +417,17 @@ class DiTEngine:
             if sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
                 # returned blocks in place (flexam_amd/dist.py)
-                hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
+                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None), qkv)
                 a_o, koff_o = self._ulysses_attention(qkv, p, B, lc, tok0)
                 hip.gemm_gate_residual(a_o, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb, a_koff=koff_o)
             elif sp > 1:
                 # K|V projection + K norm/RoPE first, written straight into the send buffer; their all-gather (RCCL over xGMI)
                 # runs under the Q projection, the Q norm/RoPE and the attention to the LOCAL chunk
-                hip.gemm(hbuf, p["wqkv"][d:], p["bqkv"][d:], out=qkv[:, d:])
-                self._allgather_attention(qkv, hbuf, p, ao4, q4, B, lc, tok0)
+                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(d, None), qkv[:, d:])
+                self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0)
                 hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             else:
-                if fp8_here:
-                    w8 = self._fp8_w[i]
-                    hip.gemm_fp8(a8, sa, w8["wqkv"], w8["s_wqkv"], p["bqkv"], out=qkv)
-                else:
-                    hip.gemm(hbuf, p["wqkv"], p["bqkv"], out=qkv)
+                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None), qkv)
                 hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
                                  tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
                 hip.attn_fwd(q4, k4, v4, out=ao4, prescaled=True)
@@ -554,48 +557,65 @@ class DiTEngine:
                 best, best_cost = s, cost
         return best
 
-    def _allgather_attention(self, qkv, hbuf, p, ao4, q4, B, lc, tok0):
+    def _proj(self, hbuf, a8sa, layer, p, wname, bname, rows, out):
+        """out = h @ W[rows]^T + b[rows]: bf16 MFMA, or fp8 MFMA on the row-quantised h (`a8sa` = (bytes, row scales)) with the
+        per-channel scales of the same weight rows."""
+        if a8sa:
+            w8 = self._fp8_w[layer]
+            return hip.gemm_fp8(a8sa[0], a8sa[1], w8[wname][rows], w8["s_" + wname][rows], p[bname][rows], out=out)
+        return hip.gemm(hbuf, p[wname][rows], p[bname][rows], out=out)
+
+    def _allgather_attention(self, qkv, hbuf, a8sa, layer, p, ao4, q4, B, lc, tok0):
         """K|V of this rank's tokens are in qkv[:, C:] (projected, not yet normed).  The RMSNorm+RoPE launch writes K (normed,
-        rotated) and V into the send buffer [B, lc, 2C]; one all-gather per CFG row assembles [B, L, 2C] in token order (no
-        re-layout pass); while it is in flight: Q projection, Q norm/RoPE, attention of the local queries to the LOCAL chunk
-        (partial softmax); then the chunks before / after the local one; one merge (reference call sites of the missing
-        exchange: wan_transformer3d_FlexAM.py:801-815, 970-975)."""
+        rotated) and V into the send buffer, cut into `sp_pieces` groups of heads: [G, B, lc, 2*C/G].  One all-gather per group
+        and CFG row assembles [G, B, L, 2*C/G] in token order (the rank-major concatenation IS the token order: no re-layout
+        pass), all of them issued at once.  Underneath: Q projection, Q norm/RoPE, then the heads of group 0 attend to the LOCAL
+        chunk (partial softmax, straight from the send buffer), to the chunks before / after it once piece 0 has landed, one
+        merge; the heads of group g > 0 run one ordinary attention call on their gathered piece, which travelled while group
+        g - 1 computed.  A peer chunk cannot arrive faster than its one xGMI link delivers it, and the chunks of one gather all
+        land together; cutting along the heads gives pieces that are complete work for part of the kernel, so all links stay
+        busy in every phase (reference call sites of the missing exchange: wan_transformer3d_FlexAM.py:801-815, 970-975)."""
         import torch.distributed as dist
-        sp, nh, hd, d, dev, rank = self.sp_size, self.nh, self.hd, self.dim, self.device, self.sp_rank
+        sp, nh, hd, d, dev = self.sp_size, self.nh, self.hd, self.dim, self.device
         ws = self._ws[(B, lc)]
         L = sp * lc
+        G = self.sp_pieces
+        cb, hg = d // G, nh // G
         if "kv_send" not in ws:
-            ws["kv_send"] = torch.empty(B, lc, 2 * d, device=dev, dtype=BF16)
-            ws["kv_cat"] = torch.empty(B, L, 2 * d, device=dev, dtype=BF16)
-            units = B * nh * ((lc + 255) // 256)
+            ws["kv_send"] = torch.empty(G, B, lc, 2 * cb, device=dev, dtype=BF16)
+            ws["kv_cat"] = torch.empty(G, B, L, 2 * cb, device=dev, dtype=BF16)
+            units = B * hg * ((lc + 255) // 256)
             ranges = [lc, tok0, L - tok0 - lc]                                            # local, before, after
             ws["kv_splits"] = [self._splits_for(units, (n + 63) // 64) if n else 0 for n in ranges]
-            ws["kv_part"] = hip.attn_partial_workspace(B, nh, lc, sum(hip.attn_effective_splits(n, s) for n, s in zip(ranges, ws["kv_splits"]) if n), dev)
+            ws["kv_part"] = hip.attn_partial_workspace(B, hg, lc, sum(hip.attn_effective_splits(n, s) for n, s in zip(ranges, ws["kv_splits"]) if n), dev)
         cd = self.cond
         send, cat = ws["kv_send"], ws["kv_cat"]
         flat = send.view(-1)
-        hip.rmsnorm_rope_scatter(None, None, qkv[:, d:2 * d], p["nk"], qkv[:, 2 * d:], None, flat, flat[d:], ld_out=2 * d, out_bs=lc * 2 * d,
-                                 col_block=d, block_stride=0, eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc,
-                                 token_offset=tok0, head_dim=hd)
-        works = [dist.all_gather_into_tensor(cat[b], send[b], group=self.sp_group, async_op=True) for b in range(B)]
-        hip.gemm(hbuf, p["wqkv"][:d], p["bqkv"][:d], out=qkv[:, 0:d])
+        hip.rmsnorm_rope_scatter(None, None, qkv[:, d:2 * d], p["nk"], qkv[:, 2 * d:], None, flat, flat[cb:], ld_out=2 * cb, out_bs=lc * 2 * cb,
+                                 col_block=cb, block_stride=B * lc * 2 * cb, eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                                 tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
+        works = [[dist.all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=True) for b in range(B)] for g in range(G)]
+        self._proj(hbuf, a8sa, layer, p, "wqkv", "bqkv", slice(0, d), qkv[:, 0:d])
         hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0,
                          head_dim=hd)
-        heads = lambda t: t.unflatten(2, (nh, hd))
-        if not self.sp_overlap:
-            for w in works:
+        heads = lambda t: t.unflatten(2, (hg, hd))
+        for g in range(G):
+            qg, og = q4[:, :, g * hg:(g + 1) * hg], ao4[:, :, g * hg:(g + 1) * hg]
+            kc, vc = cat[g, :, :, 0:cb], cat[g, :, :, cb:]
+            if g > 0 or not self.sp_overlap:
+                for w in works[g]:
+                    w.wait()
+                hip.attn_fwd(qg, heads(kc), heads(vc), out=og, prescaled=True)
+                continue
+            s_loc, s_before, s_after = ws["kv_splits"]
+            n = hip.attn_fwd_partial(qg, heads(send[0, :, :, 0:cb]), heads(send[0, :, :, cb:]), ws["kv_part"], 0, s_loc, prescaled=True)
+            for w in works[0]:
                 w.wait()
-            hip.attn_fwd(q4, heads(cat[:, :, 0:d]), heads(cat[:, :, d:]), out=ao4, prescaled=True)
-            return
-        s_loc, s_before, s_after = ws["kv_splits"]
-        n = hip.attn_fwd_partial(q4, heads(send[:, :, 0:d]), heads(send[:, :, d:]), ws["kv_part"], 0, s_loc, prescaled=True)
-        for w in works:
-            w.wait()
-        if tok0 > 0:
-            n += hip.attn_fwd_partial(q4, heads(cat[:, :tok0, 0:d]), heads(cat[:, :tok0, d:]), ws["kv_part"], n, s_before, prescaled=True)
-        if tok0 + lc < L:
-            n += hip.attn_fwd_partial(q4, heads(cat[:, tok0 + lc:, 0:d]), heads(cat[:, tok0 + lc:, d:]), ws["kv_part"], n, s_after, prescaled=True)
-        hip.attn_merge(ao4, ws["kv_part"], n, prescaled=True)
+            if tok0 > 0:
+                n += hip.attn_fwd_partial(qg, heads(kc[:, :tok0]), heads(vc[:, :tok0]), ws["kv_part"], n, s_before, prescaled=True)
+            if tok0 + lc < L:
+                n += hip.attn_fwd_partial(qg, heads(kc[:, tok0 + lc:]), heads(vc[:, tok0 + lc:]), ws["kv_part"], n, s_after, prescaled=True)
+            hip.attn_merge(og, ws["kv_part"], n, prescaled=True)
 
     def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
         """All-gather of the head output [B, Lc, 192] -> [B, L, 192] (the reference's one collective,

@@ -128,16 +128,28 @@ def device_check():
 # ----------------------------------------------------------------------------- GEMM
 _GEMM_WS = {}
 GEMM_WS_BYTES = 256 * 256 * 256 * 4                 # FLEXAM_GEMM_WS_BYTES
+WS_CACHE_SLOTS = 8                                  # (device, stream) pairs that keep their scratch; older ones are dropped
+
+
+def _ws_slot(cache: dict, key, make):
+    """Scratch per (device, stream) -- launches that can run concurrently never share it -- in a small LRU: a program that
+    creates streams per call does not grow memory without bound.  Dropping an entry waits for its device first (rare: the
+    9th distinct stream), so no kernel still writes the slabs when the allocator hands them out again."""
+    hit = cache.pop(key, None)
+    if hit is None:
+        while len(cache) >= WS_CACHE_SLOTS:
+            old = next(iter(cache))
+            torch.cuda.synchronize(old[0])
+            del cache[old]
+        hit = make()
+    cache[key] = hit                                # re-inserted last = most recently used
+    return hit
 
 
 def _gemm_workspace(device, stream: int):
-    """Tail split-K scratch (64 MiB of partial-sum slabs) handed to every GEMM call: one buffer per (device, stream),
-    so launches that can run concurrently never share slabs."""
+    """Tail split-K scratch (64 MiB of partial-sum slabs) handed to every GEMM call, per (device, stream)."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream)
-    buf = _GEMM_WS.get(key)
-    if buf is None:
-        buf = _GEMM_WS[key] = torch.empty(GEMM_WS_BYTES, device=device, dtype=torch.uint8)
-    return buf
+    return _ws_slot(_GEMM_WS, key, lambda: torch.empty(GEMM_WS_BYTES, device=device, dtype=torch.uint8))
 
 
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=None, m=None, k=None):
@@ -277,10 +289,12 @@ def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_u
         return out
     n = units - from_unit
     st = _stream()
-    slot, key = (q.device, st), (S, n)
+    slot, key = (q.device.index if q.device.index is not None else torch.cuda.current_device(), st), (S, n)
     if _ATTN_WS.get(slot, (None,))[0] != key:   # per-shape scratch per (device, stream), reused across launches (stream-ordered)
-        _ATTN_WS[slot] = (key, torch.empty(S, n, 256, D, device=q.device, dtype=F32), torch.empty(S, n, 256, 2, device=q.device, dtype=F32))
-    _, ws_o, ws_ml = _ATTN_WS[slot]
+        _ATTN_WS.pop(slot, None)
+        _ws_slot(_ATTN_WS, slot, lambda: (key, torch.empty(S, n, 256, D, device=q.device, dtype=F32),
+                                          torch.empty(S, n, 256, 2, device=q.device, dtype=F32)))
+    _, ws_o, ws_ml = _ws_slot(_ATTN_WS, slot, None)
     _check(lib().flexam_attn_fwd_splitkv(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1),
                                          _ptr(v, BF16), v.stride(0), v.stride(1), _ptr(out, BF16), out.stride(0), out.stride(1),
                                          B, H, Lq, Lk, D, scale, S, from_unit, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()),
@@ -404,7 +418,7 @@ def mod_table(mod, e, out, rows_per_batch, scale_mask, mdens=None, dens=None, de
 
 
 def small_linear(x, w, b=None, silu_in=False, out=None):
-    """fp32 y[M,N] = silu?(x[M,K]) @ w[N,K]^T + b, M <= 8; w bf16 or fp32."""
+    """fp32 y[M,N] = silu?(x[M,K]) @ w[N,K]^T + b, M <= 32; w bf16 or fp32 (each output sums in the same order whatever M is)."""
     M, K, ldx = _rows(x)
     N, wk, ldw = _rows(w)
     if wk != K:
@@ -462,12 +476,19 @@ def axpby(y, a, x, b):
 
 
 def checksum(t: torch.Tensor):
-    """Content fingerprint (two 64-bit sums over the raw words) of a device tensor; synchronises (host logic only)."""
-    t = t.contiguous()
-    out = torch.zeros(2, device=t.device, dtype=I64)
-    _check(lib().flexam_checksum(_ptr(t), t.numel() * t.element_size(), _ptr(out), _stream()), "flexam_checksum")
-    a, b = out.tolist()
-    return a, b
+    """Content fingerprint (two 64-bit sums of per-(index, word) hashes) of a device tensor; synchronises (host logic only)."""
+    return checksums([t])[0]
+
+
+def checksums(tensors):
+    """Fingerprints of several device tensors with ONE readback: every launch adds into its own slot of one buffer."""
+    ts = [t.contiguous() for t in tensors]
+    if not ts:
+        return []
+    out = torch.zeros(len(ts), 2, device=ts[0].device, dtype=I64)
+    for i, t in enumerate(ts):
+        _check(lib().flexam_checksum(_ptr(t), t.numel() * t.element_size(), out[i].data_ptr(), _stream()), "flexam_checksum")
+    return [tuple(r) for r in out.tolist()]
 
 
 def cfg_velocity(tok_uncond, tok_cond, tok0, guidance, out):

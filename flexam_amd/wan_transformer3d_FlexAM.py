@@ -408,6 +408,7 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         self._engine: Optional[DiTEngine] = None
         self._engine_sig = None
         self._cond_key = None
+        self._cond_ident = None
         self.init_weights()
 
     # ------------------------------------------------------------------ parameters
@@ -471,6 +472,7 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         (`param.data` arithmetic on fp32 / bias / norm parameters; bf16 weight matrices are shared with the engine, not copied)."""
         self._engine = None
         self._cond_key = None
+        self._cond_ident = None
 
     def engine(self) -> DiTEngine:
         if self._engine is not None and self._engine_sig != self._signature():
@@ -487,13 +489,21 @@ class WanTransformer3DModel_FlexAM(nn.Module):
 
     def _conditioning_key(self, context, y, full_ref, additional_control, density, latent_shape):
         """Content key of the step-invariant inputs.  The reference sampler rebuilds them with torch.cat on every step
-        (PIPE.py:850-886), so identity says nothing; a checksum pass over ~120 MB costs microseconds against the cnn-block, the
-        text MLP and 30 cross-K/V GEMMs it saves."""
+        (PIPE.py:850-886), so identity says nothing about a change -- but identity DOES prove "unchanged": when every tensor is the
+        very object of the last call (same storage, same version counter) the key of that call is reused with no device work.
+        Otherwise one checksum launch per tensor into one buffer and ONE readback (~120 MB hashed in microseconds, against the
+        cnn-block, the text MLP and 30 cross-K/V GEMMs a hit saves).  The RoPE variant is part of the key: the rotation tables
+        live in the per-clip state."""
         from . import hip
-        parts = [tuple(latent_shape)]
-        for v in (y, full_ref, additional_control, density, *context):
-            parts.append(None if v is None else (tuple(v.shape), str(v.dtype), hip.checksum(v)))
-        return tuple(parts)
+        tensors = [v for v in (y, full_ref, additional_control, density, *context) if v is not None]
+        ident = (tuple(latent_shape), self._riflex, tuple((id(v), v.data_ptr(), v._version, tuple(v.shape), v.dtype) for v in tensors),
+                 tuple(v is None for v in (y, full_ref, additional_control, density)))
+        if self._cond_ident is not None and self._cond_ident[0] == ident:
+            return self._cond_ident[1]
+        sums = hip.checksums(tensors)
+        key = (tuple(latent_shape), self._riflex, ident[3], tuple((tuple(v.shape), str(v.dtype), c) for v, c in zip(tensors, sums)))
+        self._cond_ident = (ident, key, tensors)          # the tensors are kept alive so that id() / data_ptr() cannot be recycled
+        return key
 
     # ------------------------------------------------------------------ feature switches (reference API)
     def enable_teacache(self, coefficients, num_steps: int, rel_l1_thresh: float, num_skip_start_steps: int = 0, offload: bool = True):
@@ -529,15 +539,21 @@ class WanTransformer3DModel_FlexAM(nn.Module):
 
     def enable_riflex(self, k=6, L_test=66, L_test_scale=4.886):
         self._riflex = (k, L_test, L_test_scale)
-        self.freqs = self._rope_angles()
-        if self._engine is not None:
-            self._engine._angles = None
+        self._rope_changed()
 
     def disable_riflex(self):
         self._riflex = None
+        self._rope_changed()
+
+    def _rope_changed(self):
+        """The rotation tables are part of the engine's per-clip state (DiTEngine.set_conditioning): drop it with the angles,
+        or a forward() with unchanged conditioning would keep rotating by the old table."""
         self.freqs = self._rope_angles()
+        self._cond_key = None
+        self._cond_ident = None
         if self._engine is not None:
             self._engine._angles = None
+            self._engine.cond = None
 
     @staticmethod
     def default_cfg_parallel(world: int, num_heads: int, sp_mode: str = "allgather") -> bool:
@@ -706,3 +722,14 @@ class Wan2_2Transformer3DModel_FlexAM(WanTransformer3DModel_FlexAM):
     def __init__(self, *args, **kwargs):
         kwargs.pop("cross_attn_type", None)
         super().__init__(*args, cross_attn_type="cross_attn", **kwargs)
+
+
+# The reference's module-level class names (wan_transformer3d_FlexAM.py:173,192,205,353,381,475): code that imports or
+# isinstance-checks them finds the HIP modules.
+WanRMSNorm = _Norm
+WanLayerNorm = _Norm
+WanSelfAttention = _SelfAttn
+WanCrossAttention = _CrossAttn
+WanAttentionBlock = _Block
+Head = _Head
+WAN_CROSSATTENTION_CLASSES = {"cross_attn": _CrossAttn}       # wan_transformer3d_FlexAM.py:374-378 (the Wan2.2 text-only entry)

@@ -164,8 +164,10 @@ int flexam_rmsnorm_rope_scatter(const void* q_in, int64_t ldq_in, const float* w
 int flexam_mod_table(const float* mod, const float* e, const float* mdens, const float* dens, float* out, int nblk, int R,
                      int nj, int nslot, int C, int rows_per_batch, int scale_mask, int dens_slots, void* stream);
 
-/* y[M,N] = silu_in?(x[M,K]) . W[N,K]^T + b, fp32 math, 1 <= M <= 8, W bf16 or fp32.  The time /
- * density embedding MLPs (forced fp32 in the reference: wan_transformer3d_FlexAM.py:928-955). */
+/* y[M,N] = silu_in?(x[M,K]) . W[N,K]^T + b, fp32 math, 1 <= M <= 32, W bf16 or fp32.  The time /
+ * density embedding MLPs (forced fp32 in the reference: wan_transformer3d_FlexAM.py:928-955).  Every output is summed in the
+ * same order whatever M is (M <= 8: one output per wave; above: four per wave and 32 rows per pass over W, for foreground
+ * masks with many distinct per-token timesteps). */
 int flexam_small_linear_f32(const float* x, int64_t ldx, const void* W, int w_is_bf16, int64_t ldw, const float* b, float* y,
                             int64_t ldy, int M, int N, int K, int silu_in, void* stream);
 

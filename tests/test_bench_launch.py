@@ -1,0 +1,46 @@
+"""`python bench.py --gpus N` as the driver calls it (no torch.distributed.run environment): the parent starts the N ranks
+itself without touching the GPU, forwards rank 0's JSON line and carries the self-check of the multi-rank exchange.
+CPU: the launcher's refusal path.  GPU (one device): two and four ranks share cuda:0 under gloo -- the rank code path RCCL
+drives on a multi-GPU node; such a line is marked invalid as a measurement, its `check` is real."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--frames", "9", "--height", "256", "--width", "256", "--layers", "2", "--steps", "2", "--warmup", "1", "--no-vae", "--no-cpu-baseline",
+         "--no-kernel-timing"]
+
+
+def _run(args, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_launcher_refuses_more_ranks_than_gpus_without_touching_them():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this host has the GPUs: nothing to refuse")
+    r = _run(["--gpus", "2", *SMALL], {"FLEXAM_BENCH_ONE_DEVICE": "0"}, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2 but only" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,env", [(2, {}), (4, {}), (4, {"FLEXAM_CFG_PARALLEL": "0"}), (4, {"FLEXAM_SP_MODE": "ulysses"})])
+def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
+    r = _run(["--gpus", str(world), *SMALL], {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", **env})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == world and res["launch"]["attempt"] == "default" and not res["launch"]["fallback"]
+    chk = res["check"]
+    print(world, env, res["config"]["parallelism"], chk)
+    assert chk["ok"] and chk["ranks_agree"] and chk["ranks"] == world and chk["worst_rank_rel_rms"] <= 1e-2
+    assert "invalid" in res and "code-path validation" in res["invalid"]      # one device / gloo: not a measurement
+    assert res["finite"]

@@ -258,3 +258,59 @@ def test_default_layout_follows_the_exchange_mode():
     assert not M.default_cfg_parallel(4, 24, "ulysses") and not M.default_cfg_parallel(8, 24, "ulysses")
     assert M.default_cfg_parallel(4, 2, "ulysses")                                      # 2 heads do not divide over 4 ranks
     assert not M.default_cfg_parallel(3, 24) and not M.default_cfg_parallel(1, 24)
+
+
+def _head_group_pieces(rank, world):
+    """The K|V gather cut into G head-group pieces (DiTEngine._allgather_attention): send layout [G, B, lc, 2*C/G] (K of the
+    group's heads | V of the group's heads), one all-gather per (piece, CFG row) whose rank-major concatenation is the token
+    order.  Group g's attention needs ONLY piece g -- whatever the other pieces' buffers hold (here: NaN until their own gather
+    is consumed, in reverse order of issue) -- and the groups together equal attention over all heads; within a piece the
+    per-peer chunks are merged from partial softmaxes in EVERY arrival order."""
+    import itertools
+    import math
+    from flexam_amd.dist import chunk_bounds
+    g = torch.Generator().manual_seed(9)
+    B, L, H, D, G = 2, 24, 4, 16, 2
+    hg, cb = H // G, H // G * D
+    q, k, v = (torch.randn(B, L, H, D, generator=g) for _ in range(3))
+    s, e = chunk_bounds(L, rank, world)
+    lc = e - s
+    ql = q[:, s:e]
+    send = torch.empty(G, B, lc, 2 * cb)
+    for gi in range(G):
+        send[gi, :, :, :cb] = k[:, s:e, gi * hg:(gi + 1) * hg].flatten(2)
+        send[gi, :, :, cb:] = v[:, s:e, gi * hg:(gi + 1) * hg].flatten(2)
+    cat = torch.full((G, B, L, 2 * cb), float("nan"))
+    works = [[dist.all_gather_into_tensor(cat[gi, b], send[gi, b], async_op=True) for b in range(B)] for gi in range(G)]
+    want = O.attention(ql, k, v)
+    worst = 0.0
+
+    def partial(qh, keys, vals):
+        sc = torch.einsum("blhd,bmhd->bhlm", qh, keys) / math.sqrt(D) * math.log2(math.e)
+        ref = sc.max(dim=-1).values
+        p = torch.exp2(sc - ref.unsqueeze(-1))
+        return torch.einsum("bhlm,bmhd->blhd", p, vals), ref, p.sum(-1)
+    for gi in reversed(range(G)):                                   # consume the LAST piece first: pieces are independent
+        for w in works[gi]:
+            w.wait()
+        kg = cat[gi, :, :, :cb].unflatten(2, (hg, D))
+        vg = cat[gi, :, :, cb:].unflatten(2, (hg, D))
+        assert torch.equal(kg, k[:, :, gi * hg:(gi + 1) * hg]) and torch.equal(vg, v[:, :, gi * hg:(gi + 1) * hg])
+        qh = ql[:, :, gi * hg:(gi + 1) * hg]
+        got = O.attention(qh, kg, vg)
+        worst = max(worst, float((got - want[:, :, gi * hg:(gi + 1) * hg]).abs().max()))
+        chunks = [chunk_bounds(L, r, world) for r in range(world)]
+        for order in itertools.permutations(range(world)):          # peer chunks in every arrival order
+            parts = [partial(qh, kg[:, chunks[r][0]:chunks[r][1]], vg[:, chunks[r][0]:chunks[r][1]]) for r in order]
+            m = torch.stack([p[1] for p in parts]).max(dim=0).values
+            acc = sum(p[0] * torch.exp2(p[1] - m).permute(0, 2, 1).unsqueeze(-1) for p in parts)
+            l = sum(p[2] * torch.exp2(p[1] - m) for p in parts)
+            merged = acc / l.permute(0, 2, 1).unsqueeze(-1)
+            worst = max(worst, float((merged - want[:, :, gi * hg:(gi + 1) * hg]).abs().max()))
+    return worst
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_head_group_pieces_and_chunk_arrival_orders(world):
+    errs = run_world(_head_group_pieces, world)
+    assert max(errs) < 1e-5, errs

@@ -58,6 +58,32 @@ def test_dit_with_riflex_matches_reference_golden(golden):
     check(m(**case), golden("g4_dit_tokent")["out"], "g4 after disable_riflex")
 
 
+def test_riflex_toggle_between_calls_rebuilds_the_rotation_tables():
+    """The RoPE tables live in the engine's per-clip state, which forward() reuses while the conditioning is unchanged: toggling
+    RIFLEx between two calls with the SAME conditioning must still switch the rotation (r2 advisor finding) -- each result is
+    bit-identical to a fresh model in that state, and identical conditioning without a toggle does not redo the per-clip work."""
+    cfg = dict(O.DIT_TINY)
+    m, _ = build(cfg, 7)
+    case = to_dev(C.dit_case(cfg, 41))
+    base = m(**case).clone()
+    again = m(**case).clone()
+    assert torch.equal(base, again) and m.engine().n_conditioning == 1          # same tensors: identity fast path, no re-run
+    m.enable_riflex(k=2, L_test=3, L_test_scale=1.0)
+    on = m(**case).clone()
+    fresh, _ = build(cfg, 7)
+    fresh.enable_riflex(k=2, L_test=3, L_test_scale=1.0)
+    assert torch.equal(on, fresh(**case)) and not torch.equal(on, base)
+    m.disable_riflex()
+    assert torch.equal(m(**case), base)
+    assert m.engine().n_conditioning == 3
+    # re-created tensors with the same content (the reference sampler's torch.cat per step): content key, still no re-run
+    clone = {k: ([u.clone() for u in v] if isinstance(v, list) else (v.clone() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    assert torch.equal(m(**clone), base) and m.engine().n_conditioning == 3
+    clone["y"][0, 0, 0, 0, 0] += 1.0                                              # one element differs: the key must see it
+    m(**clone)
+    assert m.engine().n_conditioning == 4
+
+
 def test_dit_matches_oracle_other_shape_batch1_and_bf16_weights():
     cfg = dict(O.DIT_TINY, num_layers=3)
     m, sd = build(cfg, 19)

@@ -124,6 +124,36 @@ def test_full_width_one_layer_model_at_config2_shape():
     stats(out, want, "one-layer 5B-width model, 97x512x896 latent")
 
 
+def test_full_width_one_layer_model_foreground_edit_masks_at_config2_shape():
+    """BASELINE configs[3] at full size: the per-token timesteps of a foreground_edit clip whose mask is NOT pinned
+    (bench.py --mask blob-open: the drifting disc also covers frame 0, so PIPE.py:688-690 keeps the trilinear latent mask and
+    `mask[::2, ::2] * t` (PIPE.py:891-898) has soft-edge values: a dozen distinct timesteps per sample instead of two), rounded
+    to bf16 like the reference's `mask.to(weight_dtype) * t`.  One-layer 5B-width model on the config-2 latent vs the oracle,
+    which embeds every token's timestep the way FX.py:928-944 writes it."""
+    from bench import blob_mask_pixels
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import prepare_masks
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+    cfg = dict(CFG_5B, num_layers=1)
+    sd = C.dit_weights(cfg, 13)
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda:0")
+    case = C.dit_case(cfg, 15, frames=25, h=32, w=56, batch=2, text_lens=(77, 126))
+    _, mask, pinned = prepare_masks(blob_mask_pixels(97, 512, 896, "blob-open"), (1, 48, 25, 32, 56))
+    assert not pinned
+    tok_t = (mask[0, 0, :, ::2, ::2].reshape(-1).to(BF) * torch.tensor(731.5, dtype=BF)).float()
+    n_distinct = int(torch.unique(tok_t).numel())
+    assert 8 <= n_distinct <= 64, n_distinct
+    case["t"] = tok_t.unsqueeze(0).repeat(2, 1)
+    dcase = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    out = m(**dcase)
+    with torch.no_grad():
+        want = O.dit_forward(sd, cfg, **case)
+    stats(out, want, f"one-layer 5B-width model, foreground_edit timesteps ({n_distinct} distinct), 97x512x896 latent")
+
+
 # ----------------------------------------------------------------------------- exact GEMMs at the FFN shapes
 def _checksums_exact(out_dev, a, w, bias_rowsum, what):
     """A single wrong element changes one row sum and one column sum: both are exact in fp64 for integer data."""

@@ -569,3 +569,45 @@ def test_cfg_euler_blend(H):
     x = lat + (-0.0371) * (vu + 6.0 * (vc - vu))
     want = (1 - mask) * known + mask * x
     torch.testing.assert_close(ld.cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_small_linear_many_rows_is_row_batch_independent(H):
+    """Foreground masks with soft edges give hundreds of distinct per-token timesteps: rows are embedded 32 per pass over the weight
+    (4 outputs per wave).  Every output must be BIT-identical to the 8-row instance (same per-lane k order, same wave reduction),
+    so a timestep's embedding does not depend on how many other timesteps the step has."""
+    g = torch.Generator().manual_seed(231)
+    x = torch.randn(29, 256, generator=g)
+    for wdt, n in ((torch.float32, 771), (BF, 768)):                     # 771: the last wave's 4 outputs run past N
+        w = (torch.randn(n, 256, generator=g) / 16).to(wdt)
+        b = torch.randn(n, generator=g)
+        wide = H.small_linear(x.to(dev()), w.to(dev()), b.to(dev()), silu_in=True)
+        torch.testing.assert_close(wide.cpu(), F.linear(F.silu(x), w.float(), b), rtol=1e-5, atol=1e-5)
+        narrow = torch.cat([H.small_linear(x[i:i + 8].to(dev()), w.to(dev()), b.to(dev()), silu_in=True) for i in range(0, 29, 8)])
+        assert torch.equal(wide, narrow)
+
+
+@pytest.mark.parametrize("c,f,h,w,tok0,cfg", [(48, 25, 32, 56, 448, True), (48, 3, 8, 12, 7, False), (16, 2, 4, 6, 0, True)])
+def test_cfg_euler_blend_tiled_and_gather_forms_agree(H, c, f, h, w, tok0, cfg):
+    """The LDS-tiled form (token rows read once, 16 B per lane) against the oracle at the config-2 latent shape, and against the
+    gather form the library falls back to when the token rows are not 16-byte aligned (bit-identical: same arithmetic per element)."""
+    from oracle import dit as O
+    g = torch.Generator().manual_seed(26)
+    n = f * (h // 2) * (w // 2)
+    tu, tc = torch.randn(tok0 + n, 4 * c, generator=g), torch.randn(tok0 + n, 4 * c, generator=g)
+    lat, known = torch.randn(c, f, h, w, generator=g), torch.randn(c, f, h, w, generator=g)
+    mask = torch.rand(f, h, w, generator=g)
+    mask[0] = 0
+    ld = lat.clone().to(dev())
+    H.cfg_euler_blend(tu.to(dev()), tc.to(dev()) if cfg else None, tok0, 6.0, -0.0371, ld, known.to(dev()), mask.to(dev()))
+    vu = O.unpatchify(tu[tok0:], (f, h // 2, w // 2), (1, 2, 2), c)
+    v = vu + 6.0 * (O.unpatchify(tc[tok0:], (f, h // 2, w // 2), (1, 2, 2), c) - vu) if cfg else vu
+    want = (1 - mask) * known + mask * (lat + (-0.0371) * v)
+    torch.testing.assert_close(ld.cpu(), want, rtol=1e-5, atol=1e-5)
+    # misaligned token rows (row pitch 4C + 1 floats) take the gather kernel
+    pad = lambda t: torch.cat([t, torch.zeros(t.shape[0], 1)], dim=1).to(dev())[:, :4 * c]
+    ld2 = lat.clone().to(dev())
+    H.cfg_euler_blend(pad(tu), pad(tc) if cfg else None, tok0, 6.0, -0.0371, ld2, known.to(dev()), mask.to(dev()))
+    assert torch.equal(ld, ld2)
+    vel = torch.empty(c, f, h, w, device=dev())
+    H.cfg_velocity(tu.to(dev()), tc.to(dev()) if cfg else None, tok0, 6.0, vel)
+    torch.testing.assert_close(vel.cpu(), v, rtol=1e-6, atol=1e-6)

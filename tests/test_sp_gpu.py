@@ -60,15 +60,18 @@ def _worker(rank, world, port, ret, cfg_parallel, wide=False, backend="gloo"):
 @pytest.mark.parametrize("world,cfg_parallel,mode", [(2, False, "ulysses"), (2, False, "allgather"), (2, False, "allgather-wait"),
                                                      (2, True, "allgather"), (4, True, "ulysses"), (4, True, "allgather"),
                                                      (4, False, "allgather"), (4, False, "allgather-wait"), (4, None, "allgather"),
-                                                     (2, None, "allgather")])
+                                                     (2, None, "allgather"), (2, False, "allgather-p1"), (4, False, "allgather-p1"),
+                                                     (4, True, "allgather-p1-wait")])
 def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel, mode, monkeypatch):
     """(2, False): pure sequence parallel (CFG pair batched, B = 2 per rank); (2, True): CFG-parallel, no per-block traffic;
     (4, True): 2 CFG rows x 2 token chunks -- what the default (None) picks at 4 and 8 GPUs, while two ranks default to the
     CFG split; (4, False): four token chunks, CFG pair batched (ranks 1, 2 have remote chunks on both sides of theirs).
     mode: the exchange around self-attention -- "allgather" (K|V all-gather with local-chunk-first attention, the default),
-    "allgather-wait" (the same gather, one attention call after it: FLEXAM_SP_OVERLAP=0) or "ulysses" (all-to-all over heads)."""
+    "allgather-wait" (the same gather, one attention call after it: FLEXAM_SP_OVERLAP=0) or "ulysses" (all-to-all over heads);
+    "-p1": the gather in ONE piece (FLEXAM_SP_PIECES=1) instead of the default two head-group pieces."""
     monkeypatch.setenv("FLEXAM_SP_MODE", mode.split("-")[0])             # inherited by the spawned ranks
     monkeypatch.setenv("FLEXAM_SP_OVERLAP", "0" if mode.endswith("-wait") else "1")
+    monkeypatch.setenv("FLEXAM_SP_PIECES", "1" if "-p1" in mode else "2")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

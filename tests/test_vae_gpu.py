@@ -110,3 +110,27 @@ def test_vae_row_band_decode_is_exact(world):
     torch.testing.assert_close(torch.cat(bands, dim=2), full, rtol=0, atol=0)
     cut, a, b, lo, hi, sc = eng.stripe_plan(8, 1, world)
     assert (cut, sc) == (2, 4) and b - a < 32 or world == 2          # bands are narrower than the frame once world > 2
+
+
+@pytest.mark.parametrize("frames", [9, 12])
+def test_vae_decode_ring_wraps_are_consumed(frames, monkeypatch):
+    """The causal convs keep their input frames in a ring of 4 chunks; the wrap copy fires after chunk 3, 7, ... and the chunk
+    AFTER a wrap reads the copied history.  9 latent frames = chunks 0..8 (two wraps consumed, first chunk of 1 frame so the
+    window start is de-aligned like the 25-chunk config-2 decode); 12 = three wraps.  Against the fp32 oracle, and the ring
+    must not change a bit: FLEXAM_VAE_RING = 1 (copy after every chunk, the r1 form) decodes the identical video."""
+    import flexam_amd.wan_vae3_8 as V
+    vae, sd = build(seed=83)
+    z = C.vae_case(seed=84, frames=frames, h=2, w=4)
+    want = OV.vae_decode(sd, z, C.VAE_SMALL["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
+    assert V._Conv.RING == 4
+    out = vae.decode(z.cuda()).sample
+    assert out.shape == (1, 3, 4 * (frames - 1) + 1, 32, 64)
+    check(out, want, f"vae decode {frames} chunks (ring of 4)")
+    again = vae.decode(z.cuda()).sample                       # second call starts from a reset ring
+    torch.testing.assert_close(out, again, rtol=0, atol=0)
+    monkeypatch.setattr(V._Conv, "RING", 1)
+    vae1, _ = build(seed=83)
+    out1 = vae1.decode(z.cuda()).sample
+    torch.testing.assert_close(out, out1, rtol=0, atol=0)
+    # last frames alone: an error in a consumed wrap would show there even if the clip-level PSNR hid it
+    check(out[:, :, -8:], want[:, :, -8:], "last two chunks")
