@@ -73,3 +73,13 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   for (int i = 0; i < NT / 64; ++i) t += red[i];
   return t;
 }
+
+// The lane id, recomputed where it is needed (2 VALU instructions) instead of kept: code behind the K loop (the next unit's staging
+// offsets, the epilogue's addresses) otherwise keeps threadIdx.x / the lane id alive ACROSS the loop, where all 256 registers
+// are taken: hipcc spills them and reloads them in front of the epilogue with an s_waitcnt vmcnt(0) that also drains the next
+// unit's two prefetched K blocks.  `volatile`: not hoisted, not merged with another copy.
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}

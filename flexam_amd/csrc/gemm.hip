@@ -34,6 +34,7 @@
 namespace {
 
 constexpr int BN = 256, BK = 64;
+constexpr int GEMM_STAGGER_DEFAULT = 0;    // gate-residual launches (see the kernel top); FLEXAM_GEMM_STAGGER overrides for every epilogue
 constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB per operand tile (A: up to 256 rows)
 
 struct GemmParams {
@@ -57,6 +58,7 @@ struct GemmParams {
   // (gemm_splitk_finish_kernel) adds the slices up in slice order and runs the epilogue
   int units, split_full, split_s;
   float* ws;
+  int stagger;             // start-up delay of workgroup class (blockIdx / 8) % 4 in units of ~1 us (0 = none): de-phases the epilogues of the persistent workgroups
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -113,9 +115,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][STG_WAVE] of epilogue staging
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wave;                                 // asm: an SGPR value hipcc keeps (or parks in a VGPR lane) instead of re-deriving it from a
+  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(wave) : "v"(tid >> 6));   // spilled copy of threadIdx.x in front of every use
   const int wm = wave / WNW, wn = wave % WNW;
 
+  // All persistent workgroups run tiles of the same length, so without this they reach their epilogues together: every CU then
+  // waits on HBM for its tile's X rows at 1/256 of the chip's bandwidth while its matrix pipe idles.  A one-off start-up offset
+  // of a fraction of the epilogue's length per class spreads the epilogues of an XCD's workgroups over time.
+  if (p.stagger > 0) {
+    const int d = ((blockIdx.x >> 3) & 3) * p.stagger;
+    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(32);
+  }
   // ---- persistent workgroups over an XCD-aware, grouped tile order: workgroup w lives on XCD w & 7 (round-robin
   // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
   // stride gridDim/8, so the tiles resident on an XCD at any time are neighbours in the list (shared A / W panels in
@@ -151,10 +161,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   uint32_t a_off[PA], w_off[PW];
   const char *a_tile, *w_tile;
   auto stage_setup = [&](int m0, int n0) {
+    const int ts = (wave << 6) | fresh_lane();          // thread id, rebuilt (see fresh_lane)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = i * 64 + (tid >> 3);
-      const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+      const int row = i * 64 + (ts >> 3);
+      const int chunk = (ts & 7) ^ ((row >> 1) & 7);
       if (i < PA) a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);   // edge tiles re-read their last row
       if (i < PW) w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
     }
@@ -163,12 +174,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   };
 
   // ---- fragment read offsets (bytes inside a tile): row = base16 + (lane&15), chunk = (lane>>4) + 4*ks
-  // 16x16x32: row lane%16, 16-byte chunk lane/16 of a 32-deep K half; 32x32x16: row lane%32, chunk lane/32 of a 16-deep K step
-  const int sw = ((lane & (RT - 1)) >> 1) & 7;
+  // 16x16x32: row lane%16, 16-byte chunk lane/16 of a 32-deep K half; 32x32x16: row lane%32, chunk lane/32 of a 16-deep K step.
+  // Rebuilt at the top of every unit from a fresh lane id: alive in the K loop only, not across the epilogue (where they were
+  // spilled and came back behind a vmcnt(0) that drained the epilogue's stores in front of the next K loop).
   int frag_off[M32 ? 4 : 2];
+  auto frag_setup = [&]() {
+    const int lf = fresh_lane();
+    const int sw = ((lf & (RT - 1)) >> 1) & 7;
 #pragma unroll
-  for (int ks = 0; ks < (M32 ? 4 : 2); ++ks)
-    frag_off[ks] = (lane & (RT - 1)) * 128 + ((((M32 ? 2 * ks + (lane >> 5) : 4 * ks + (lane >> 4))) ^ sw) << 4);
+    for (int ks = 0; ks < (M32 ? 4 : 2); ++ks)
+      frag_off[ks] = (lf & (RT - 1)) * 128 + ((((M32 ? 2 * ks + (lf >> 5) : 4 * ks + (lf >> 4))) ^ sw) << 4);
+  };
   bool staged = false;          // K blocks 0 and 1 of the coming unit are already on their way into the two LDS buffers
   bool pend = false;            // ... and exactly PEND stores of the last epilogue were issued by this wave after them
   constexpr int PEND = (EPI == EPI_GATE_RESIDUAL ? 4 : 2) * MT;
@@ -308,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     if (i < PA) asm volatile("" : "+v"(a_off[i]));
     if (i < PW) asm volatile("" : "+v"(w_off[i]));
   }
+  frag_setup();
 #pragma unroll
   for (int g = 0; g < (NF + PER - 1) / PER; ++g) ld2(smem, 0, g, f0);
 
@@ -371,8 +388,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // reducing workgroup read zeros instead of another slice's sums: profiles/r2_splitk_handoff_bug.txt.)
   if constexpr (TAIL) {
     constexpr int SLAB = 256 * BN;                     // floats per slab (every tile shape fits); 16-byte element of (row tile t, unit v) at ((t*NV+v)*512 + tid)*4
-    int te = tid;                                      // opaque copy (see `le` below): slab addresses stay out of the K loop's registers
-    asm volatile("" : "+v"(te));
+    const int te = (wave << 6) | fresh_lane();         // rebuilt (see fresh_lane): slab addresses stay out of the K loop's registers
     const int tr = tile - p.split_full;
     float* slab = p.ws + ((int64_t)tr * ns + slice) * SLAB;
 #pragma unroll
@@ -385,8 +401,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   if constexpr (!TAIL) {
 
   // ---- epilogue: lane holds C[m = .. + RT*t + lane%RT][n = .. + 4*NG*v + 4*(lane/RT) + 0..3] per (row tile t, unit v)
-  int le = lane;                     // opaque copy of the lane id: the epilogue's per-lane address arithmetic must not be hoisted
-  asm volatile("" : "+v"(le));       // out of the tile loop, where it would hold registers across the K loop (spills into it)
+  const int le = fresh_lane();       // not the kernel's `lane`: the epilogue's per-lane address arithmetic must not be hoisted out of
+                                     // the tile loop, nor keep the lane id alive across the K loop (spills, see fresh_lane)
   const int mrow = m0 + wm * (16 * MT) + (le & (RT - 1));
   const int ncol = n0 + wn * (16 * NTW) + (le / RT) * 4;
   f32x4 bias[NV];
@@ -738,6 +754,10 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
     const char* g = getenv("FLEXAM_GEMM_GM");
     p.gm = g ? atoi(g) : 4;                  // 4 tile-rows x (32 / 4) tile-columns resident per XCD measured best (profiles/r1e notes)
     if (p.gm < 1) p.gm = 4;
+  }
+  {
+    const char* st = getenv("FLEXAM_GEMM_STAGGER");      // read per call: tools/ab_stagger.py flips it inside one process
+    p.stagger = st ? atoi(st) : (EPI == EPI_GATE_RESIDUAL ? GEMM_STAGGER_DEFAULT : 0);
   }
 #ifdef FLEXAM_GEMM_ABLATE
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
   constexpr int H0 = (MT + 1) / 2, H1 = MT - H0;      // m-tiles of phase A / phase B
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wave;                                 // asm: kept as an SGPR value, not re-derived from a spilled copy of threadIdx.x (gemm.hip, fresh_lane)
+  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(wave) : "v"(tid >> 6));
   const int wm = wave >> 2, wn = wave & 3;
 
   const int nwg = p.units;
@@ -90,10 +90,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
   uint32_t a_off[PA], w_off[4];
   const char *a_tile, *w_tile;
   auto stage_setup = [&](int m0, int n0) {
+    const int ts = (wave << 6) | fresh_lane();          // thread id, rebuilt: nothing per-lane stays alive across the K loop
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = i * 64 + (tid >> 3);
-      const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+      const int row = i * 64 + (ts >> 3);
+      const int chunk = (ts & 7) ^ ((row >> 1) & 7);
       if (i < PA) a_off[i] = (uint32_t)((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 16);
       w_off[i] = (uint32_t)((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 16);
     }
@@ -101,10 +102,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
     w_tile = (const char*)(p.W + (int64_t)n0 * p.ldw);
   };
   // fragment read offsets: row = lane%16, 16-byte chunks 2g and 2g+1 (g = lane/16) of the 128-byte row segment, swizzled like the staging
-  const int sw = ((lane & 15) >> 1) & 7;
+  // (rebuilt at the top of every unit from a fresh lane id: alive in the K loop only, not across the epilogue)
   int frag_off[2];
+  auto frag_setup = [&]() {
+    const int lf = fresh_lane();
+    const int sw = ((lf & 15) >> 1) & 7;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) frag_off[c] = (lane & 15) * 128 + (((2 * (lane >> 4) + c) ^ sw) << 4);
+    for (int c = 0; c < 2; ++c) frag_off[c] = (lf & 15) * 128 + (((2 * (lf >> 4) + c) ^ sw) << 4);
+  };
   bool staged = false, pend = false;
   constexpr int PEND = (EPI == EPI_GATE_RESIDUAL ? 4 : 2) * MT;
   const int nk = p.K / BKB;
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
     if (i < PA) asm volatile("" : "+v"(a_off[i]));
     asm volatile("" : "+v"(w_off[i]));
   }
+  frag_setup();
 #pragma unroll
   for (int j = 0; j < NTW; ++j) frag(smem, j, wf[j]);
 #pragma unroll
@@ -231,25 +237,28 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
   }
 
   // ---- epilogue: lane holds C[m = .. + 16 t + lane%16][n = .. + 16 v + 4 (lane/16) + 0..3] per (m-tile t, n-tile v)
-  int le = lane;
-  asm volatile("" : "+v"(le));
+  const int le = fresh_lane();
   const int mrow = m0 + wm * (16 * MT) + (le & 15);
   const int ncol = n0 + wn * (16 * NTW) + (le >> 4) * 4;
-  f32x4 bias[NV], swv[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int n = ncol + v * 16;
-    bias[v] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    swv[v] = n < p.N ? *(const f32x4*)(p.sw + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Per-column bias / weight scale of the wave's 64 columns and the row scales of its 16 MT rows go through 1 KiB of LDS per wave
+  // (written once per tile, read back per (m-tile, n-tile) as one ds_read_b128 / ds_read_b32): held in registers they were 39
+  // values next to 16 MT accumulators and the packed outputs, and the MT = 7 instances spilled 12-32 of them.  A wave's LDS
+  // operations are served in order: no barrier between its writes and its reads.
+  float* cst = (float*)(smem + 4 * TILE_BYTES + 8 * STG_WAVE + wave * 1024);      // [64 bias][64 sw][128 sa]
+  {
+    const int n = n0 + wn * (16 * NTW) + le;
+    cst[le] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    cst[64 + le] = n < p.N ? p.sw[n] : 0.f;
+    const int mr = m0 + wm * (16 * MT) + le;
+    cst[128 + le] = p.sa[min(mr, p.M - 1)];
+    if (16 * MT > 64) cst[192 + le] = p.sa[min(mr + 64, p.M - 1)];
   }
-  float sav[NRT];
-#pragma unroll
-  for (int t = 0; t < NRT; ++t) sav[t] = p.sa[min(mrow + t * 16, p.M - 1)];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(bias[v]), "v"(swv[v]));
-#pragma unroll
-  for (int t = 0; t < NRT; ++t) asm volatile("" ::"v"(sav[t]));
-  auto yv = [&](int t, int v) -> f32x4 { return acc[t][v] * (swv[v] * sav[t]) + bias[v]; };
+  auto yv = [&](int t, int v) -> f32x4 {
+    const f32x4 b = *(const f32x4*)(cst + 16 * v + 4 * (le >> 4));
+    const f32x4 w = *(const f32x4*)(cst + 64 + 16 * v + 4 * (le >> 4));
+    const float sa_t = cst[128 + 16 * t + (le & 15)];
+    return acc[t][v] * (w * sa_t) + b;
+  };
   char* stg = smem + 4 * TILE_BYTES + wave * STG_WAVE;
   const int wr_row = le & 15, wr_g = le >> 4;
   auto stg_write = [&](int v, bf16x4 o) {
@@ -428,12 +437,12 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16* __re
 int pick_mt8(int M, int tiles_n) {
   const char* e = getenv("FLEXAM_GEMM_MT");
   const int forced = e ? atoi(e) : 0;
-  if (forced >= 4 && forced <= 8) return forced;
-  int best = 8;
+  if (forced >= 4 && forced <= 7) return forced;
+  int best = 7;
   double best_cost = 1e30;
   const int G = flexam_num_cus();
-  // 224-row tiles at most by default: the 256-row instance keeps 64 A + 32 W fragment registers next to 128 accumulators and spills
-  // (1.5-1.7 PF against 2.1-2.2 for MT = 7 at the FFN2 shapes, tools/fp8_ffn2_sweep.py)
+  // 224-row tiles at most: a 256-row instance would keep 64 A + 32 W fragment registers next to 128 accumulators and spill
+  // (it ran at 1.5-1.7 PF against 2.1-2.2 for MT = 7 at the FFN2 shapes, tools/fp8_ffn2_sweep.py, and is no longer compiled)
   for (int mt = 7; mt >= 4; --mt) {
     const int tiles = (int)((long)((M + 32 * mt - 1) / (32 * mt)) * tiles_n);
     const double cost = ((tiles + G - 1) / G) * (mt + 1.25);
@@ -446,7 +455,7 @@ template <int EPI, int MT>
 int launch_shape8(Gemm8Params p, hipStream_t s) {
   auto kern = gemm_fp8_kernel<EPI, MT>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};
-  const int smem = 4 * TILE_BYTES + 8 * 16 * 128;
+  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 8 * 1024;      // K-block buffers, output staging, epilogue constants
   const int dev = flexam_current_device();
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -468,11 +477,10 @@ int launch8(Gemm8Params p, hipStream_t s) {
     p.gm = g && atoi(g) >= 1 ? atoi(g) : 4;
   }
   switch (pick_mt8(p.M, p.tiles_n)) {
-    case 7: return launch_shape8<EPI, 7>(p, s);
     case 6: return launch_shape8<EPI, 6>(p, s);
     case 5: return launch_shape8<EPI, 5>(p, s);
     case 4: return launch_shape8<EPI, 4>(p, s);
-    default: return launch_shape8<EPI, 8>(p, s);
+    default: return launch_shape8<EPI, 7>(p, s);      // no 256-row instance: it needs 64 A + 32 W fragment registers next to 128 accumulators and spilled 60-150 of them
   }
 }
 

