@@ -278,13 +278,15 @@ class DiTEngine:
             e1 = hip.small_linear(s, *self.dens[0])
             dens_emb = hip.small_linear(e1, *self.dens[1], silu_in=True)
             dens0 = hip.small_linear(dens_emb, *self.dens[2], silu_in=True).view(B, 2, d)
+        # all samples carry the same density (the sampler's CFG pair does): part of what lets block 0 share its self-attention half
+        dens_same = dens0 is None or B == 1 or bool((dens0 == dens0[:1]).all())
         grid = (f + (1 if ref_len else 0), h // 2, w // 2)
         if self._angles is None:
             self._angles = self.model._rope_angles()
         cos, sin = rope_tables(grid, L, self.hd, self._angles)
         self.cond = dict(B=B, nb=nb, L=L, lvid=lvid, ref_len=ref_len, latent_shape=(cx, f, h, w), patch_a=patch_a, ref_tok=ref_tok,
                          cross_kv=cross_kv, dens_emb=dens_emb, dens0=dens0, cos=cos.to(dev), sin=sin.to(dev),
-                         ctx=ctx.view(B, self.text_len, d), grid=grid)
+                         ctx=ctx.view(B, self.text_len, d), grid=grid, dens_same=dens_same)
         self.n_conditioning += 1
         return self.cond
 
@@ -354,8 +356,15 @@ class DiTEngine:
                 dst[:ref_len].copy_(cd["ref_tok"][b if cd["nb"] > 1 else 0])
             if sp > 1:
                 xr[b].copy_(full[tok0:tok0 + lc])
-        for b in range(bx, B):
-            xr[b].copy_(xr[0])
+        # CFG pair on one latent (PIPE.py:846-848 feeds `torch.cat([latents] * 2)`): until the first cross-attention the two samples
+        # are the same tensor -- same tokens, same timestep rows, same density -- so block 0 runs LayerNorm, q|k|v, RoPE, self-
+        # attention and the output projection ONCE and the second sample's residual stream is a copy (half of 1/30 of the
+        # attention and projection work of a step; every later operation sees the text and runs per sample)
+        share0 = (self.fused and B == 2 and bx == 1 and sp == 1 and rows_shared and cd.get("dens_same", False) and teacache is None
+                  and os.environ.get("FLEXAM_SHARE_BLOCK0", "1") != "0")
+        if not share0:
+            for b in range(bx, B):
+                xr[b].copy_(xr[0])
 
         # ---- timestep embedding on the distinct rows + AdaLN tables of all blocks and the head
         R = t_rows.numel()
@@ -410,10 +419,13 @@ class DiTEngine:
             else:
                 T = tab[i]
             fp8_here = self.fp8
+            nb = 1 if (share0 and i == 0) else B               # samples that run the self-attention half of this block (share0: above)
+            mb = nb * lc
+            ri = row_index[:mb] if row_index is not None else None
             if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
-                a8, sa = self._ln_fp8(xres, ws, hbuf, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
+                a8, sa = self._ln_fp8(xres[:mb], ws, hbuf[:mb], shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
             else:
-                hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=row_index, rows_per_batch=rpb)
+                hip.ln_modulate(xres[:mb], out=hbuf[:mb], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
             if sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
                 # returned blocks in place (flexam_amd/dist.py)
@@ -427,11 +439,14 @@ class DiTEngine:
                 self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0)
                 hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             else:
-                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None), qkv)
-                hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                a8sa = fp8_here and (a8[:mb], sa[:mb])
+                self._proj(hbuf[:mb], a8sa, i, p, "wqkv", "bqkv", slice(None), qkv[:mb])
+                hip.rmsnorm_rope(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
                                  tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
-                hip.attn_fwd(q4, k4, v4, out=ao4, prescaled=True)
-                hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
+                hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
+                hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
+                if nb < B:
+                    xr[1].copy_(xr[0])
             # cross-attention on the text context (K/V precomputed per clip)
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
             qc = qkv[:, 0:d]

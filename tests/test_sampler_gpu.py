@@ -171,3 +171,34 @@ def test_fractional_mask_many_timestep_rows_and_bounded_table():
     p = C.psnr(out_b, ref)
     print(f"fractional mask, U = {pipe._state['U']}: psnr {p:.1f} dB")
     assert p >= 40.0
+
+
+def test_block0_shared_self_attention_half_equals_per_sample_run(monkeypatch):
+    """The sampler's CFG pair is one latent with two prompts: until block 0's cross-attention both samples are the same tensor, so
+    the engine runs block 0's LayerNorm / q|k|v / RoPE / self-attention / output projection once and copies the residual stream
+    (DiTEngine.run, `share0`).  Same arithmetic per row as the per-sample run (FLEXAM_SHARE_BLOCK0=0): the two must agree to the
+    rounding of the split-KV merge (the attention launch splits a different set of work units), and both match the oracle loop.
+    A model.forward() call with a batch-2 latent (no shared-latent promise) never takes the shortcut."""
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    from oracle import sampler as S
+    cfg = dict(O.DIT_TINY, num_layers=3)
+    sd = C.dit_weights(cfg, 7)
+    sc = C.sampler_case(cfg)
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], sc["mask_pixels"])
+    kw = dict(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+              num_inference_steps=3, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent")
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FLEXAM_SHARE_BLOCK0", flag)
+        outs[flag] = make_pipe(cfg, 7)(**kw).videos.float().cpu()
+    rel = ((outs["1"] - outs["0"]).pow(2).mean().sqrt() / outs["0"].pow(2).mean().sqrt()).item()
+    print(f"shared block-0 half vs per-sample: rel-rms {rel:.2e}")
+    assert rel <= 1e-3
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    ref = S.denoise_loop(lambda **k: O.dit_forward(sd, cfg, **k), S.FlowMatchEulerSchedule(1000, 5.0), 3, sc["latents"], sc["context_uncond"],
+                         sc["context_cond"], sc["control_latents"], sc["additional_control"], ml, sc["masked_video_latents"],
+                         sc["ref_latents"], mask, pinned, 0.1, 6.0)
+    for flag, o in outs.items():
+        p = C.psnr(o, ref)
+        print(f"FLEXAM_SHARE_BLOCK0={flag}: psnr vs oracle {p:.1f} dB")
+        assert p >= 40.0
