@@ -115,8 +115,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][STG_WAVE] of epilogue staging
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  int wave;                                 // asm: an SGPR value hipcc keeps (or parks in a VGPR lane) instead of re-deriving it from a
-  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(wave) : "v"(tid >> 6));   // spilled copy of threadIdx.x in front of every use
+  // The builtin, so that hipcc places the wait state gfx950 wants between a VALU write of a VGPR and a v_readfirstlane of it (a
+  // hand-written v_readfirstlane right behind the shift read a stale register: memory faults); the empty asm makes the SGPR value
+  // opaque, so it is kept (or parked in a VGPR lane) instead of re-derived from a spilled copy of threadIdx.x in front of every use.
+  int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  asm volatile("" : "+s"(wave));
   const int wm = wave / WNW, wn = wave % WNW;
 
   // All persistent workgroups run tiles of the same length, so without this they reach their epilogues together: every CU then

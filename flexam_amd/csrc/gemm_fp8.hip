@@ -67,8 +67,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
   constexpr int H0 = (MT + 1) / 2, H1 = MT - H0;      // m-tiles of phase A / phase B
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
-  int wave;                                 // asm: kept as an SGPR value, not re-derived from a spilled copy of threadIdx.x (gemm.hip, fresh_lane)
-  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(wave) : "v"(tid >> 6));
+  // The builtin, so that hipcc places the wait state gfx950 wants between a VALU write of a VGPR and a v_readfirstlane of it (a
+  // hand-written v_readfirstlane right behind the shift read a stale register: memory faults); the empty asm makes the SGPR value
+  // opaque, so it is kept (or parked in a VGPR lane) instead of re-derived from a spilled copy of threadIdx.x in front of every use.
+  int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  asm volatile("" : "+s"(wave));
   const int wm = wave >> 2, wn = wave & 3;
 
   const int nwg = p.units;
