@@ -519,6 +519,7 @@ def main():
             base["legs"] = cpu_baseline_legs(cfg)
 
     eng_cfg, eng_sp, eng_mode = eng.cfg_size, eng.sp_size, getattr(eng, "sp_mode", "-")
+    eng_cross_lk = eng.cond.get("cross_lk")
     if eng_mode == "allgather":
         pcs = getattr(eng, "sp_pieces", 1)
         eng_mode = (f"K|V all-gather per block in {pcs} head-group piece(s), " +
@@ -542,6 +543,9 @@ def main():
         # projections and self-attention run once, not per sample (DiTEngine.run, share0)
         shared0 = (world == 1 and os.environ.get("FLEXAM_SHARE_BLOCK0", "1") != "0" and cfg["num_layers"] > 0)
         removed_flops = (8 * L * cfg["dim"] ** 2 + 4 * L * L * cfg["dim"]) if shared0 else 0
+        # ... and the identical padded text rows are attended to as one weighted key (DiTEngine.set_conditioning, cross_lk)
+        cross_lk = eng_cross_lk if eng_cross_lk else cfg["text_len"]
+        removed_flops += 4 * L * (cfg["text_len"] - cross_lk) * cfg["dim"] * B * cfg["num_layers"]
         executed_block_flops = step_block_flops - removed_flops
         result = {
             "metric": "denoise-steps/sec", "value": steps_per_sec, "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
@@ -567,8 +571,9 @@ def main():
             "sec_per_clip": (enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
             "dit_block_tflops": executed_block_flops * steps_per_sec / 1e12,
             "dit_block_mfma_frac": executed_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
-            "dit_block_mfma_frac_note": ("EXECUTED block FLOPs (algorithmic 5.131 TF x 60 per step minus the block-0 self-attention half that the CFG pair "
-                                         "shares: %.3f of %.1f TF) against the 2.5 PFLOP/s bf16 peak" % (removed_flops / 1e12, step_block_flops / 1e12))
+            "dit_block_mfma_frac_note": ("EXECUTED block FLOPs (algorithmic 5.131 TF x 60 per step minus what the build removes -- the block-0 self-attention half "
+                                         "the CFG pair shares and the identical padded text keys of cross-attention: %.3f of %.1f TF) against the 2.5 PFLOP/s "
+                                         "bf16 peak" % (removed_flops / 1e12, step_block_flops / 1e12))
                                         + (" (QKV / FFN ran on the 5 PFLOP/s fp8 pipe: not a roofline fraction)" if args.fp8 else ""),
             "finite": finite,
             "mask": args.mask, "timestep_rows_per_sample": rows_u,

@@ -53,6 +53,7 @@ struct AttnParams {
   // this call are only PART of the softmax: local-chunk-first attention under a sequence-parallel K|V all-gather);
   // n_slots: slots the merge kernel adds up
   int partial, slot0, n_slots;
+  float last_key_bias;  // added to the score of key Lk - 1 in exp2 units (log2 of its multiplicity), 0 = none: see flexam_attn_fwd_lastkey
   int prio_young;       // tuning switch (FLEXAM_ATTN_PRIO=1): s_setprio 1 for waves 4-7, the arbitration losers of every segment (guide, two waves per SIMD, item 4)
 };
 
@@ -292,13 +293,17 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     qk_mma(ds0_c, kf, sacc);
   };
   bf16x8 kf_pre[4];      // the first four K fragments of the NEXT half tile, read one step ahead (block A starts on the matrix pipe)
+  // weight of the LAST key as a score bias (multiplicity N of a key = + log2 N on its score): raw-score units in the non-PRE form
+  const float last_bias = PRE ? p.last_key_bias : p.last_key_bias / p.scale_log2e;
   auto mask_half = [&](int g, f32x16& sacc) {      // g: local half index; keys are global
     const int gg = 2 * t0 + g;
-    if ((gg + 1) * 32 > p.Lk || g >= 2 * ntiles) {   // past the end of the keys, or of this split's range
+    // past the end of the keys, or of this split's range -- or the half tile that holds a weighted last key
+    if ((gg + 1) * 32 > p.Lk || g >= 2 * ntiles || (p.last_key_bias != 0.f && (gg + 1) * 32 == p.Lk)) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = gg * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (key >= p.Lk || g >= 2 * ntiles) sacc[e] = -INFINITY;
+        else if (key == p.Lk - 1) sacc[e] += last_bias;
       }
     }
   };
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
 
 int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
              int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk, int head_dim, float softmax_scale,
-             int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream, int partial_slot0 = -1) {
+             int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream, int partial_slot0 = -1, float last_key_bias = 0.f) {
   FX_REQUIRE(q && k && v && (o || partial_slot0 >= 0), FLEXAM_E_ARG, "attn_fwd: null pointer");
   FX_REQUIRE(head_dim == HD, FLEXAM_E_SHAPE, "attn_fwd: head_dim %d unsupported (128 only)", head_dim);
   FX_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, FLEXAM_E_SHAPE, "attn_fwd: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
@@ -576,6 +581,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.kv_splits = (tiles_all + p.tiles_per_split - 1) / p.tiles_per_split;     // drop empty trailing splits
   p.ws_o = ws_o; p.ws_ml = ws_ml;
   p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits;
+  p.last_key_bias = last_key_bias;
   {
     const char* e = getenv("FLEXAM_ATTN_PRIO");           // read per call: tools/ab_attn_prio.py flips it inside one process
     p.prio_young = e ? atoi(e) : 0;
@@ -625,6 +631,14 @@ extern "C" int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const 
                                int Lq, int Lk, int head_dim, float softmax_scale, void* stream) {
   return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, 1, 0, nullptr,
                   nullptr, stream);
+}
+
+extern "C" int flexam_attn_fwd_lastkey(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,
+                                       const void* v, int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
+                                       int Lq, int Lk, int head_dim, float softmax_scale, float last_key_multiplicity, void* stream) {
+  FX_REQUIRE(last_key_multiplicity >= 1.0f, FLEXAM_E_ARG, "attn_fwd_lastkey: multiplicity %g < 1", (double)last_key_multiplicity);
+  return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, softmax_scale, 1, 0, nullptr,
+                  nullptr, stream, -1, log2f(last_key_multiplicity));
 }
 
 extern "C" int flexam_attn_fwd_splitkv(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs,

@@ -14,43 +14,41 @@ __device__ __forceinline__ float row_sum(float v, float* red) { return block_sum
 
 // ------------------------------------------------------------------------------------------
 // Same LayerNorm + modulation, ONE WAVE PER ROW (C = 512*NV8, NV8 <= 8): every lane keeps 8*NV8 values in registers, both
-// reductions are wave shuffles (no LDS, no barrier), four rows per 256-thread block.  The block-per-row form below spends
-// its time in two block reductions per 12 KiB row; this one keeps 6 x 32 B loads per lane in flight.
+// reductions are wave shuffles (no LDS, no barrier), one row per 64-thread workgroup.  The block-per-row form below spends
+// its time in two block reductions per 12 KiB row; this one keeps 12 x 16 B loads per lane in flight.
 // ------------------------------------------------------------------------------------------
 // FP8: the output row is written as OCP e4m3 bytes with a per-row scale (absmax / 448) -- the A operand of flexam_gemm_fp8 -- instead
 // of bf16: the row is in registers anyway, so the quantiser costs one more wave reduction and no second pass over HBM.
 template <int NV8, bool FP8 = false>
-__global__ __launch_bounds__(256) void ln_modulate_wave_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, float eps,
-                                                               const float* __restrict__ shift, const float* __restrict__ scale,
-                                                               int64_t tab_ld, const int32_t* __restrict__ row_index,
-                                                               int64_t rows_per_batch, const float* __restrict__ ln_w,
-                                                               const float* __restrict__ ln_b, bf16* __restrict__ out, int64_t ldo,
-                                                               float* __restrict__ row_scale = nullptr) {
-  constexpr int C = 512 * NV8;
-  const int lane = threadIdx.x & 63;
-  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
+__global__ __launch_bounds__(64) void ln_modulate_wave_kernel(const float* __restrict__ x, int64_t ldx, int64_t M, float eps,
+                                                              const float* __restrict__ shift, const float* __restrict__ scale,
+                                                              int64_t tab_ld, const int32_t* __restrict__ row_index,
+                                                              int64_t rows_per_batch, const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b, bf16* __restrict__ out, int64_t ldo,
+                                                              float* __restrict__ row_scale = nullptr) {
+  // Access shape (tools/ab_rowkernels.py, r3): a lane owns 4 consecutive floats of every 256-float segment, so one load
+  // instruction of the wave covers 1 KiB without gaps (the earlier 8-floats-per-lane shape read it as two half-dense
+  // instructions: -9.6 % time), and ONE wave per workgroup, so no row waits for the slowest of four (-9.3 % on its own).
+  constexpr int C = 512 * NV8, NV = 2 * NV8;
+  const int lane = threadIdx.x;
+  const int64_t m = blockIdx.x;
   const float* xr = x + m * ldx;
-  f32x4 v[NV8][2];
+  f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV8; ++i) {
-    const int c = (i * 64 + lane) * 8;
-    v[i][0] = *(const f32x4*)(xr + c);
-    v[i][1] = *(const f32x4*)(xr + c + 4);
-  }
+  for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(xr + (i * 64 + lane) * 4);
 #pragma unroll
-  for (int i = 0; i < NV8; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s += v[i][0][j] + v[i][1][j];
+    for (int j = 0; j < 4; ++j) s += v[i][j];
   const float mean = wave_sum(s) * (1.0f / C);
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV8; ++i)
+  for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = v[i][0][j] - mean, b = v[i][1][j] - mean;
-      q += a * a + b * b;
+      const float a = v[i][j] - mean;
+      q += a * a;
     }
   const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * (1.0f / C) + eps);
   const float* sh = nullptr;
@@ -60,20 +58,25 @@ __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(const float* __re
     sh = shift + r * tab_ld;
     sc = scale + r * tab_ld;
   }
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    f32x4 y = (v[i] - mean) * rstd;
+    if (ln_w) y = y * *(const f32x4*)(ln_w + c) + *(const f32x4*)(ln_b + c);
+    if (sh) y = y * *(const f32x4*)(sc + c) + *(const f32x4*)(sh + c);
+    if constexpr (FP8) {
+      v[i] = y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(y[j]));
+    } else {
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(y[j]);
+      *(bf16x4*)(out + m * ldo + c) = o;
+    }
+  }
   if constexpr (FP8) {
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV8; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = (i * 64 + lane) * 8 + h * 4;
-        f32x4 y = (v[i][h] - mean) * rstd;
-        if (ln_w) y = y * *(const f32x4*)(ln_w + c) + *(const f32x4*)(ln_b + c);
-        if (sh) y = y * *(const f32x4*)(sc + c) + *(const f32x4*)(sh + c);
-        v[i][h] = y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(y[j]));
-      }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     const float qs = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
@@ -81,34 +84,12 @@ __global__ __launch_bounds__(256) void ln_modulate_wave_kernel(const float* __re
     if (lane == 0) row_scale[m] = qs;
     uint8_t* qrow = (uint8_t*)out + m * ldo;
 #pragma unroll
-    for (int i = 0; i < NV8; ++i) {
-      u32x2 o;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int w = 0;
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][h][0] * inv, v[i][h][1] * inv, w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][h][2] * inv, v[i][h][3] * inv, w, true);
-        o[h] = (unsigned)w;
-      }
-      *(u32x2*)(qrow + (i * 64 + lane) * 8) = o;
+    for (int i = 0; i < NV; ++i) {
+      int w = 0;
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][0] * inv, v[i][1] * inv, w, false);
+      w = __builtin_amdgcn_cvt_pk_fp8_f32(v[i][2] * inv, v[i][3] * inv, w, true);
+      *(unsigned*)(qrow + (i * 64 + lane) * 4) = (unsigned)w;
     }
-    return;
-  }
-  bf16* orow = out + m * ldo;
-#pragma unroll
-  for (int i = 0; i < NV8; ++i) {
-    const int c0 = (i * 64 + lane) * 8;
-    bf16x8 o;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = c0 + h * 4;
-      f32x4 y = (v[i][h] - mean) * rstd;
-      if (ln_w) y = y * *(const f32x4*)(ln_w + c) + *(const f32x4*)(ln_b + c);
-      if (sh) y = y * *(const f32x4*)(sc + c) + *(const f32x4*)(sh + c);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[h * 4 + j] = f2bf(y[j]);
-    }
-    *(bf16x8*)(orow + c0) = o;
   }
 }
 
@@ -625,7 +606,7 @@ extern "C" int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C,
   FX_REQUIRE(!shift || row_index || rows_per_batch > 0, FLEXAM_E_ARG, "ln_modulate: need row_index or rows_per_batch");
   if (rows_per_batch <= 0) rows_per_batch = 1;
   if (C % 512 == 0 && C <= 4096) {             // wave-per-row form (the DiT width 3072 = 512 * 6)
-    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    const dim3 grid((unsigned)M), block(64);   // one wave per row, one row per workgroup
 #define LN_WAVE(NV8_)                                                                                                              \
   case NV8_:                                                                                                                       \
     hipLaunchKernelGGL(ln_modulate_wave_kernel<NV8_>, grid, block, 0, (hipStream_t)stream, x, ldx, M, eps, shift, scale, tab_ld, \
@@ -650,7 +631,7 @@ extern "C" int flexam_ln_modulate_fp8(const float* x, int64_t ldx, int64_t M, in
              "ln_modulate_fp8: shift / scale and ln_w / ln_b go together");
   FX_REQUIRE(!shift || row_index || rows_per_batch > 0, FLEXAM_E_ARG, "ln_modulate_fp8: need row_index or rows_per_batch");
   if (rows_per_batch <= 0) rows_per_batch = 1;
-  const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+  const dim3 grid((unsigned)M), block(64);
 #define LN_WAVE8(NV8_)                                                                                                                   \
   case NV8_:                                                                                                                            \
     hipLaunchKernelGGL((ln_modulate_wave_kernel<NV8_, true>), grid, block, 0, (hipStream_t)stream, x, ldx, M, eps, shift, scale, tab_ld, \

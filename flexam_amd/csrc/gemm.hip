@@ -754,8 +754,13 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
   GemmParams p = p_;
   const GemmWorkspace g_ws = make_ws(ws, ws_bytes);
   {
+    // Tile-rows per L2 group.  Plain-store epilogues: 4 tile-rows x 8 tile-columns resident per XCD is the smallest panel set
+    // (12 panels of 32 KiB per K block) and measured best (profiles/r1e notes; r3 round-robin over 1 / 2 / 4 / 8 / 16:
+    // profiles/r3d_gemm_gm_ab.txt).  Gate-residual epilogues read-modify-write 1 KiB of an X row per tile: there the resident
+    // tiles' X footprint matters more than panel sharing -- one tile-row across all columns (whole 12 KiB rows of X, long K) or a
+    // tall group (short K, where the epilogue is a fifth of the tile) were 2.0 % / 2.6 % faster than 4.
     const char* g = getenv("FLEXAM_GEMM_GM");
-    p.gm = g ? atoi(g) : 4;                  // 4 tile-rows x (32 / 4) tile-columns resident per XCD measured best (profiles/r1e notes)
+    p.gm = g ? atoi(g) : (EPI == EPI_GATE_RESIDUAL && a_koff == nullptr ? (p.K >= 8192 ? 1 : 16) : 4);
     if (p.gm < 1) p.gm = 4;
   }
   {

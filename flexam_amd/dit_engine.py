@@ -261,9 +261,17 @@ class DiTEngine:
         # text -> context embedding -> per-block cross K (normalised) and V
         tdim = self.txt[0][0].shape[1]
         ctx_in = torch.zeros(B * self.text_len, tdim, device=dev, dtype=BF16)
+        n_max = 0
         for b, u in enumerate(context):
             n = min(u.shape[0], self.text_len)
+            n_max = max(n_max, n)
             ctx_in[b * self.text_len:b * self.text_len + n, :u.shape[1]] = u[:n].to(dev, BF16)
+        # Rows n_max .. text_len - 1 of EVERY sample are zero before the text MLP (the reference pads the same way, FX.py:958-964),
+        # so behind it they are one and the same context row and, per block, one and the same K / V row: cross-attention keeps the
+        # first of them and counts it text_len - n_max times (flexam_attn_fwd_lastkey) instead of attending to 386 copies
+        cross_lk, cross_mult = None, 1.0
+        if n_max + 1 < self.text_len and os.environ.get("FLEXAM_CROSS_DEDUP", "1") != "0":
+            cross_lk, cross_mult = n_max + 1, float(self.text_len - n_max)
         hmid = hip.gemm(ctx_in, self.txt[0][0], self.txt[0][1], epilogue=hip.EPI_GELU_TANH)
         ctx = hip.gemm(hmid, self.txt[1][0], self.txt[1][1])
         cross_kv = []
@@ -286,7 +294,7 @@ class DiTEngine:
         cos, sin = rope_tables(grid, L, self.hd, self._angles)
         self.cond = dict(B=B, nb=nb, L=L, lvid=lvid, ref_len=ref_len, latent_shape=(cx, f, h, w), patch_a=patch_a, ref_tok=ref_tok,
                          cross_kv=cross_kv, dens_emb=dens_emb, dens0=dens0, cos=cos.to(dev), sin=sin.to(dev),
-                         ctx=ctx.view(B, self.text_len, d), grid=grid, dens_same=dens_same)
+                         ctx=ctx.view(B, self.text_len, d), grid=grid, dens_same=dens_same, cross_lk=cross_lk, cross_mult=cross_mult)
         self.n_conditioning += 1
         return self.cond
 
@@ -453,7 +461,12 @@ class DiTEngine:
             hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
             hip.rmsnorm_rope(qc, p["cnq"], eps=self.eps)
             kv = cd["cross_kv"][i][rsel]
-            hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
+            if cd.get("cross_lk"):                          # the identical padded text rows as ONE weighted key
+                lk = cd["cross_lk"]
+                hip.attn_fwd_lastkey(q4, kv[:, :lk, 0:d].unflatten(2, (nh, hdim)), kv[:, :lk, d:].unflatten(2, (nh, hdim)), cd["cross_mult"],
+                                     out=ao4, prescaled=True)
+            else:
+                hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
             hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
             # FFN
             if self.fp8:

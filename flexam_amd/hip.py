@@ -28,6 +28,7 @@ _SIGNATURES = {
     "flexam_gemm_fp8": ([_P, _L, _P, _P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P], c_int),
     "flexam_gemm_fp8_gate_residual": ([_P, _L, _P, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
+    "flexam_attn_fwd_lastkey": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P], c_int),
     "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_fwd_partial": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_merge": ([_P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
@@ -262,6 +263,23 @@ _ATTN_WS = {}
 
 
 ATTN_PRESCALED = -1.0      # flexam_hip.h FLEXAM_ATTN_PRESCALED
+
+
+def attn_fwd_lastkey(q, k, v, last_key_multiplicity, out=None, softmax_scale=None, prescaled=False):
+    """attn_fwd with the last key counted `last_key_multiplicity` times (identical trailing context rows folded into one, see
+    flexam_hip.h); same layouts as attn_fwd, no split-KV (short contexts)."""
+    B, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != D:
+            raise RuntimeError("attn_fwd_lastkey: heads must be packed along the row (stride(2) == head_dim, stride(3) == 1)")
+    if out is None:
+        out = torch.empty(B, Lq, H, D, device=q.device, dtype=BF16)
+    scale = ATTN_PRESCALED if prescaled else (softmax_scale if softmax_scale is not None else D ** -0.5)
+    _check(lib().flexam_attn_fwd_lastkey(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1),
+                                         _ptr(v, BF16), v.stride(0), v.stride(1), _ptr(out, BF16), out.stride(0), out.stride(1),
+                                         B, H, Lq, Lk, D, scale, float(last_key_multiplicity), _stream()), "flexam_attn_fwd_lastkey")
+    return out
 
 
 def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_unit=None, prescaled=False):

@@ -94,6 +94,14 @@ int flexam_gemm_fp8_gate_residual(const void* A, int64_t lda, const float* a_sca
 int flexam_attn_fwd(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                     int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk,
                     int head_dim, float softmax_scale, void* stream);
+/* flexam_attn_fwd with the LAST key counted `last_key_multiplicity` (>= 1) times: softmax over {k_0 .. k_{Lk-2}, N copies of
+ * k_{Lk-1}} -- exactly what attention over a context whose trailing rows are identical computes, at the cost of one copy
+ * (the copy's score gets + log2 N before the exponential).  The reference pads every prompt to text_len = 512 rows with
+ * zeros BEFORE the text-embedding MLP and attends to all of them (wan_transformer3d_FlexAM.py:958-964, context_lens = None at
+ * :367): the 386+ padded rows of a 126-token prompt are one and the same K/V row. */
+int flexam_attn_fwd_lastkey(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
+                            int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk,
+                            int head_dim, float softmax_scale, float last_key_multiplicity, void* stream);
 /* Same, with the work units u = (batch*H + head)*ceil(Lq/256) + q_block at and after `split_from_unit` cut into kv_splits key
  * ranges each (flash-decoding style partial softmaxes + a merge launch), the units before it in one pass: with
  * split_from_unit = floor(units/256)*256 only the last, partial round of the 256 CUs is split; 0 splits everything (ranks of a

@@ -84,6 +84,24 @@ def test_riflex_toggle_between_calls_rebuilds_the_rotation_tables():
     assert m.engine().n_conditioning == 4
 
 
+def test_padded_text_rows_folded_into_one_weighted_key(golden, monkeypatch):
+    """The zero-padded text rows are one K/V row behind the text MLP: cross-attention over [real tokens | one padded row counted
+    text_len - n times] (the default) must reproduce attention over all text_len rows (FLEXAM_CROSS_DEDUP=0, what the reference
+    computes) -- and both match the reference golden (prompts of 5 and 11 tokens in a 16-row context)."""
+    cfg = dict(O.DIT_TINY)
+    case = to_dev(C.dit_case(cfg, 41))
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FLEXAM_CROSS_DEDUP", flag)
+        m, _ = build(cfg, 7)
+        outs[flag] = m(**case).float().cpu()
+        assert (m.engine().cond["cross_lk"] == 12 and m.engine().cond["cross_mult"] == 5.0) if flag == "1" else m.engine().cond["cross_lk"] is None
+        check(outs[flag], golden("g4_dit_tokent")["out"], f"g4 with FLEXAM_CROSS_DEDUP={flag}")
+    rel = ((outs["1"] - outs["0"]).pow(2).mean().sqrt() / outs["0"].pow(2).mean().sqrt()).item()
+    print(f"folded vs explicit padded text rows: rel-rms {rel:.2e}")
+    assert rel <= 2e-3
+
+
 def test_dit_matches_oracle_other_shape_batch1_and_bf16_weights():
     cfg = dict(O.DIT_TINY, num_layers=3)
     m, sd = build(cfg, 19)

@@ -611,3 +611,26 @@ def test_cfg_euler_blend_tiled_and_gather_forms_agree(H, c, f, h, w, tok0, cfg):
     vel = torch.empty(c, f, h, w, device=dev())
     H.cfg_velocity(tu.to(dev()), tc.to(dev()) if cfg else None, tok0, 6.0, vel)
     torch.testing.assert_close(vel.cpu(), v, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("lk,mult,prescaled", [(100, 29, True), (96, 417, True), (127, 386, False), (1, 512, True), (65, 2, False)])
+def test_attention_weighted_last_key_equals_explicit_copies(H, lk, mult, prescaled):
+    """flexam_attn_fwd_lastkey: softmax over {k_0 .. k_{Lk-2}, N copies of k_{Lk-1}} must equal plain attention over a context that
+    really holds the N copies (what the reference's zero-padded text context is behind the text MLP); Lk a multiple of 32 takes
+    the branch of the half tile that ends exactly at the last key; both score forms (q pre-scaled / scale in the kernel)."""
+    g = torch.Generator().manual_seed(77 + lk)
+    B, Lq, Hh, D = 2, 300, 2, 128
+    scale = D ** -0.5
+    q = bf(torch.randn(B, Lq, Hh, D, generator=g))
+    k = bf(torch.randn(B, lk, Hh, D, generator=g))
+    v = bf(torch.randn(B, lk, Hh, D, generator=g))
+    k_full = torch.cat([k, k[:, -1:].expand(B, mult - 1, Hh, D)], dim=1).contiguous()
+    v_full = torch.cat([v, v[:, -1:].expand(B, mult - 1, Hh, D)], dim=1).contiguous()
+    qd = bf(q.float() * scale * math.log2(math.e)).to(dev()) if prescaled else q.to(dev())
+    got = H.attn_fwd_lastkey(qd, k.to(dev()), v.to(dev()), float(mult), prescaled=prescaled)
+    ref = H.attn_fwd(qd, k_full.to(dev()), v_full.to(dev()), prescaled=prescaled)
+    assert_bf16_close(got, ref, ulps=2.0, atol=2e-3, msg=f"lastkey lk={lk} x{mult}")
+    from oracle import dit as O
+    if not prescaled:
+        want = O.attention(q.float(), k_full.float(), v_full.float())
+        assert_bf16_close(got, want, ulps=3.0, atol=4e-3, msg="lastkey vs oracle")
