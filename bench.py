@@ -484,6 +484,14 @@ def main():
         elapsed = float(tt.item())
     finite = bool(torch.isfinite(pipe._state["latents"]).all())
     rows_u = int(pipe._state["U"])
+    # host side of a step: how long Python + ctypes need to ENQUEUE one step's ~420 launches (the GPU is idle-free while this
+    # stays below the step's GPU time; at N ranks the GPU time shrinks N-fold, the enqueue time does not)
+    sync()
+    th0 = time.perf_counter()
+    for i in range(2):
+        pipe.denoise_step((args.warmup + args.steps + i) % total_steps)
+    host_enqueue = (time.perf_counter() - th0) / 2
+    sync()
 
     def timed(p):
         for i in range(args.warmup):
@@ -577,6 +585,7 @@ def main():
                                         + (" (QKV / FFN ran on the 5 PFLOP/s fp8 pipe: not a roofline fraction)" if args.fp8 else ""),
             "finite": finite,
             "mask": args.mask, "timestep_rows_per_sample": rows_u,
+            "host_enqueue_ms_per_step": host_enqueue * 1e3,
         }
         if motion_elapsed is not None:
             result["configs1_same_process"] = {"ms_per_step": motion_elapsed / args.steps * 1e3, "value": args.steps / motion_elapsed,
