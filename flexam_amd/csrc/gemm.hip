@@ -149,8 +149,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   };
   // tile index in the grouped order -> first row / column
   auto tile_origin = [&](int bid, int& m0, int& n0) {
-    const int GM = p.gm;
-    const int per_group = GM * p.tiles_n;
+    int GM = p.gm;
+    asm volatile("" : "+s"(GM));         // laundered: the uniform divisions below are redone per unit (a few VALU operations) instead of
+    const int per_group = GM * p.tiles_n;   // keeping their float reciprocals alive across the K loop in VGPRs that end up in scratch
     const int group = bid / per_group;
     const int first_m = group * GM;
     const int gsz = min(p.tiles_m - first_m, GM);
@@ -188,6 +189,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     for (int ks = 0; ks < (M32 ? 4 : 2); ++ks)
       frag_off[ks] = (lf & (RT - 1)) * 128 + ((((M32 ? 2 * ks + (lf >> 5) : 4 * ks + (lf >> 4))) ^ sw) << 4);
   };
+  // ---- bias of the wave's 64 columns through LDS (standard tile shape).  A plain bias load at the top of the epilogue sits BEHIND
+  // the next unit's 16 prefetched LDS-DMA pieces in the wave's in-order vmcnt queue: the first use of the bias waited for all of
+  // them (s_waitcnt vmcnt(0): a full DMA latency with the matrix pipe idle, once per tile).  Instead one 256-byte LDS-DMA per unit,
+  // issued IN FRONT of the unit's K block 0 pieces (so every wait that covers K block 0 covers it), into one of two slots (unit
+  // parity: the next unit's bias is on its way while this unit's epilogue reads its own).
+  constexpr bool BIAS_LDS = STD && !TAIL && !M32;
+  constexpr int BIAS_OFF = 4 * TILE_BYTES + 8 * STG_WAVE;       // [2 slots][8 waves][64 floats]
+  auto bias_dma = [&](int n0, int slot) {
+    if constexpr (BIAS_LDS) {
+      const float* pb = p.bias;          // laundered: the test is made here, on scalar registers, not kept as a 0 / 1 VGPR across the K loop
+      asm volatile("" : "+s"(pb));       // (with ~100 SGPRs in use hipcc parks loop-invariant uniform values in VGPRs and then spills those)
+      if (pb) {
+        const uint32_t voff = (uint32_t)min(n0 + wn * (16 * NTW) + fresh_lane(), p.N - 1) * 4u;
+        const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + BIAS_OFF + (slot * 8 + wave) * 256;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(pb), "s"(dst) : "memory");
+      }
+    }
+  };
+  if constexpr (BIAS_LDS) {
+    if (!p.bias) {                // no bias: both slots hold zeros for the whole launch (wave-local, ordered before any later read)
+      float* z = (float*)(smem + BIAS_OFF + wave * 256);
+      z[fresh_lane()] = 0.f;
+      z[8 * 64 + fresh_lane()] = 0.f;
+    }
+  }
   bool staged = false;          // K blocks 0 and 1 of the coming unit are already on their way into the two LDS buffers
   bool pend = false;            // ... and exactly PEND stores of the last epilogue were issued by this wave after them
   constexpr int PEND = (EPI == EPI_GATE_RESIDUAL ? 4 : 2) * MT;
@@ -302,6 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // reads of a phase are spread one group (4 MFMAs) apart instead of stalling the wave up front.
   bf16x8 f0[NF], f1[NF];
   if (!staged) {
+    bias_dma(n0, it & 1);
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma(i, kcol_a(kb0), (int64_t)kb0 * BK, smem);
     if (nkl > 1) {
@@ -375,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     unit_decode(nth_unit(it + 1), ntile, nkb0, nnkl, nslice, nns);
     tile_origin(ntile, nm0, nn0);
     stage_setup(nm0, nn0);
+    bias_dma(nn0, (it + 1) & 1);
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma(i, kcol_a(nkb0), (int64_t)nkb0 * BK, smem);
     if (nnkl > 1) {
@@ -409,10 +437,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   const int mrow = m0 + wm * (16 * MT) + (le & (RT - 1));
   const int ncol = n0 + wn * (16 * NTW) + (le / RT) * 4;
   f32x4 bias[NV];
+  if constexpr (BIAS_LDS) {
+    const float* bl = (const float*)(smem + BIAS_OFF + ((it & 1) * 8 + wave) * 256);     // landed with this unit's K block 0
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    const int n = ncol + v * (4 * NG);
-    bias[v] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < NV; ++v) bias[v] = *(const f32x4*)(bl + v * (4 * NG) + (le / RT) * 4);
+  } else {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int n = ncol + v * (4 * NG);
+      bias[v] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
   }
   // "used" on every path: a bias load that some path never reads stays pending in the compiler's wait bookkeeping, which then
   // puts a vmcnt(0) in front of the first MFMA of the next unit that reuses the register - draining the epilogue stores
@@ -670,7 +704,7 @@ template <int EPI, typename OutT, int MT, bool M32, int WMW = 2, int NTW = 4>
 int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
   auto kern = gemm_bf16_kernel<EPI, OutT, MT, M32, false, WMW, NTW>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};          // per device: the attribute belongs to the device's copy of the code object
-  const int smem = 4 * TILE_BYTES + 8 * (M32 ? 32 : 16) * 128;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave
+  const int smem = 4 * TILE_BYTES + 8 * (M32 ? 32 : 16) * 128 + (M32 ? 0 : 2 * 8 * 256);   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots per wave
   const int dev = flexam_current_device();
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)

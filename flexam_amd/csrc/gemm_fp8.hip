@@ -182,6 +182,24 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
     if (i < PA) asm volatile("" : "+v"(a_off[i]));
     asm volatile("" : "+v"(w_off[i]));
   }
+  // This unit's epilogue constants (bias and weight scale of the wave's 64 columns, activation scale of its 16 MT rows) start their
+  // way into the wave's 1 KiB of LDS now, as LDS-DMA pieces behind everything the top wait left in flight: they land under the K
+  // loop (its last barrier waits for vmcnt(0)).  As plain loads at the top of the epilogue they sat behind the next unit's 16
+  // prefetched pieces in the in-order vmcnt queue and their first use waited for all of them.
+  {
+    const int le0 = fresh_lane();
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + 4 * TILE_BYTES + 8 * STG_WAVE + wave * 1024;
+    const uint32_t ncol4 = (uint32_t)min(n0 + wn * (16 * NTW) + le0, p.N - 1) * 4u;
+    const int mr = m0 + wm * (16 * MT) + le0;
+    const float* pb = p.bias;
+    asm volatile("" : "+s"(pb));
+    if (pb) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(ncol4), "s"(pb), "s"(dst) : "memory");
+    else ((float*)(smem + 4 * TILE_BYTES + 8 * STG_WAVE + wave * 1024))[le0] = 0.f;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(ncol4), "s"(p.sw), "s"(dst + 256) : "memory");
+    const uint32_t r0 = (uint32_t)min(mr, p.M - 1) * 4u, r1 = (uint32_t)min(mr + 64, p.M - 1) * 4u;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(r0), "s"(p.sa), "s"(dst + 512) : "memory");
+    if (16 * MT > 64) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(r1), "s"(p.sa), "s"(dst + 768) : "memory");
+  }
   frag_setup();
 #pragma unroll
   for (int j = 0; j < NTW; ++j) frag(smem, j, wf[j]);
@@ -244,18 +262,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
   const int mrow = m0 + wm * (16 * MT) + (le & 15);
   const int ncol = n0 + wn * (16 * NTW) + (le >> 4) * 4;
   // Per-column bias / weight scale of the wave's 64 columns and the row scales of its 16 MT rows go through 1 KiB of LDS per wave
-  // (written once per tile, read back per (m-tile, n-tile) as one ds_read_b128 / ds_read_b32): held in registers they were 39
-  // values next to 16 MT accumulators and the packed outputs, and the MT = 7 instances spilled 12-32 of them.  A wave's LDS
-  // operations are served in order: no barrier between its writes and its reads.
-  float* cst = (float*)(smem + 4 * TILE_BYTES + 8 * STG_WAVE + wave * 1024);      // [64 bias][64 sw][128 sa]
-  {
-    const int n = n0 + wn * (16 * NTW) + le;
-    cst[le] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-    cst[64 + le] = n < p.N ? p.sw[n] : 0.f;
-    const int mr = m0 + wm * (16 * MT) + le;
-    cst[128 + le] = p.sa[min(mr, p.M - 1)];
-    if (16 * MT > 64) cst[192 + le] = p.sa[min(mr + 64, p.M - 1)];
-  }
+  // (brought in once per tile by LDS-DMA at the top of the unit, read back per (m-tile, n-tile) as one ds_read_b128 / ds_read_b32):
+  // held in registers they were 39 values next to 16 MT accumulators and the packed outputs, and the MT = 7 instances spilled
+  // 12-32 of them.
+  const float* cst = (const float*)(smem + 4 * TILE_BYTES + 8 * STG_WAVE + wave * 1024);      // [64 bias][64 sw][128 sa], landed under the K loop
   auto yv = [&](int t, int v) -> f32x4 {
     const f32x4 b = *(const f32x4*)(cst + 16 * v + 4 * (le >> 4));
     const f32x4 w = *(const f32x4*)(cst + 64 + 16 * v + 4 * (le >> 4));
