@@ -163,7 +163,10 @@ class DiTEngine:
         self.sp_overlap = os.environ.get("FLEXAM_SP_OVERLAP", "1") != "0"
         # the K|V gather is cut into `sp_pieces` groups of heads, one collective each: the attention of a group starts when ITS
         # piece has landed, the later pieces travel underneath it (1: one gather per block and CFG row)
-        pieces = int(os.environ.get("FLEXAM_SP_PIECES", "2"))
+        # Default: 2 pieces from 4 chunks on (3+ peers: the gather outlasts the Q projection + local-chunk attention it hides under),
+        # 1 below (two chunks: one peer's 36 MB arrive within that window anyway, and a piece costs 3-4 more launches per block)
+        env = os.environ.get("FLEXAM_SP_PIECES")
+        pieces = int(env) if env is not None else (2 if sp_size >= 4 and self.nh % 2 == 0 else 1)
         if pieces < 1 or self.nh % pieces:
             raise ValueError(f"FLEXAM_SP_PIECES={pieces}: must divide the {self.nh} heads")
         self.sp_pieces = pieces if sp_size > 1 else 1
