@@ -7,7 +7,7 @@ from flexam_amd import hip as H
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 L, d, f = 11648, 3072, 14336
-M = 2 * L
+M = int(os.environ.get("FLEXAM_AB_M", str(2 * L)))          # rows: 23296 = the CFG pair on one GPU; 2912 = one of 8 ranks
 r = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(BF).to(dev)
 x, hmid = r(M, d), r(M, f)
 w_o, w_qkv, w_f1, w_f2 = r(d, d), r(3 * d, d), r(f, d), r(d, f)
