@@ -114,7 +114,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][STG_WAVE] of epilogue staging
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   // The builtin, so that hipcc places the wait state gfx950 wants between a VALU write of a VGPR and a v_readfirstlane of it (a
   // hand-written v_readfirstlane right behind the shift read a stale register: memory faults); the empty asm makes the SGPR value
   // opaque, so it is kept (or parked in a VGPR lane) instead of re-derived from a spilled copy of threadIdx.x in front of every use.

@@ -49,7 +49,9 @@ int flexam_device_check(void);          /* FLEXAM_E_ARCH unless the current devi
  * that all CUs work; the slices' partial sums are parked in `ws` and a second launch on the same stream adds them up in slice
  * order (deterministic) and runs the epilogue.  Device memory, 16-byte aligned, slabs of 256 KiB, no initialisation needed;
  * FLEXAM_GEMM_WS_BYTES covers every shape.  NULL / too small: the GEMM never splits.  The buffer is used only by this call
- * (stream-ordered): calls that may run concurrently (other streams, other devices) need their own.
+ * (stream-ordered): calls that may run concurrently (other streams, other devices) need their own.  (The Python binding keeps
+ * one 64 MiB buffer per (device, stream) in an LRU of 8 slots, flexam_amd/hip.py:_gemm_workspace: that is the per-stream cost of
+ * using the library from several streams.)
  * Replaces nn.Linear -> cuBLAS (+ its workspace): FlexAM/models/wan_transformer3d_FlexAM.py:242-244,261,363-365,
  * 370,415-416,487,626-636 and Conv3d/Conv2d -> cuDNN: FlexAM/models/wan_vae3_8.py:39-47,94,99. */
 #define FLEXAM_GEMM_WS_BYTES (256 * 262144)
