@@ -298,35 +298,49 @@ def multi_gpu_check(pipe, model, inp, cond, step_index, total_steps, world, rank
     head output, so "all ranks hold the same latents" alone would also pass with a wrong K|V exchange.  Two checks:
       (1) ranks_agree: checksum of every rank's latents == rank 0's (they are bit-identical by construction);
       (2) rel_rms_vs_single_gpu: one more denoise step from the current latents on the N-rank layout, and the SAME step on this
-          rank alone (weights are replicated: a second engine with no parallel layout, full CFG pair, no collective); the two
-          latent updates must agree to the rounding of the partial-softmax merge (<= 1e-2 relative RMS of the update).
+          rank alone (weights are replicated: a second engine with no parallel layout, full CFG pair, no collective); the DiT's
+          head outputs of the two runs -- per CFG row, BEFORE the guidance combine, which multiplies any difference by ~8 at
+          guidance 6 -- must agree to the rounding of two summation orders: relative RMS <= 1.5e-2, the library's stated bf16
+          tolerance (typical 2-6e-3; a wrong or missing remote chunk shows up as O(1)).
     Returns the `check` object of the JSON line (rank 0's view + the worst rank)."""
     import torch.distributed as dist
     from flexam_amd import Wan2_2FunControlPipeline_FlexAM, hip
+    tol = 1.5e-2
+
+    def step_and_grab(p):
+        got = {}
+        orig = p._sampler_update
+
+        def grab(i, tok_u, tok_c):
+            got["rows"] = [t.double().clone() for t in (tok_u, tok_c) if t is not None]
+            return orig(i, tok_u, tok_c)
+        p._sampler_update = grab
+        try:
+            p.denoise_step(step_index)
+        finally:
+            p._sampler_update = orig
+        return got["rows"]
     st = pipe._state
     lat0 = st["latents"].clone()
-    pipe.denoise_step(step_index)
-    lat_multi = st["latents"].clone()
+    rows_multi = step_and_grab(pipe)
     sums = [None] * world
-    dist.all_gather_object(sums, hip.checksum(lat_multi))
+    dist.all_gather_object(sums, hip.checksum(st["latents"]))
     agree = all(tuple(c) == tuple(sums[0]) for c in sums)
     layout = model._parallel
     model._parallel, model._engine = None, None                 # a fresh engine: one GPU, no collective
     solo = Wan2_2FunControlPipeline_FlexAM(transformer=model)
     solo.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
     solo._state["latents"].copy_(lat0)
-    solo.denoise_step(step_index)
-    upd_s = (solo._state["latents"] - lat0).double()
-    upd_m = (lat_multi - lat0).double()
-    rel = float(((upd_m - upd_s).pow(2).mean().sqrt() / upd_s.pow(2).mean().sqrt().clamp_min(1e-30)).item())
+    rows_solo = step_and_grab(solo)
+    rel = max(float(((m - s_).pow(2).mean().sqrt() / s_.pow(2).mean().sqrt().clamp_min(1e-30)).item()) for m, s_ in zip(rows_multi, rows_solo))
     model._parallel, model._engine = layout, None
     rels = [None] * world
     dist.all_gather_object(rels, rel)
     worst = max(rels)
-    ok = bool(agree and worst <= 1e-2 and math.isfinite(worst))
-    return {"ok": ok, "ranks": world, "ranks_agree": bool(agree), "rel_rms_vs_single_gpu": rel, "worst_rank_rel_rms": worst, "tolerance": 1e-2,
-            "what": "latent update of one denoise step: N-rank layout vs the same step on one GPU (no collective), every rank; "
-                    "checksums of the N ranks' latents"}
+    ok = bool(agree and worst <= tol and math.isfinite(worst))
+    return {"ok": ok, "ranks": world, "ranks_agree": bool(agree), "rel_rms_vs_single_gpu": rel, "worst_rank_rel_rms": worst, "tolerance": tol,
+            "what": "DiT head output of one denoise step per CFG row (before the guidance combine): N-rank layout vs the same step on "
+                    "one GPU (no collective), every rank; checksums of the N ranks' latents"}
 
 
 def launch_ranks(args):
