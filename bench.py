@@ -290,7 +290,30 @@ def time_vae(device, frames, height, width):
         torch.cuda.synchronize()
         enc.append(time.perf_counter() - t0)
         finite = finite and bool(torch.isfinite(mu.float()).all())
-    return sec, enc[0], enc[1], finite
+    return sec, enc[0], enc[1], finite, vae
+
+
+def time_clip(model, vae, inp, frames, height, width, steps, device):
+    """ONE clip end to end through the drop-in call the reference's demo makes (PIPE.py:505-965 via pipelines.py:1174-1190):
+    pixel-space conditioning streams -> VAE encode of the 8 streams -> `steps` denoise steps -> VAE decode -> frames on the
+    host.  Synthetic pixel videos (seeded), the bench's prompt embeddings; a 2-step call first takes the allocations."""
+    from flexam_amd import Wan2_2FunControlPipeline_FlexAM
+    g = torch.Generator(device=device).manual_seed(7)
+    vid = lambda: torch.rand(1, 3, frames, height, width, device=device, generator=g)
+    mask = torch.full((1, 1, frames, height, width), 255.0, device=device)
+    mask[:, :, 0] = 0                                      # motion_transfer: frame 0 kept, the rest regenerated
+    streams = dict(video=vid(), control_video=vid(), depth_video=vid(), cos_control_videos={k: vid() for k in range(4)},
+                   ref_image=torch.rand(1, 3, 1, height, width, device=device, generator=g), mask_video=mask)
+    pipe = Wan2_2FunControlPipeline_FlexAM(transformer=model, vae=vae)
+    call = dict(prompt_embeds=inp["ctx_c"], negative_prompt_embeds=inp["ctx_u"], height=height, width=width, num_frames=frames,
+                guidance_scale=6.0, density=0.1, latents=inp["latents"], output_type="pt", **streams)
+    pipe(num_inference_steps=2, **call)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = pipe(num_inference_steps=steps, **call).videos
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    return sec, tuple(out.shape), bool(torch.isfinite(out.float()).all())
 
 
 def multi_gpu_check(pipe, model, inp, cond, step_index, total_steps, world, rank):
@@ -422,6 +445,7 @@ def main():
     ap.add_argument("--no-cpu-legs", action="store_true", help="skip the config-1 and VAE-chunk CPU baseline legs (keep the one-block leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--no-clip", action="store_true", help="skip the end-to-end clip (pixels -> encode -> 50 steps -> decode -> frames)")
     ap.add_argument("--mask", choices=["motion", "blob", "blob-open", "soft"], default="motion",
                     help="motion: BASELINE configs[1] (motion_transfer, frame 0 known); blob: configs[3] foreground_edit as demo.py "
                          "builds it; blob-open / soft: foreground masks that are not pinned (many per-token timesteps)")
@@ -550,12 +574,22 @@ def main():
     elif eng_mode == "ulysses":
         eng_mode = "all-to-all over heads (q|k|v out, attention output back)"
     vae_sec = enc_sec = enc_stream_sec = None
+    clip = None
     if rank == 0 and world == 1 and not args.no_vae:
-        del pipe, model, eng
+        del pipe, eng
         torch.cuda.empty_cache()
-        vae_sec, enc_stream_sec, enc_image_sec, vae_finite = time_vae(device, args.frames, args.height, args.width)
+        vae_sec, enc_stream_sec, enc_image_sec, vae_finite, vae = time_vae(device, args.frames, args.height, args.width)
         enc_sec = 7 * enc_stream_sec + enc_image_sec     # control, depth, 4 cos levels, masked video + the reference image
         finite = finite and vae_finite
+        if not args.no_clip and args.mask == "motion":
+            try:                                         # the measured clip must not cost the steps/s line if it fails
+                sec, shape, ok = time_clip(model, vae, inp, args.frames, args.height, args.width, total_steps, device)
+                clip = {"sec": sec, "steps": total_steps, "output_shape": list(shape), "finite": ok,
+                        "what": "Wan2_2FunControlPipeline_FlexAM.__call__ end to end: 8 pixel-space conditioning streams -> VAE encode -> "
+                                "50 denoise steps -> VAE decode -> frames on the host (synthetic pixels, prompt embeddings given)"}
+                finite = finite and ok
+            except Exception as e:                       # noqa: BLE001
+                clip = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         steps_per_sec = args.steps / elapsed
@@ -590,6 +624,7 @@ def main():
             "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
             "vae_decode_sec": vae_sec, "vae_encode_sec_per_stream": enc_stream_sec, "conditioning_encode_sec_8_streams": enc_sec,
             "prepare_sec": prepare_sec,
+            "clip_end_to_end": clip,
             "sec_per_clip": (enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
             "dit_block_tflops": executed_block_flops * steps_per_sec / 1e12,
             "dit_block_mfma_frac": executed_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
