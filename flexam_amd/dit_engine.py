@@ -302,15 +302,19 @@ class DiTEngine:
         return self.cond
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, B, lc):
-        key = (B, lc)
+    def _workspace(self, B, lc, lane: int = 0):
+        """Activation buffers of one run; `lane` > 0: a second, independent set for a run that is in flight on another stream at
+        the same time (the dual-stream CFG step).  Buffers of other shapes are dropped when a new shape arrives."""
+        key = (B, lc) if lane == 0 else (B, lc, lane)
         if key not in self._ws:
             dev, d, m = self.device, self.dim, B * lc
-            self._ws = {key: dict(
+            if any(k[:2] != (B, lc) for k in self._ws):
+                self._ws = {}
+            self._ws[key] = dict(
                 x=torch.empty(m, d, device=dev, dtype=F32), h=torch.empty(m, d, device=dev, dtype=BF16),
                 qkv=torch.empty(m, 3 * d, device=dev, dtype=BF16), ao=torch.empty(m, d, device=dev, dtype=BF16),
                 ffn=torch.empty(m, self.ffn, device=dev, dtype=BF16),
-                head=torch.empty(m, self.head_w.shape[0], device=dev, dtype=F32))}
+                head=torch.empty(m, self.head_w.shape[0], device=dev, dtype=F32))
             if self.fp8:
                 self._ws[key].update(a8=torch.empty(m, self.ffn, device=dev, dtype=torch.uint8), sa=torch.empty(m, device=dev, dtype=F32))
         return self._ws[key]
@@ -331,11 +335,16 @@ class DiTEngine:
         return e, e0.view(R, 6, d)
 
     def run(self, x: torch.Tensor, t_rows: torch.Tensor, row_index: Optional[torch.Tensor], rows_per_batch: int,
-            only_row: Optional[int] = None, teacache=None, cond_flag: bool = True, rows_shared: bool = False) -> torch.Tensor:
+            only_row: Optional[int] = None, teacache=None, cond_flag: bool = True, rows_shared: bool = False, lane: int = 0,
+            fork: Optional[dict] = None) -> torch.Tensor:
         """x [Bx, 48, F, H, W] (Bx = B, or 1 when all rows share the latent); t_rows [R] distinct
         timesteps with R = B * rows_per_batch table rows (rows of batch b are b*rows_per_batch ..);
         row_index int32 [B * L] global table row per token, or None (then token (b, l) uses row b).
-        Returns the head output tokens fp32 [B, Lc, 4*out_dim] of this rank's token chunk."""
+        Returns the head output tokens fp32 [B, Lc, 4*out_dim] of this rank's token chunk.
+        lane / fork: the dual-stream CFG step (pipeline.denoise_step): two single-row runs in flight at once on two streams, each
+        with its own workspace (`lane`).  fork = dict(role, buf, event): the "producer" copies its residual stream behind block 0's
+        self-attention half -- identical for both rows -- into `buf` and records `event`; the "consumer" skips its stem and that
+        half, waits for the event and starts from the copy."""
         cd, dev, d = self.cond, self.device, self.dim
         B, L, lvid, ref_len = cd["B"], cd["L"], cd["lvid"], cd["ref_len"]
         # only_row: run a single conditioning row (cfg_skip: the unconditional row is dropped, cfg_optimization.py:5-37);
@@ -351,14 +360,17 @@ class DiTEngine:
             raise RuntimeError(f"sequence length {L} is not divisible by the sequence-parallel size {sp}")
         lc = L // sp
         tok0 = rank * lc
-        ws = self._workspace(B, lc)
+        ws = self._workspace(B, lc, lane)
+        role = fork["role"] if fork else None
+        if role is not None and not (self.fused and sp == 1 and B == 1 and teacache is None):
+            raise RuntimeError("dual-stream runs are single-row, single-GPU, fused-path runs")
         xres, hbuf, qkv, ao, ffn, head = ws["x"], ws["h"], ws["qkv"], ws["ao"], ws["ffn"], ws["head"]
         xr = xres.view(B, lc, d)
 
         # ---- stem: patch embedding of the noisy latent (+ cached static channels), ref tokens
         bx = x.shape[0]
         full = torch.empty(L, d, device=dev, dtype=F32) if sp > 1 else None
-        for b in range(bx):
+        for b in range(0 if role == "consumer" else bx):
             pa = cd["patch_a"][b if cd["nb"] > 1 else 0]
             hip.patchify(x[b].to(dev).contiguous(), pa, col0=0)
             dst = full if sp > 1 else xr[b]
@@ -430,14 +442,22 @@ class DiTEngine:
             else:
                 T = tab[i]
             fp8_here = self.fp8
+            if i == 0 and role == "consumer":                   # the other stream's run computed this half: start from its copy
+                torch.cuda.current_stream().wait_event(fork["event"])
+                xres.copy_(fork["buf"])
             nb = 1 if (share0 and i == 0) else B               # samples that run the self-attention half of this block (share0: above)
             mb = nb * lc
             ri = row_index[:mb] if row_index is not None else None
-            if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
+            skip_sa = i == 0 and role == "consumer"
+            if skip_sa:
+                pass
+            elif fp8_here:                                 # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
                 a8, sa = self._ln_fp8(xres[:mb], ws, hbuf[:mb], shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
             else:
                 hip.ln_modulate(xres[:mb], out=hbuf[:mb], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
-            if sp > 1 and self.sp_mode == "ulysses":
+            if skip_sa:
+                pass
+            elif sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
                 # returned blocks in place (flexam_amd/dist.py)
                 self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None), qkv)
@@ -458,6 +478,9 @@ class DiTEngine:
                 hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
                 if nb < B:
                     xr[1].copy_(xr[0])
+                if i == 0 and role == "producer":           # the other stream's run starts from here
+                    fork["buf"].copy_(xres)
+                    fork["event"].record(torch.cuda.current_stream())
             # cross-attention on the text context (K/V precomputed per clip)
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
             qc = qkv[:, 0:d]
