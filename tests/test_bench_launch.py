@@ -44,3 +44,30 @@ def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
     assert chk["ok"] and chk["ranks_agree"] and chk["ranks"] == world and chk["worst_rank_rel_rms"] <= chk["tolerance"]
     assert "invalid" in res and "code-path validation" in res["invalid"]      # one device / gloo: not a measurement
     assert res["finite"]
+
+
+@pytest.mark.gpu
+def test_launcher_falls_back_to_the_conservative_exchange_when_the_check_fails():
+    """A failed self-check of the first attempt (forced here) must cost one more attempt with FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0,
+    not the measurement: the forwarded line is the second attempt's, says so, and keeps the first attempt's verdict."""
+    r = _run(["--gpus", "4", *SMALL], {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["launch"]["fallback"] and res["launch"]["attempt"].startswith("FLEXAM_SP_PIECES=1")
+    first = res["launch"]["earlier_attempts"][0]
+    assert first["attempt"] == "default" and first["check"]["ok"] is False and first["check"]["ranks_agree"]
+    assert res["check"]["ok"] and "waited for before attention" in res["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_under_rccl_when_the_box_has_two_gpus():
+    """The driver's own multi-GPU command on real devices (skipped on one-GPU boxes): two ranks, RCCL, the self-check, no fallback."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    r = _run(["--gpus", "2", *SMALL], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["check"]["ok"] and "invalid" not in res
