@@ -116,7 +116,7 @@ def kernel_rooflines(eng, B, L, lc):
     """Live per-launch timing of the hot kernels at this run's shapes, on the engine's own buffers."""
     from flexam_amd import hip
     d, f, nh, hd = eng.dim, eng.ffn, eng.nh, eng.hd
-    ws = eng._ws[(B, lc)]
+    ws = eng._workspace(B, lc)             # the step's own buffers (made here if the step ran another layout, e.g. the dual-stream mode)
     p = eng.blocks[0]
     qkv, ao, hbuf, ffn = ws["qkv"], ws["ao"], ws["h"], ws["ffn"]
     M = B * lc
