@@ -661,10 +661,9 @@ def main():
                                   "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
                                   "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the launches of one call (" + os.path.basename(tpath) + ")",
                                   "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"],
-                                  "launch_note": "one self-attention call = attn_fwd_kernel<0, true> over the full rounds of work units + "
-                                                 "attn_fwd_kernel<0, true> over the last partial round with its keys cut in 3 + attn_merge_kernel; "
-                                                 "launch_ms is the whole call, so rocprofv3 shows 2 attn_fwd_kernel<0, true> rows per call "
-                                                 "(launch_ms = 2 x its AverageNs + the merge)"}
+                                  "launch_note": "one self-attention call = ONE attn_fwd_kernel<0, true> launch (the full rounds of work units and, on the same "
+                                                 "XCDs behind them, the last partial round with its keys cut in 3) + attn_merge_kernel; launch_ms is the whole "
+                                                 "call = its AverageNs in rocprofv3 + the merge (profiles before r3o: two attn_fwd_kernel rows per call)"}
             result["kernels"] = {k: ({"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1), "bound": "mfma",
                                       "peak": PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS,
                                       "frac": round(v["tflops"] / (PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS), 4)} if "flops" in v else

@@ -47,6 +47,11 @@ struct AttnParams {
   // un-normalised O (fp32) and (running max, row sum) to the workspace; attn_merge_kernel combines the splits
   int kv_splits, tiles_per_split;
   int unit0, n_units;   // this launch covers work units (q block, head, batch) unit0 .. unit0 + n_units - 1
+  // whole_units > 0: ONE launch for a split-KV call.  Units 0 .. whole_units - 1 (= unit0) run all keys in one workgroup each and
+  // write O; the n_units units behind them run as kv_splits workgroups each and write partials.  Every XCD gets an eighth of both
+  // kinds, its whole units first: the short workgroups start as the CUs of that XCD finish their last whole unit, without a launch
+  // boundary (and its drain) in between.
+  int whole_units;
   float* ws_o;          // [slots][n_units][256 rows][128]
   float* ws_ml;         // [slots][n_units][256 rows][2]
   // partial: write un-normalised O and (reference, row sum) to workspace slot slot0 + split even with one key range (the keys of
@@ -165,16 +170,31 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const int r = lane & 31, h = lane >> 5;
   if (p.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-  const int nwg = p.n_units * p.kv_splits;
-  int bid = blockIdx.x;
+  // workgroups bid = 8 * local + xcd go to XCD `xcd` in the order of `local`: an XCD walks a contiguous eighth of the work list
+  auto eighth = [](int n, int xcd, int local) -> int {      // index into a list of n items, -1 past this XCD's share
+    const int q = n >> 3, rr = n & 7;
+    if (local >= q + (xcd < rr ? 1 : 0)) return -1;
+    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
+  };
+  int split = 0, ul, unit, tps = p.tiles_per_split, partial = p.partial;
   {
-    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int wmax = (p.whole_units + 7) >> 3;
+    if (local < wmax) {                              // (whole_units = 0: wmax = 0)
+      unit = eighth(p.whole_units, xcd, local);
+      if (unit < 0) return;
+      ul = unit;
+      tps = (p.Lk + KVBLK - 1) / KVBLK;
+      partial = 0;
+    } else {
+      // consecutive workgroups: the units of one split, i.e. q blocks of one head first -> same K/V range in L2
+      const int j = eighth(p.n_units * p.kv_splits, xcd, local - wmax);
+      if (j < 0) return;
+      split = j / p.n_units;
+      ul = j - split * p.n_units;                    // unit index inside the launch's split (or only) part
+      unit = p.unit0 + ul;
+    }
   }
-  // consecutive workgroups: the units of one split, i.e. q blocks of one head first -> same K/V range in L2
-  const int split = bid / p.n_units;
-  const int ul = bid - split * p.n_units;          // unit index inside this launch
-  const int unit = p.unit0 + ul;
   const int qb = unit % p.q_blocks;
   const int bh = unit / p.q_blocks;
   const int head = bh % p.H, b = bh / p.H;
@@ -210,8 +230,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   // ---- LDS-DMA staging: piece id = tid + 512*i (i < 2) lands at LDS byte id*16 of the tile, i.e. row id/16,
   //      slot id%16; it must carry chunk (slot ^ swizzle(row)) of that key row
   const int tiles_all = (p.Lk + KVBLK - 1) / KVBLK;
-  const int t0 = split * p.tiles_per_split;                        // first key tile of this split (0 without split-KV)
-  const int ntiles = min(p.tiles_per_split, tiles_all - t0);       // tiles are indexed locally below; t0 + t is the global tile
+  const int t0 = split * tps;                                      // first key tile of this split (0 without split-KV)
+  const int ntiles = min(tps, tiles_all - t0);       // tiles are indexed locally below; t0 + t is the global tile
   const unsigned k_step = (unsigned)(KVBLK * p.k_rs * 2), v_step = (unsigned)(KVBLK * p.v_rs * 2);
   unsigned k_go[2], v_go[2];
 #pragma unroll
@@ -486,7 +506,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   // ---- epilogue: O[q][32dt + 8i + 4h + (0..3)] = o_acc[dt][4i + (0..3)] / l
   const float l_tot = pair_sum(l_run);
   const int qi = q0 + r;
-  if (p.partial) {                         // partial result of this key range; attn_merge_kernel finishes the softmax
+  if (partial) {                           // partial result of this key range; attn_merge_kernel finishes the softmax
     if (qi < p.Lq) {
       const int64_t row = ((int64_t)(p.slot0 + split) * p.n_units + ul) * QBLK + wave * 32 + r;
       float* orow = p.ws_o + row * HD;
@@ -580,7 +600,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.tiles_per_split = (tiles_all + kv_splits - 1) / kv_splits;
   p.kv_splits = (tiles_all + p.tiles_per_split - 1) / p.tiles_per_split;     // drop empty trailing splits
   p.ws_o = ws_o; p.ws_ml = ws_ml;
-  p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits;
+  p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits; p.whole_units = 0;
   p.last_key_bias = last_key_bias;
   {
     const char* e = getenv("FLEXAM_ATTN_PRIO");           // read per call: tools/ab_attn_prio.py flips it inside one process
@@ -611,6 +631,17 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
     return flexam_check_launch("flexam_attn_fwd_partial");
   }
   if (S == 1) split_from_unit = units;
+  const char* fe = getenv("FLEXAM_ATTN_FUSED_TAIL");     // read per call (A/B in one process); 0 = the two-launch form
+  if (split_from_unit > 0 && split_from_unit < units && (!fe || atoi(fe) != 0)) {
+    // one launch: whole units and the split tail side by side on every XCD (see AttnParams::whole_units), then the merge
+    p.whole_units = split_from_unit;
+    p.unit0 = split_from_unit; p.n_units = units - split_from_unit; p.kv_splits = S; p.tiles_per_split = tps; p.partial = 1; p.n_slots = S;
+    const int grid = 8 * ((p.whole_units + 7) / 8 + (p.n_units * S + 7) / 8);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), smem, (hipStream_t)stream, p);
+    const int64_t g = ((int64_t)p.n_units * QBLK + 3) / 4;
+    hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, p);
+    return flexam_check_launch("flexam_attn_fwd");
+  }
   if (split_from_unit > 0) {               // units [0, split_from_unit): one pass over all keys
     p.unit0 = 0; p.n_units = split_from_unit; p.kv_splits = 1; p.tiles_per_split = tiles_all;
     hipLaunchKernelGGL(kern, dim3(p.n_units), dim3(NT), smem, (hipStream_t)stream, p);

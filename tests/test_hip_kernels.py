@@ -327,6 +327,24 @@ def test_attention_tail_split_matches_single_pass(H):
         assert_bf16_close(out, ref, ulps=2.0, atol=6e-3, msg=f"tail split from unit {from_unit}")
 
 
+@pytest.mark.parametrize("b,h,lq,lk,splits,from_unit", [(2, 3, 700, 1300, 2, 5), (2, 3, 700, 1300, 3, 17), (1, 5, 2600, 900, 4, 9),
+                                                          (1, 24, 1100, 1100, 3, 64), (2, 2, 257, 4100, 5, 3)])
+def test_attention_one_launch_tail_equals_two_launches(H, monkeypatch, b, h, lq, lk, splits, from_unit):
+    """The default form of a split-KV call -- whole units and the split tail in ONE launch, an eighth of both kinds per XCD
+    (AttnParams::whole_units) -- against the two-launch form (FLEXAM_ATTN_FUSED_TAIL=0): same workgroup programs on the same
+    data, so bit-identical; unit counts that are not multiples of 8 leave idle workgroups in the padded grid."""
+    g = torch.Generator().manual_seed(b * 1000 + lq)
+    q = bf(torch.randn(b, lq, h, 128, generator=g)).to(dev())
+    k = bf(torch.randn(b, lk, h, 128, generator=g)).to(dev())
+    v = bf(torch.randn(b, lk, h, 128, generator=g)).to(dev())
+    monkeypatch.setenv("FLEXAM_ATTN_FUSED_TAIL", "0")
+    two = H.attn_fwd(q, k, v, kv_splits=splits, split_from_unit=from_unit).clone()
+    monkeypatch.setenv("FLEXAM_ATTN_FUSED_TAIL", "1")
+    one = H.attn_fwd(q, k, v, kv_splits=splits, split_from_unit=from_unit)
+    assert torch.equal(one, two)
+    assert_bf16_close(one.cpu(), _attn_ref(q.cpu(), k.cpu(), v.cpu()), ulps=2.0, atol=6e-3, msg="one-launch tail vs oracle")
+
+
 def test_attention_split_plan():
     f = __import__("flexam_amd.hip", fromlist=["attn_split_plan"]).attn_split_plan
     assert f(48, 11648, 11648) == (3, 2048)    # one GPU: 2208 units = 8 full rounds + 160 units cut in 3

@@ -4,6 +4,8 @@ import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flexam_amd import hip as H
+if os.environ.get("FLEXAM_AB_LIB"):                         # a probe build instead of the in-tree library
+    H.load_library(os.environ["FLEXAM_AB_LIB"])
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 L, d, f = 11648, 3072, 14336
