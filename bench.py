@@ -402,7 +402,7 @@ def launch_ranks(args):
     for name, extra in attempts:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
-        proc = subprocess.Popen(cmd, env={**env0, **extra}, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        proc = subprocess.Popen(cmd, env={**env0, **extra, "FLEXAM_BENCH_SPAWNED": "1"}, stdout=subprocess.PIPE, text=True, start_new_session=True)
         try:
             out, _ = proc.communicate(timeout=limit)
             rc = proc.returncode
@@ -558,8 +558,25 @@ def main():
     if kern is not None and pipe._state.get("known") is not None:
         kern["cfg_euler_blend"] = sampler_step_roofline(pipe)
     check = None
+    inproc_fallback = None
     if world > 1 and not args.no_check:
         check = multi_gpu_check(pipe, model, inp, cond, (args.warmup + args.steps) % total_steps, total_steps, world, rank)
+        # Started by someone else's torch.distributed.run (not by launch_ranks, which has its own second attempt): a failed check of
+        # the default exchange gets ONE more measurement in this process on the conservative form of the same exchange -- one K|V
+        # all-gather per block, waited for before attention.  Every rank takes the same decision (check.ok is built from all-gathered
+        # values); the engine is rebuilt on its next use (multi_gpu_check leaves model._engine = None) and reads the switches again.
+        if (not check["ok"] and os.environ.get("FLEXAM_BENCH_SPAWNED") != "1" and eng.sp_size > 1
+                and "FLEXAM_SP_OVERLAP" not in os.environ and "FLEXAM_SP_PIECES" not in os.environ):
+            inproc_fallback = {"attempt": "default", "check": check, "ms_per_step": elapsed / args.steps * 1e3}
+            os.environ["FLEXAM_SP_PIECES"], os.environ["FLEXAM_SP_OVERLAP"] = "1", "0"
+            pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+            eng = model.engine()
+            elapsed = timed(pipe)
+            tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+            finite = bool(torch.isfinite(pipe._state["latents"]).all())
+            check = multi_gpu_check(pipe, model, inp, cond, (args.warmup + args.steps) % total_steps, total_steps, world, rank)
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(L, cfg)
@@ -642,6 +659,9 @@ def main():
             result["configs1_same_process"] = {"ms_per_step": motion_elapsed / args.steps * 1e3, "value": args.steps / motion_elapsed,
                                                "delta_pct": (elapsed / motion_elapsed - 1.0) * 100.0,
                                                "note": "the same steps on the motion_transfer conditioning (BASELINE configs[1]) in this process"}
+        if inproc_fallback is not None:
+            result["launch"] = {"spawned_by": "the caller's torch.distributed.run", "attempt": "FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0 (second measurement in the same processes)",
+                                "earlier_attempts": [inproc_fallback], "fallback": True}
         if check is not None:
             result["check"] = check
             result["rccl_ranks"] = world if backend == "nccl" else 0

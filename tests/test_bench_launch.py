@@ -61,6 +61,40 @@ def test_launcher_falls_back_to_the_conservative_exchange_when_the_check_fails()
     assert res["check"]["ok"] and "waited for before attention" in res["config"]["parallelism"]
 
 
+def _torchrun(world, args, env_extra, timeout=900):
+    """The other way the driver may start it: `python -m torch.distributed.run ... bench.py --gpus N` (ranks are not bench.py's children)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FLEXAM_BENCH_SPAWNED"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), *args]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_ranks_started_by_torchrun_remeasure_on_the_conservative_exchange_when_the_check_fails():
+    """Under the caller's own torch.distributed.run there is no parent to start a second attempt: a failed self-check (forced) makes the
+    SAME processes switch to FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0, measure again and check again; the line keeps the first verdict."""
+    r = _torchrun(4, SMALL, {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["launch"]["fallback"] and res["launch"]["attempt"].startswith("FLEXAM_SP_PIECES=1")
+    first = res["launch"]["earlier_attempts"][0]
+    assert first["attempt"] == "default" and first["check"]["ok"] is False and first["ms_per_step"] > 0
+    assert res["check"]["ok"] and res["check"]["ranks_agree"] and "waited for before attention" in res["config"]["parallelism"]
+    r = _torchrun(2, SMALL, {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo"})       # and the plain case: no launch object, check ok
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][0])
+    assert "launch" not in res and res["check"]["ok"] and res["n_gpus"] == 2
+
+
 @pytest.mark.gpu
 def test_bench_under_rccl_when_the_box_has_two_gpus():
     """The driver's own multi-GPU command on real devices (skipped on one-GPU boxes): two ranks, RCCL, the self-check, no fallback."""
