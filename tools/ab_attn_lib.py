@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flexam_amd import hip as H
 here = os.path.dirname(os.path.abspath(__file__))
-libs = {"A": os.path.join(here, "probes", "libflexam_ab_base.so"), "B": H.LIB_PATH}
+libs = {"A": os.environ.get("FLEXAM_AB_A", os.path.join(here, "probes", "libflexam_ab_base.so")), "B": os.environ.get("FLEXAM_AB_B", H.LIB_PATH)}
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 L, d, T = 11648, 3072, 512
