@@ -427,7 +427,9 @@ def launch_ranks(args):
         last_rc, last_line = rc, line
         if ok:
             break
-        notes.append({"attempt": name, "rc": rc, "check": (json.loads(line).get("check") if line else None)})
+        failed = json.loads(line) if line else {}
+        notes.append({"attempt": name, "rc": rc, "check": failed.get("check"), "parallelism": failed.get("config", {}).get("parallelism"),
+                      "layout_probe": failed.get("layout_probe")})
     if last_line is not None:
         print(last_line, flush=True)
     sys.exit(last_rc if last_rc != 0 else (0 if last_line is not None else 1))
@@ -494,6 +496,39 @@ def main():
                                      ref_latents=i["ref"], mask_latents=i["mask_latents"], mask=i["mask"], mask_pixels=i["mask_pixels"])
     inp, cond = conditioning(args.mask)
     total_steps = 50
+    # N >= 4 and nothing pinned by the caller: which exchange is faster depends on what the links of THIS node deliver (the K|V
+    # all-gather moves N/2 times the bytes of the all-to-all over heads but hides part of them; the all-to-all uses every link of
+    # the mesh when the CFG pair is batched).  Two steps of each candidate layout on the real fabric decide; the line says so.
+    layout_probe = None
+    pinned = [k for k in ("FLEXAM_SP_MODE", "FLEXAM_CFG_PARALLEL", "FLEXAM_SP_OVERLAP", "FLEXAM_SP_PIECES") if k in os.environ]
+    if world >= 4 and not pinned and os.environ.get("FLEXAM_BENCH_LAYOUT_PROBE", "1") != "0":
+        cands = [(f"cfg2 x sp{world // 2}, K|V all-gather", "allgather", True)]
+        if cfg["num_heads"] % world == 0:
+            cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples pipelined", "ulysses", False))
+        if cfg["num_heads"] % (world // 2) == 0:
+            cands.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True))
+        layout_probe = {"candidates": [], "steps": 2}
+        for name, mode, cfgp in cands:
+            os.environ["FLEXAM_SP_MODE"] = mode
+            model.enable_multi_gpus_inference(cfg_parallel=cfgp)
+            model._engine = None                          # the engine (buffers, per-clip state) is rebuilt for the layout on its next use
+            pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+            pipe.denoise_step(0)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            tq = time.perf_counter()
+            for i in range(2):
+                pipe.denoise_step(1 + i)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - tq], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp})
+        best = min(layout_probe["candidates"], key=lambda c: c["ms_per_step"])       # identical on every rank (all-reduced times)
+        if os.environ.get("FLEXAM_BENCH_LAYOUT_FORCE"):                              # test hook: run candidate i whatever the probe measured
+            best = layout_probe["candidates"][int(os.environ["FLEXAM_BENCH_LAYOUT_FORCE"])]
+        layout_probe["chosen"] = best["layout"]
+        os.environ["FLEXAM_SP_MODE"] = best["mode"]
+        model.enable_multi_gpus_inference(cfg_parallel=best["cfg_parallel"])
+        model._engine = None
     pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
     torch.cuda.synchronize()
     tp0 = time.perf_counter()                       # second call: buffers exist, this is the per-clip cost of the step-invariant work
@@ -591,7 +626,9 @@ def main():
                     ("each consumed as it lands: Q projection + local-chunk attention under piece 0 (partial softmaxes merged), piece g+1 under the attention of group g"
                      if getattr(eng, "sp_overlap", False) else "waited for before attention (overlaps the Q projection only)"))
     elif eng_mode == "ulysses":
-        eng_mode = "all-to-all over heads (q|k|v out, attention output back)"
+        eng_mode = "all-to-all over heads (q|k|v out, attention output back)" + (
+            ", the samples of the CFG pair as pipeline stages: a sample's blocks travel under the other's projection / attention"
+            if (b_local > 1 and getattr(eng, "sp_overlap", False)) else "")
     vae_sec = enc_sec = enc_stream_sec = None
     clip = None
     if rank == 0 and world == 1 and not args.no_vae:
@@ -659,6 +696,8 @@ def main():
             result["configs1_same_process"] = {"ms_per_step": motion_elapsed / args.steps * 1e3, "value": args.steps / motion_elapsed,
                                                "delta_pct": (elapsed / motion_elapsed - 1.0) * 100.0,
                                                "note": "the same steps on the motion_transfer conditioning (BASELINE configs[1]) in this process"}
+        if layout_probe is not None:
+            result["layout_probe"] = layout_probe
         if inproc_fallback is not None:
             result["launch"] = {"spawned_by": "the caller's torch.distributed.run", "attempt": "FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0 (second measurement in the same processes)",
                                 "earlier_attempts": [inproc_fallback], "fallback": True}

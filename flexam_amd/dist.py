@@ -85,13 +85,15 @@ def all_to_all_chunks(out: torch.Tensor, inp: torch.Tensor, group=None, async_op
     return None
 
 
-def all_to_all_blocks(outs, ins, group=None):
+def all_to_all_blocks(outs, ins, group=None, async_op: bool = False):
     """ins[j] (contiguous) goes to rank j, outs[i] (contiguous, anywhere in memory) receives rank i's block: the list form lets
     every received block land where the consumer wants it (no unpack pass).  RCCL: one grouped send/recv (dist.all_to_all);
-    other backends (the gloo runs of the tests): the same result from an all-gather of every rank's stacked blocks."""
+    async_op = True returns its Work (wait() makes the caller's stream wait for the exchange), so the next sample's exchange
+    travels under this sample's attention.  Other backends (the gloo runs of the tests): the same result from an all-gather of
+    every rank's stacked blocks, finished before returning (None: nothing to wait for)."""
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "nccl":
-        return dist.all_to_all(list(outs), list(ins), group=group)
+        return dist.all_to_all(list(outs), list(ins), group=group, async_op=async_op)
     rank = dist.get_rank(group)
     mine = torch.stack([t.contiguous() for t in ins])                      # [dst, ...]
     everything = torch.empty((world,) + tuple(mine.shape), device=mine.device, dtype=mine.dtype)

@@ -460,8 +460,7 @@ class DiTEngine:
             elif sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
                 # returned blocks in place (flexam_amd/dist.py)
-                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None), qkv)
-                a_o, koff_o = self._ulysses_attention(qkv, p, B, lc, tok0)
+                a_o, koff_o = self._ulysses_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, B, lc, tok0)
                 hip.gemm_gate_residual(a_o, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb, a_koff=koff_o)
             elif sp > 1:
                 # K|V projection + K norm/RoPE first, written straight into the send buffer; their all-gather (RCCL over xGMI)
@@ -565,13 +564,18 @@ class DiTEngine:
         return calc
 
     # ------------------------------------------------------------------ sequence parallel
-    def _ulysses_attention(self, qkv, p, B, lc, tok0):
-        """qkv [B*lc, 3C] (this rank's tokens, all heads, straight from the projection) -> (A base view, per-K-block A offsets)
-        of the attention output for the o-projection.  Head group j = heads j*H/sp .. goes to rank j.
+    def _ulysses_attention(self, qkv, hbuf, a8sa, layer, p, B, lc, tok0):
+        """h [B*lc, C] (LayerNorm output of this rank's tokens) -> q|k|v projection -> exchange -> attention -> exchange back ->
+        (A base view, per-K-block A offsets) of the attention output for the o-projection.  Head group j = heads j*H/sp .. goes
+        to rank j.
         Send layout [B, sp, lc, 3*G] (G = H/sp * head_dim): written by the RMSNorm+RoPE launch itself (q, k normed + rotated, v
         copied), block (b, j) goes to rank j.  Receive layout [B, sp, lc, 3*G] = [B, L, 3*G]: rank-major blocks ARE the token
         order, so attention addresses it with plain strides.  Its output [B, L, G] is cut into the sp token chunks that go back;
-        rank j's block returns to [j, B, lc, G], which the o-projection reads as A[m, j*G + c] through its K-block offsets."""
+        rank j's block returns to [j, B, lc, G], which the o-projection reads as A[m, j*G + c] through its K-block offsets.
+        With several samples per rank (the CFG pair batched: pure N-way chunks) the samples are pipeline stages
+        (FLEXAM_SP_OVERLAP, default on): sample b's q|k|v leave as soon as ITS projection and norm are done and travel under
+        the projection of sample b + 1; its attention runs while sample b + 1's blocks arrive and sample b - 1's output
+        returns -- every peer link carries 1/N of a sample at a time, and only the last return is not under compute."""
         from .dist import all_to_all_blocks
         sp, nh, hd, d, dev = self.sp_size, self.nh, self.hd, self.dim, self.device
         hg = nh // sp
@@ -586,17 +590,37 @@ class DiTEngine:
             ws["a2a_koff"] = torch.tensor([(kb * 64 // G) * (B * lc * G) + (kb * 64) % G for kb in range(d // 64)], dtype=I64, device=dev)
         cd = self.cond
         send, recv, out, recv2 = ws["a2a_send"], ws["a2a_recv"], ws["a2a_out"], ws["a2a_recv2"]
-        flat = send.view(-1)
-        hip.rmsnorm_rope_scatter(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], qkv[:, 2 * d:], flat, flat[G:], flat[2 * G:],
-                                 ld_out=W, out_bs=sp * lc * W, col_block=G, block_stride=lc * W, eps=self.eps, rope_cos=cd["cos"],
-                                 rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
-        for b in range(B):
-            all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group)
         full = recv.view(B, sp * lc, 3, hg, hd)
-        hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=out, prescaled=True)
         chunks = out.view(B, sp, lc, G)
+
+        def project_and_pack(rows, b0, nb):          # samples b0 .. b0 + nb - 1: rows of h -> q|k|v -> normed / rotated send blocks
+            a8 = a8sa and (a8sa[0][rows], a8sa[1][rows])
+            self._proj(hbuf[rows], a8, layer, p, "wqkv", "bqkv", slice(None), qkv[rows])
+            flat = send[b0:b0 + nb].view(-1)
+            hip.rmsnorm_rope_scatter(qkv[rows, 0:d], p["nq"], qkv[rows, d:2 * d], p["nk"], qkv[rows, 2 * d:], flat, flat[G:], flat[2 * G:],
+                                     ld_out=W, out_bs=sp * lc * W, col_block=G, block_stride=lc * W, eps=self.eps, rope_cos=cd["cos"],
+                                     rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
+
+        if B == 1 or not self.sp_overlap:
+            project_and_pack(slice(None), 0, B)
+            for b in range(B):
+                all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group)
+            hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=out, prescaled=True)
+            for b in range(B):
+                all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group)
+            return recv2.view(sp * B * lc, G), ws["a2a_koff"]
+        there, back = [], []
         for b in range(B):
-            all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group)
+            project_and_pack(slice(b * lc, (b + 1) * lc), b, 1)
+            there.append(all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group, async_op=True))
+        for b in range(B):
+            if there[b] is not None:
+                there[b].wait()
+            hip.attn_fwd(full[b:b + 1, :, 0], full[b:b + 1, :, 1], full[b:b + 1, :, 2], out=out[b:b + 1], prescaled=True)
+            back.append(all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True))
+        for w in back:
+            if w is not None:
+                w.wait()
         return recv2.view(sp * B * lc, G), ws["a2a_koff"]
 
     @staticmethod
@@ -648,7 +672,11 @@ class DiTEngine:
         hip.rmsnorm_rope_scatter(None, None, qkv[:, d:2 * d], p["nk"], qkv[:, 2 * d:], None, flat, flat[cb:], ld_out=2 * cb, out_bs=lc * 2 * cb,
                                  col_block=cb, block_stride=B * lc * 2 * cb, eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
                                  tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
-        works = [[dist.all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=True) for b in range(B)] for g in range(G)]
+        # RCCL runs the pieces one after the other on its own stream, in the order they are issued here.  The host-staged backends of the
+        # test runs (gloo) execute several in-flight collectives of one group on concurrent worker threads, which is not what is being
+        # modelled (and delivered wrong chunks intermittently with 8 ranks on one device): there each gather completes before the next.
+        overlapped = dist.get_backend(self.sp_group) == "nccl"
+        works = [[dist.all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=overlapped) for b in range(B)] for g in range(G)]
         self._proj(hbuf, a8sa, layer, p, "wqkv", "bqkv", slice(0, d), qkv[:, 0:d])
         hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0,
                          head_dim=hd)
@@ -658,13 +686,15 @@ class DiTEngine:
             kc, vc = cat[g, :, :, 0:cb], cat[g, :, :, cb:]
             if g > 0 or not self.sp_overlap:
                 for w in works[g]:
-                    w.wait()
+                    if w is not None:
+                        w.wait()
                 hip.attn_fwd(qg, heads(kc), heads(vc), out=og, prescaled=True)
                 continue
             s_loc, s_before, s_after = ws["kv_splits"]
             n = hip.attn_fwd_partial(qg, heads(send[0, :, :, 0:cb]), heads(send[0, :, :, cb:]), ws["kv_part"], 0, s_loc, prescaled=True)
             for w in works[0]:
-                w.wait()
+                if w is not None:
+                    w.wait()
             if tok0 > 0:
                 n += hip.attn_fwd_partial(qg, heads(kc[:, :tok0]), heads(vc[:, :tok0]), ws["kv_part"], n, s_before, prescaled=True)
             if tok0 + lc < L:

@@ -44,6 +44,12 @@ def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
     assert chk["ok"] and chk["ranks_agree"] and chk["ranks"] == world and chk["worst_rank_rel_rms"] <= chk["tolerance"]
     assert "invalid" in res and "code-path validation" in res["invalid"]      # one device / gloo: not a measurement
     assert res["finite"]
+    if world >= 4 and not env:             # nothing pinned: two steps of every candidate layout were timed and the fastest one ran
+        lp = res["layout_probe"]
+        assert len(lp["candidates"]) == 3 and lp["chosen"] in [c["layout"] for c in lp["candidates"]]
+        assert all(c["ms_per_step"] > 0 for c in lp["candidates"])
+    else:
+        assert "layout_probe" not in res
 
 
 @pytest.mark.gpu

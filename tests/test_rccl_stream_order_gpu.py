@@ -63,6 +63,15 @@ def _worker(port, ret):
             all_to_all_blocks([cat], [send], None)
             hip.axpby(acc, 2.0, cat, 1.0)                        # acc += 2 * (-(i + 1) * base)
         ok_a2a = bool(torch.equal(acc, base * (-36)))
+        acc.zero_(); acc_side.zero_()
+        for i in range(8):                                       # the pipelined all-to-all exchange: async grouped send / recv, waited for later
+            hip.axpby(send, float(i + 1), base, 0.0)
+            w = all_to_all_blocks([cat], [send], None, async_op=True)
+            hip.axpby(side, 1.0, send, 0.0)
+            hip.axpby(acc_side, 1.0, side, 1.0)
+            w.wait()
+            hip.axpby(acc, 1.0, cat, 1.0)
+        ok_a2a = ok_a2a and bool(torch.equal(acc, base * 36)) and bool(torch.equal(acc_side, base * 36))
         ret["ok"] = (ok_gather, ok_seq, ok_a2a)
     finally:
         dist.destroy_process_group()
