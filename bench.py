@@ -502,14 +502,15 @@ def main():
     layout_probe = None
     pinned = [k for k in ("FLEXAM_SP_MODE", "FLEXAM_CFG_PARALLEL", "FLEXAM_SP_OVERLAP", "FLEXAM_SP_PIECES") if k in os.environ]
     if world >= 4 and not pinned and os.environ.get("FLEXAM_BENCH_LAYOUT_PROBE", "1") != "0":
-        cands = [(f"cfg2 x sp{world // 2}, K|V all-gather", "allgather", True)]
+        cands = [(f"cfg2 x sp{world // 2}, K|V all-gather", "allgather", True, "1")]
         if cfg["num_heads"] % world == 0:
-            cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples pipelined", "ulysses", False))
+            cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples pipelined", "ulysses", False, "1"))
+            cands.append((f"cfg1 x sp{world}, all-to-all over heads, one exchange for the pair", "ulysses", False, "0"))
         if cfg["num_heads"] % (world // 2) == 0:
-            cands.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True))
+            cands.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, "1"))
         layout_probe = {"candidates": [], "steps": 2}
-        for name, mode, cfgp in cands:
-            os.environ["FLEXAM_SP_MODE"] = mode
+        for name, mode, cfgp, ovl in cands:
+            os.environ["FLEXAM_SP_MODE"], os.environ["FLEXAM_SP_OVERLAP"] = mode, ovl
             model.enable_multi_gpus_inference(cfg_parallel=cfgp)
             model._engine = None                          # the engine (buffers, per-clip state) is rebuilt for the layout on its next use
             pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
@@ -521,12 +522,16 @@ def main():
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
             tt = torch.tensor([time.perf_counter() - tq], device=device, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp})
+            layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp, "overlap": ovl})
         best = min(layout_probe["candidates"], key=lambda c: c["ms_per_step"])       # identical on every rank (all-reduced times)
         if os.environ.get("FLEXAM_BENCH_LAYOUT_FORCE"):                              # test hook: run candidate i whatever the probe measured
             best = layout_probe["candidates"][int(os.environ["FLEXAM_BENCH_LAYOUT_FORCE"])]
         layout_probe["chosen"] = best["layout"]
         os.environ["FLEXAM_SP_MODE"] = best["mode"]
+        if best["overlap"] == "1":
+            os.environ.pop("FLEXAM_SP_OVERLAP", None)      # the default; left unset so that a failed self-check can still fall back to 0
+        else:
+            os.environ["FLEXAM_SP_OVERLAP"] = "0"
         model.enable_multi_gpus_inference(cfg_parallel=best["cfg_parallel"])
         model._engine = None
     pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)

@@ -46,7 +46,7 @@ def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
     assert res["finite"]
     if world >= 4 and not env:             # nothing pinned: two steps of every candidate layout were timed and the fastest one ran
         lp = res["layout_probe"]
-        assert len(lp["candidates"]) == 3 and lp["chosen"] in [c["layout"] for c in lp["candidates"]]
+        assert len(lp["candidates"]) == 4 and lp["chosen"] in [c["layout"] for c in lp["candidates"]]
         assert all(c["ms_per_step"] > 0 for c in lp["candidates"])
     else:
         assert "layout_probe" not in res
