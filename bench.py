@@ -361,7 +361,7 @@ def multi_gpu_check(pipe, model, inp, cond, step_index, total_steps, world, rank
     dist.all_gather_object(rels, rel)
     worst = max(rels)
     ok = bool(agree and worst <= tol and math.isfinite(worst))
-    if os.environ.get("FLEXAM_BENCH_FORCE_CHECK_FAIL") == "1" and "FLEXAM_SP_OVERLAP" not in os.environ:
+    if os.environ.get("FLEXAM_BENCH_FORCE_CHECK_FAIL") == "1" and os.environ.get("FLEXAM_SP_OVERLAP") != "0":
         ok = False                       # test hook (tests/test_bench_launch.py): exercises the launcher's fallback attempt
     return {"ok": ok, "ranks": world, "ranks_agree": bool(agree), "rel_rms_vs_single_gpu": rel, "worst_rank_rel_rms": worst, "tolerance": tol,
             "what": "DiT head output of one denoise step per CFG row (before the guidance combine): N-rank layout vs the same step on "
@@ -504,8 +504,8 @@ def main():
     if world >= 4 and not pinned and os.environ.get("FLEXAM_BENCH_LAYOUT_PROBE", "1") != "0":
         cands = [(f"cfg2 x sp{world // 2}, K|V all-gather", "allgather", True, "1")]
         if cfg["num_heads"] % world == 0:
-            cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples pipelined", "ulysses", False, "1"))
-            cands.append((f"cfg1 x sp{world}, all-to-all over heads, one exchange for the pair", "ulysses", False, "0"))
+            cands.append((f"cfg1 x sp{world}, all-to-all over heads, a sample's blocks leave under the other's projection", "ulysses", False, "1"))
+            cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples fully pipelined (attention per sample)", "ulysses", False, "2"))
         if cfg["num_heads"] % (world // 2) == 0:
             cands.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, "1"))
         layout_probe = {"candidates": [], "steps": 2}
@@ -531,7 +531,7 @@ def main():
         if best["overlap"] == "1":
             os.environ.pop("FLEXAM_SP_OVERLAP", None)      # the default; left unset so that a failed self-check can still fall back to 0
         else:
-            os.environ["FLEXAM_SP_OVERLAP"] = "0"
+            os.environ["FLEXAM_SP_OVERLAP"] = best["overlap"]
         model.enable_multi_gpus_inference(cfg_parallel=best["cfg_parallel"])
         model._engine = None
     pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
@@ -605,8 +605,7 @@ def main():
         # the default exchange gets ONE more measurement in this process on the conservative form of the same exchange -- one K|V
         # all-gather per block, waited for before attention.  Every rank takes the same decision (check.ok is built from all-gathered
         # values); the engine is rebuilt on its next use (multi_gpu_check leaves model._engine = None) and reads the switches again.
-        if (not check["ok"] and os.environ.get("FLEXAM_BENCH_SPAWNED") != "1" and eng.sp_size > 1
-                and "FLEXAM_SP_OVERLAP" not in os.environ and "FLEXAM_SP_PIECES" not in os.environ):
+        if not check["ok"] and os.environ.get("FLEXAM_BENCH_SPAWNED") != "1" and eng.sp_size > 1 and not pinned:
             inproc_fallback = {"attempt": "default", "check": check, "ms_per_step": elapsed / args.steps * 1e3}
             os.environ["FLEXAM_SP_PIECES"], os.environ["FLEXAM_SP_OVERLAP"] = "1", "0"
             pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
@@ -631,9 +630,11 @@ def main():
                     ("each consumed as it lands: Q projection + local-chunk attention under piece 0 (partial softmaxes merged), piece g+1 under the attention of group g"
                      if getattr(eng, "sp_overlap", False) else "waited for before attention (overlaps the Q projection only)"))
     elif eng_mode == "ulysses":
+        lvl = getattr(eng, "sp_overlap_level", 0)
         eng_mode = "all-to-all over heads (q|k|v out, attention output back)" + (
-            ", the samples of the CFG pair as pipeline stages: a sample's blocks travel under the other's projection / attention"
-            if (b_local > 1 and getattr(eng, "sp_overlap", False)) else "")
+            (", a sample's blocks leave under the other sample's projection, one attention call for the pair" if lvl == 1 else
+             ", the samples of the CFG pair as pipeline stages: a sample's blocks travel under the other's projection / attention")
+            if (b_local > 1 and lvl > 0) else "")
     vae_sec = enc_sec = enc_stream_sec = None
     clip = None
     if rank == 0 and world == 1 and not args.no_vae:

@@ -160,7 +160,8 @@ class DiTEngine:
             raise ValueError(f"FLEXAM_SP_MODE={mode!r}: expected 'ulysses' or 'allgather'")
         self.sp_mode = mode if (mode == "allgather" or self.nh % max(sp_size, 1) == 0) else "allgather"
         # local-chunk-first attention under the K|V all-gather (0: wait for the gather, then one attention call)
-        self.sp_overlap = os.environ.get("FLEXAM_SP_OVERLAP", "1") != "0"
+        self.sp_overlap_level = int(os.environ.get("FLEXAM_SP_OVERLAP", "1"))      # all-to-all mode: 1 / 2, see _ulysses_attention
+        self.sp_overlap = self.sp_overlap_level != 0
         # the K|V gather is cut into `sp_pieces` groups of heads, one collective each: the attention of a group starts when ITS
         # piece has landed, the later pieces travel underneath it (1: one gather per block and CFG row)
         # Default: 2 pieces from 4 chunks on (3+ peers: the gather outlasts the Q projection + local-chunk attention it hides under),
@@ -572,10 +573,12 @@ class DiTEngine:
         copied), block (b, j) goes to rank j.  Receive layout [B, sp, lc, 3*G] = [B, L, 3*G]: rank-major blocks ARE the token
         order, so attention addresses it with plain strides.  Its output [B, L, G] is cut into the sp token chunks that go back;
         rank j's block returns to [j, B, lc, G], which the o-projection reads as A[m, j*G + c] through its K-block offsets.
-        With several samples per rank (the CFG pair batched: pure N-way chunks) the samples are pipeline stages
-        (FLEXAM_SP_OVERLAP, default on): sample b's q|k|v leave as soon as ITS projection and norm are done and travel under
-        the projection of sample b + 1; its attention runs while sample b + 1's blocks arrive and sample b - 1's output
-        returns -- every peer link carries 1/N of a sample at a time, and only the last return is not under compute."""
+        With several samples per rank (the CFG pair batched: pure N-way chunks) the samples are stages of the outbound exchange
+        (FLEXAM_SP_OVERLAP=1, default): sample b's q|k|v leave as soon as ITS projection and norm are done and travel under the
+        projection of sample b + 1; ONE attention call for the pair follows the last arrival (two calls of half the work units fill
+        256 CUs a quarter worse than one), then the outputs return.  FLEXAM_SP_OVERLAP=2 pipelines the attention too: sample b's
+        call runs while sample b + 1's blocks arrive and sample b - 1's output returns -- only the last return is not under compute;
+        it pays when a link is slower than the ~0.1 ms the two smaller attention calls cost (about 35 GB/s at 8 GPUs)."""
         from .dist import all_to_all_blocks
         sp, nh, hd, d, dev = self.sp_size, self.nh, self.hd, self.dim, self.device
         hg = nh // sp
@@ -613,6 +616,17 @@ class DiTEngine:
         for b in range(B):
             project_and_pack(slice(b * lc, (b + 1) * lc), b, 1)
             there.append(all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group, async_op=True))
+        if self.sp_overlap_level < 2:
+            for w in there:
+                if w is not None:
+                    w.wait()
+            hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=out, prescaled=True)
+            back = [all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True)
+                    for b in range(B)]
+            for w in back:
+                if w is not None:
+                    w.wait()
+            return recv2.view(sp * B * lc, G), ws["a2a_koff"]
         for b in range(B):
             if there[b] is not None:
                 there[b].wait()

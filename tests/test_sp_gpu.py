@@ -109,12 +109,16 @@ def test_multi_rank_layouts_match_single_process(golden, world, cfg_parallel, mo
     assert bool(torch.isfinite(lat0).all())
 
 
-def test_four_ranks_pure_ulysses_matches_single_process(monkeypatch):
+@pytest.mark.parametrize("overlap", ["1", "2", "0"])
+def test_four_ranks_pure_ulysses_matches_single_process(monkeypatch, overlap):
     """Four heads, four ranks, FLEXAM_SP_MODE=ulysses: pure sequence parallelism with the all-to-all exchange and the CFG pair
     batched on every rank (send layout written by the RMSNorm+RoPE launch, returned blocks read in place by the o-projection).
     No reference golden for this width: the check is against the single-process HIP result of the same model and inputs, for the
     DiT forward and a 2-step sampler run."""
+    # overlap 1: a sample's blocks leave under the other sample's projection, one attention call for the pair; 2: attention per sample
+    # too (full pipeline); 0: one projection, one exchange, one attention call
     monkeypatch.setenv("FLEXAM_SP_MODE", "ulysses")
+    monkeypatch.setenv("FLEXAM_SP_OVERLAP", overlap)
     world = 4
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
