@@ -25,13 +25,13 @@ def _free_port():
 @pytest.mark.parametrize("world,cfg_parallel,mode", [
     (2, None, "allgather"), (2, False, "allgather"), (2, False, "ulysses"),
     (4, None, "allgather"), (4, False, "allgather"), (4, False, "allgather-p1-wait"), (4, None, "ulysses"), (4, False, "ulysses"),
-    (8, None, "allgather"), (8, False, "allgather"), (8, None, "ulysses")])
+    (8, None, "allgather"), (8, False, "allgather"), (8, None, "ulysses"), (4, False, "ulysses-o2"), (8, False, "ulysses-o2")])
 def test_ranks_under_rccl_match_single_process(world, cfg_parallel, mode, monkeypatch):
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs >= {world} GPUs (RCCL refuses two ranks on one device)")
     from test_sp_gpu import _wide_cfg, _worker
     monkeypatch.setenv("FLEXAM_SP_MODE", mode.split("-")[0])
-    monkeypatch.setenv("FLEXAM_SP_OVERLAP", "0" if mode.endswith("-wait") else "1")
+    monkeypatch.setenv("FLEXAM_SP_OVERLAP", "0" if mode.endswith("-wait") else ("2" if mode.endswith("-o2") else "1"))   # -o2: attention per sample too
     monkeypatch.setenv("FLEXAM_SP_PIECES", "1" if "-p1" in mode else "2")
     monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sp = world // 2 if (cfg_parallel is None and world % 2 == 0 and (world == 2 or not mode.startswith("ulysses"))) else world
