@@ -511,18 +511,21 @@ def main():
         layout_probe = {"candidates": [], "steps": 2}
         for name, mode, cfgp, ovl in cands:
             os.environ["FLEXAM_SP_MODE"], os.environ["FLEXAM_SP_OVERLAP"] = mode, ovl
-            model.enable_multi_gpus_inference(cfg_parallel=cfgp)
-            model._engine = None                          # the engine (buffers, per-clip state) is rebuilt for the layout on its next use
-            pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
-            pipe.denoise_step(0)
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            tq = time.perf_counter()
-            for i in range(2):
-                pipe.denoise_step(1 + i)
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-            tt = torch.tensor([time.perf_counter() - tq], device=device, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp, "overlap": ovl})
+            try:                                          # a layout this build refuses (raised identically on every rank) is skipped, not fatal
+                model.enable_multi_gpus_inference(cfg_parallel=cfgp)
+                model._engine = None                      # the engine (buffers, per-clip state) is rebuilt for the layout on its next use
+                pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+                pipe.denoise_step(0)
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                tq = time.perf_counter()
+                for i in range(2):
+                    pipe.denoise_step(1 + i)
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                tt = torch.tensor([time.perf_counter() - tq], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp, "overlap": ovl})
+            except (NotImplementedError, ValueError) as e:
+                layout_probe.setdefault("skipped", []).append({"layout": name, "error": f"{type(e).__name__}: {e}"})
         best = min(layout_probe["candidates"], key=lambda c: c["ms_per_step"])       # identical on every rank (all-reduced times)
         if os.environ.get("FLEXAM_BENCH_LAYOUT_FORCE"):                              # test hook: run candidate i whatever the probe measured
             best = layout_probe["candidates"][int(os.environ["FLEXAM_BENCH_LAYOUT_FORCE"])]
