@@ -502,15 +502,20 @@ def main():
     layout_probe = None
     pinned = [k for k in ("FLEXAM_SP_MODE", "FLEXAM_CFG_PARALLEL", "FLEXAM_SP_OVERLAP", "FLEXAM_SP_PIECES") if k in os.environ]
     if world >= 4 and not pinned and os.environ.get("FLEXAM_BENCH_LAYOUT_PROBE", "1") != "0":
-        cands = [(f"cfg2 x sp{world // 2}, K|V all-gather", "allgather", True, "1")]
+        cands = [(f"cfg2 x sp{world // 2}, K|V all-gather", "allgather", True, "1", None)]
+        if world // 2 >= 4:
+            cands.append((f"cfg2 x sp{world // 2}, K|V all-gather in one piece", "allgather", True, "1", "1"))
         if cfg["num_heads"] % world == 0:
-            cands.append((f"cfg1 x sp{world}, all-to-all over heads, a sample's blocks leave under the other's projection", "ulysses", False, "1"))
-            cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples fully pipelined (attention per sample)", "ulysses", False, "2"))
+            cands.append((f"cfg1 x sp{world}, all-to-all over heads, a sample's blocks leave under the other's projection", "ulysses", False, "1", None))
+            cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples fully pipelined (attention per sample)", "ulysses", False, "2", None))
         if cfg["num_heads"] % (world // 2) == 0:
-            cands.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, "1"))
+            cands.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, "1", None))
         layout_probe = {"candidates": [], "steps": 2}
-        for name, mode, cfgp, ovl in cands:
+        for name, mode, cfgp, ovl, pcs in cands:
             os.environ["FLEXAM_SP_MODE"], os.environ["FLEXAM_SP_OVERLAP"] = mode, ovl
+            os.environ.pop("FLEXAM_SP_PIECES", None)
+            if pcs is not None:
+                os.environ["FLEXAM_SP_PIECES"] = pcs
             try:                                          # a layout this build refuses (raised identically on every rank) is skipped, not fatal
                 model.enable_multi_gpus_inference(cfg_parallel=cfgp)
                 model._engine = None                      # the engine (buffers, per-clip state) is rebuilt for the layout on its next use
@@ -523,7 +528,7 @@ def main():
                 torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
                 tt = torch.tensor([time.perf_counter() - tq], device=device, dtype=torch.float64)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp, "overlap": ovl})
+                layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp, "overlap": ovl, "pieces": pcs})
             except (NotImplementedError, ValueError) as e:
                 layout_probe.setdefault("skipped", []).append({"layout": name, "error": f"{type(e).__name__}: {e}"})
         best = min(layout_probe["candidates"], key=lambda c: c["ms_per_step"])       # identical on every rank (all-reduced times)
@@ -535,6 +540,9 @@ def main():
             os.environ.pop("FLEXAM_SP_OVERLAP", None)      # the default; left unset so that a failed self-check can still fall back to 0
         else:
             os.environ["FLEXAM_SP_OVERLAP"] = best["overlap"]
+        os.environ.pop("FLEXAM_SP_PIECES", None)
+        if best["pieces"] is not None:
+            os.environ["FLEXAM_SP_PIECES"] = best["pieces"]
         model.enable_multi_gpus_inference(cfg_parallel=best["cfg_parallel"])
         model._engine = None
     pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
