@@ -115,7 +115,9 @@ int flexam_attn_fwd_lastkey(const void* q, int64_t q_bs, int64_t q_rs, const voi
  * ranges each (flash-decoding style partial softmaxes + a merge launch), the units before it in one pass: with
  * split_from_unit = floor(units/256)*256 only the last, partial round of the 256 CUs is split; 0 splits everything (ranks of a
  * sequence-parallel run hold few query rows).  ws_o: fp32 [kv_splits, n, 256, 128], ws_ml: fp32 [kv_splits, n, 256, 2] scratch
- * with n = units - split_from_unit.  kv_splits = 1 == flexam_attn_fwd. */
+ * with n = units - split_from_unit.  kv_splits = 1 == flexam_attn_fwd.  Whole and split units go out as ONE kernel launch (each XCD
+ * gets an eighth of both kinds, its whole units first: the short workgroups start as its CUs finish their last whole unit),
+ * followed by the merge launch. */
 int flexam_attn_fwd_splitkv(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                             int64_t v_bs, int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk,
                             int head_dim, float softmax_scale, int kv_splits, int split_from_unit, float* ws_o, float* ws_ml,
