@@ -397,7 +397,7 @@ def launch_ranks(args):
     attempts = [("default", {})]
     if "FLEXAM_SP_OVERLAP" not in os.environ and "FLEXAM_SP_PIECES" not in os.environ and args.gpus > 2:
         attempts.append(("FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0", {"FLEXAM_SP_PIECES": "1", "FLEXAM_SP_OVERLAP": "0"}))
-    limit = float(os.environ.get("FLEXAM_BENCH_ATTEMPT_TIMEOUT", "1500"))
+    limit = float(os.environ.get("FLEXAM_BENCH_ATTEMPT_TIMEOUT", "600"))
     last_rc, last_line, notes = 1, None, []
     for name, extra in attempts:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
