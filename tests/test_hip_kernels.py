@@ -328,7 +328,8 @@ def test_attention_tail_split_matches_single_pass(H):
 
 
 @pytest.mark.parametrize("b,h,lq,lk,splits,from_unit", [(2, 3, 700, 1300, 2, 5), (2, 3, 700, 1300, 3, 17), (1, 5, 2600, 900, 4, 9),
-                                                          (1, 24, 1100, 1100, 3, 64), (2, 2, 257, 4100, 5, 3)])
+                                                          (1, 24, 1100, 1100, 3, 64), (2, 2, 257, 4100, 5, 3),
+                                                          (1, 3, 700, 1300, 2, 8), (1, 3, 700, 1300, 2, 1), (1, 1, 256, 640, 2, 0)])
 def test_attention_one_launch_tail_equals_two_launches(H, monkeypatch, b, h, lq, lk, splits, from_unit):
     """The default form of a split-KV call -- whole units and the split tail in ONE launch, an eighth of both kinds per XCD
     (AttnParams::whole_units) -- against the two-launch form (FLEXAM_ATTN_FUSED_TAIL=0): same workgroup programs on the same
