@@ -380,20 +380,22 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   //  * S(g+1) is always computed; past the last half it reads stale LDS, mask_half turns it into -inf and the
   //    step that consumes it adds exactly 0 (exp2(-inf) = 0, no rescale);
   //  * PV(g-1) is always issued; for g = 0 P is zero and the V half it reads (slot 3, second half) was zeroed.
-  auto step = [&](int g, auto g8_c, f32x16& s_cur, f32x16& s_nxt) {     // g8 = g mod 8 as a compile-time constant
-    constexpr int g8 = decltype(g8_c)::value;
+  // A half-tile step g in two parts.  Part A: first half of S(g+1) on the matrix pipe (fragments read during the previous step) |
+  // row maximum of S(g) on the VALU, and the (rare) deferred rescale.  Part B: second half of S(g+1) and PV(g-1) on the matrix pipe |
+  // exp2 / row sum / pack of S(g) on the VALU.
+  auto stepA = [&](int g, f32x16& s_cur, f32x16& s_nxt) __attribute__((always_inline)) {
     mask_half(g, s_cur);             // keys past Lk -> -inf (uniform branch, only taken in the last tile)
-    // ---- A: first half of S(g+1) on the matrix pipe (fragments read during the previous step) | row maximum of S(g) on the VALU
     qk_mma(IC<0>{}, kf_pre, s_nxt);
     const float m0 = vmax8(s_cur[0], s_cur[1], s_cur[2], s_cur[3], s_cur[4], s_cur[5], s_cur[6], s_cur[7]);
     const float m1 = vmax8(s_cur[8], s_cur[9], s_cur[10], s_cur[11], s_cur[12], s_cur[13], s_cur[14], s_cur[15]);
-    const float mx = pair_max2(m0, m1);
-    float psum = 0.f;
-    bf16x8 pn[2];
+    // the test needs no row maximum: any(lane maximum > THR) over the wave is any(row maximum > THR); the exchange between the
+    // two lanes of a row happens in the rare branch only (-0.7 % of a step, profiles/r4e_*)
+    const float mloc = vmax(m0, m1);
     if constexpr (PRE) {
       // ---- deferred rescale (always taken for half 0, which sets the reference to the first row maximum): O, l, the pending
       // P(g-1), the scores of this half and the already started chain of the next half all move to the new reference
-      if (g == 0 || __any(mx > RESCALE_THR_LOG2)) {            // mx is relative to ref
+      if (g == 0 || __any(mloc > RESCALE_THR_LOG2)) {            // relative to ref
+        const float mx = pair_max(mloc);
         const float delta = g == 0 ? mx : fmaxf(mx, 0.f);
         const float alpha = g == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
         ref += delta;
@@ -413,19 +415,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
           negref[e] = -ref;
         }
       }
-      // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
-      qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
-      pv_half(IC<((g8 + 7) & 7)>{});
-      qk_read(IC<((g8 + 2) & 7)>{}, IC<0>{}, kf_pre);          // for the next step's block A
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(s_cur[e]);
-        psum = e == 0 ? pv : psum + pv;                       // (0 + x is an instruction: x may be -0 as far as the compiler knows)
-        pn[e >> 3][e & 7] = f2bf(pv);
-      }
     } else {
       // ---- deferred rescale (always taken for half 0): O, l AND the pending P(g-1) move to the new max
-      if (__any((mx - m_run) * c > RESCALE_THR_LOG2)) {
+      if (__any((mloc - m_run) * c > RESCALE_THR_LOG2)) {
+        const float mx = pair_max(mloc);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
         l_run *= alpha;
@@ -439,17 +432,21 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) pf_prev[ss][e] = f2bf(bf2f(pf_prev[ss][e]) * alpha);
       }
-      // ---- B: second half of S(g+1) and PV(g-1) on the matrix pipe | exp2 / row sum / pack of S(g) on the VALU
-      qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
-      pv_half(IC<((g8 + 7) & 7)>{});
-      qk_read(IC<((g8 + 2) & 7)>{}, IC<0>{}, kf_pre);          // for the next step's block A
-      const float mc = m_run * c;
+    }
+  };
+  auto stepB = [&](auto g8_c, f32x16& s_cur, f32x16& s_nxt) __attribute__((always_inline)) {     // g8 = g mod 8 as a compile-time constant
+    constexpr int g8 = decltype(g8_c)::value;
+    float psum = 0.f;
+    bf16x8 pn[2];
+    qk_part(IC<((g8 + 1) & 7)>{}, IC<4>{}, s_nxt);
+    pv_half(IC<((g8 + 7) & 7)>{});
+    qk_read(IC<((g8 + 2) & 7)>{}, IC<0>{}, kf_pre);          // for the next step's part A
+    const float mc = PRE ? 0.f : m_run * c;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], c, -mc));
-        psum = e == 0 ? pv : psum + pv;
-        pn[e >> 3][e & 7] = f2bf(pv);
-      }
+    for (int e = 0; e < 16; ++e) {
+      const float pv = PRE ? __builtin_amdgcn_exp2f(s_cur[e]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], c, -mc));
+      psum = e == 0 ? pv : psum + pv;                       // (0 + x is an instruction: x may be -0 as far as the compiler knows)
+      pn[e >> 3][e & 7] = f2bf(pv);
     }
     l_run += psum;
     pf_prev[0] = pn[0];            // PV(g-1) above consumed the old value (program order)
@@ -466,7 +463,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     }
   };
 
-  auto tile = [&](int t, auto t4_c) {       // t4 = t mod 4 as a compile-time constant
+  // Measured and not kept (profiles/r4e_attn_stagger_and_local_max.txt): waves 4-7 half a step behind their SIMD partners (their
+  // barrier in front of part B instead of part A).  As two copies of the loop it does not fit the instruction cache (-10 %), as one
+  // copy with two conditional barrier sites -1.4 % alone and +1.1 % on the step.
+  auto tile = [&](int t, auto t4_c) __attribute__((always_inline)) {       // t4 = t mod 4 as a compile-time constant
     constexpr int t4 = decltype(t4_c)::value;
     if (t > 0) {
       // top of 64-key tile t: tile t+1 (issued one tile ago) has landed and becomes visible; the slot of tile
@@ -479,9 +479,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     // K pieces of tile t+2 now, its V pieces between the two half-tile steps: two short bursts of LDS-DMA issue per tile instead
     // of one of four per wave right after the barrier (-1.2...-1.6 % time; placements inside the steps' MFMA blocks were slower)
     if (t + 2 < ntiles) issue_tile(t + 2, 1);
-    step(2 * t, IC<2 * t4>{}, s_a, s_b);
+    stepA(2 * t, s_a, s_b);
+    stepB(IC<2 * t4>{}, s_a, s_b);
     if (t + 2 < ntiles) issue_tile(t + 2, 2);
-    step(2 * t + 1, IC<2 * t4 + 1>{}, s_b, s_a);
+    stepA(2 * t + 1, s_b, s_a);
+    stepB(IC<2 * t4 + 1>{}, s_b, s_a);
   };
   int t = 0;
   for (; t + 4 <= ntiles; t += 4) {
@@ -560,6 +562,15 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 //  * O^T is 8 (d) x 2 (q) tiles of 16 x 16: a lane holds 4 consecutive d of a row per tile; the epilogue turns the wave's 32 x 128
 //    block around in LDS and stores whole 256-byte rows.
 // ------------------------------------------------------------------------------------------------
+#ifndef A16_KPRE
+#define A16_KPRE 2
+#endif
+#ifndef A16_ROWSUM_MFMA
+#define A16_ROWSUM_MFMA 0
+#endif
+#ifndef A16_SCHED
+#define A16_SCHED 0
+#endif
 __device__ __forceinline__ int sigma4(int g) { return ((g & 1) << 1) | (g >> 1); }
 
 template <int KIND, bool PRE>
@@ -669,6 +680,17 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
   // one per query tile of the lane
   f32x4 negref[2];
   float ref[2] = {0.f, 0.f}, m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#if A16_ROWSUM_MFMA
+  // row sums on the matrix pipe: l^T += 1 . P^T beside O^T += V^T . P^T (one more 16 x 16 tile per query tile and 32 keys instead of
+  // 16 v_add per lane); every register of the tile, in every lane group, then holds the whole row sum of query lane & 15
+  f32x4 l_acc[2];
+  bf16x8 ones;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) l_acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+  asm volatile("" : "+v"(ones));
+#endif
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) negref[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const float c = p.scale_log2e;
@@ -696,7 +718,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
         }
       }
   };
-  constexpr int KPRE = 2;   // fragments of key tile 0 of the NEXT half tile read one step ahead (all 4 do not fit the register file)
+  constexpr int KPRE = A16_KPRE;   // fragments of key tile 0 of the NEXT half tile read one step ahead (all 4 do not fit the register file)
   bf16x8 kf_pre[4];
   const float last_bias = PRE ? p.last_key_bias : p.last_key_bias / p.scale_log2e;
   auto mask_half = [&](int g, f32x4 (&s)[2][2]) {
@@ -739,6 +761,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf_prev[qt], o_acc[dt][qt], 0, 0, 0);
     }
+#if A16_ROWSUM_MFMA
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf_prev[qt], l_acc[qt], 0, 0, 0);
+#endif
   };
   // a query row's value from its four lanes (rare path only)
   auto row_max = [&](float x) -> float {
@@ -796,7 +822,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
           const float delta = g == 0 ? mx : fmaxf(mx, 0.f);
           alpha[qt] = g == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
           ref[qt] += delta;
+#if !A16_ROWSUM_MFMA
           l_run[qt] *= alpha[qt];
+#endif
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             s_cur[0][qt][e] -= delta;
@@ -813,7 +841,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
         for (int qt = 0; qt < 2; ++qt) {
           const float m_new = fmaxf(m_run[qt], row_max(mq[qt]));
           alpha[qt] = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
+#if !A16_ROWSUM_MFMA
           l_run[qt] *= alpha[qt];
+#endif
           m_run[qt] = m_new;
         }
       }
@@ -834,29 +864,58 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float pv = PRE ? __builtin_amdgcn_exp2f(s_cur[kt][qt][e]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][qt][e], c, -mc));
+#if !A16_ROWSUM_MFMA
           psum[qt] = (kt == 0 && e == 0) ? pv : psum[qt] + pv;
+#endif
           pn[qt][4 * kt + e] = f2bf(pv);
         }
+#if !A16_ROWSUM_MFMA
       l_run[qt] += psum[qt];
+#endif
     }
     pf_prev[0] = pn[0];            // PV(g-1) above consumed the old value (program order)
     pf_prev[1] = pn[1];
+#if A16_ROWSUM_MFMA
+    asm volatile("" : "+v"(pf_prev[0]), "+v"(pf_prev[1]));
+#else
     asm volatile("" : "+v"(pf_prev[0]), "+v"(pf_prev[1]), "+v"(l_run[0]), "+v"(l_run[1]));
-    // Block B schedule: 24 MFMAs (16 cycles each), 24 LDS reads, ~42 VALU operations
+#endif
+    // Block B schedule: 24 (26) MFMAs (16 cycles each), 24 LDS reads, ~42 (26) VALU operations
+#if A16_SCHED == 0
 #pragma unroll
-    for (int i = 0; i < 24; ++i) {
+    for (int i = 0; i < 24 + 2 * A16_ROWSUM_MFMA; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
       __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 2 : 3, 0);   // VALU
     }
+#elif A16_SCHED == 1      // one VALU per MFMA for as long as they last
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+    }
+#pragma unroll
+    for (int i = 16; i < 24 + 2 * A16_ROWSUM_MFMA; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+    }
+#elif A16_SCHED == 2      // no forced interleave: hipcc's own order
+#endif
     if (resc) {                    // rare: O (now holding P(g-1).V(g-1) in the old units) to the new reference
       asm volatile("; O to the new reference" ::: "memory");     // a real branch: hipcc otherwise multiplies by 1.0 on every step
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) o_acc[dt][qt][e] *= alpha[qt];
+#if A16_ROWSUM_MFMA
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l_acc[qt][e] *= alpha[qt];
+#endif
+      }
     }
   };
 
@@ -896,10 +955,14 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
   float l_tot[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
+#if A16_ROWSUM_MFMA
+    l_tot[qt] = l_acc[qt][0];
+#else
     float x = l_run[qt];
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
     l_tot[qt] = x;
+#endif
   }
   if (partial) {                           // partial result of this key range; attn_merge_kernel finishes the softmax
 #pragma unroll
@@ -1006,8 +1069,8 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
-  const char* be = getenv("FLEXAM_ATTN_BODY");          // A/B switch (read per call): 32 = the 32x32x16 body, default 16x16x32
-  const bool body16 = !be || atoi(be) != 32;
+  const char* be = getenv("FLEXAM_ATTN_BODY");          // A/B switch (read per call): 16 = the 16x16x32 body, default 32x32x16
+  const bool body16 = be && atoi(be) == 16;
   auto kern = body16 ? (cross ? (p.prescaled ? attn_fwd16_kernel<1, true> : attn_fwd16_kernel<1, false>)
                               : (p.prescaled ? attn_fwd16_kernel<0, true> : attn_fwd16_kernel<0, false>))
                      : (cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
