@@ -276,3 +276,69 @@ def test_vae_decode_chunk_true_widths_sixteenth_area():
     with torch.no_grad():
         want = OV.vae_decode(sd_b, z, v["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
     stats(out, want, "VAE decode, true widths, 1/16 area", rel_max=2e-2, peak=2.0)
+
+
+# ----------------------------------------------------------------------------- width x depth x steps together (r3 verdict item 3)
+def _three_layer_5b(seed=5):
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+    cfg = dict(CFG_5B, num_layers=3)
+    sd = C.dit_weights(cfg, seed)
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    m.load_state_dict(sd, strict=True)
+    return cfg, sd, m.to("cuda:0")
+
+
+@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
+def test_5b_width_three_layers_four_steps_sampler_vs_oracle_loop(fp8):
+    """The loop the reference runs (PIPE.py:840-949 over FX.py:1053-1089) at the 5B WIDTH with DEPTH and STEPS together: BASELINE
+    config 1's latent [1,48,3,16,16] (9x256x256), d = 3072 / 24 heads / ffn 14336, 3 of the 30 layers, 4 Euler steps, CFG pair
+    (two prompts on one latent), HIP sampler vs oracle.sampler.denoise_loop over oracle.dit.dit_forward (fp32), every step's
+    latents compared.  bf16 path: rel-RMS <= 1.5e-2 / PSNR >= 40 dB; fp8 QKV / FFN GEMMs (configs[4]): e4m3 operands with per-row /
+    per-channel scales -> stated tolerance rel-RMS <= 3e-2 / PSNR >= 45 dB on every step's latents (measured r4: bf16 6.4e-3 / 63.9 dB,
+    fp8 2.2e-2 / 53.0 dB after the fourth step)."""
+    from flexam_amd import Wan2_2FunControlPipeline_FlexAM
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    from oracle import sampler as S
+    cfg, sd, m = _three_layer_5b()
+    if fp8:
+        m.enable_fp8_gemm(True)
+    pipe = Wan2_2FunControlPipeline_FlexAM(transformer=m)
+    sc = C.sampler_case(cfg)
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], sc["mask_pixels"])
+    trace = []
+    out = pipe(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+               num_inference_steps=4, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent",
+               callback_on_step_end=lambda p, i, t, k: trace.append(k["latents"].float().cpu().clone()))
+    if fp8:
+        assert m.engine().fp8
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    ref_trace = []
+    with torch.no_grad():
+        ref = S.denoise_loop(lambda **k: O.dit_forward(sd, cfg, **k), S.FlowMatchEulerSchedule(1000, 5.0), 4, sc["latents"],
+                             sc["context_uncond"], sc["context_cond"], sc["control_latents"], sc["additional_control"], ml,
+                             sc["masked_video_latents"], sc["ref_latents"], mask, pinned, 0.1, 6.0, trace=ref_trace)
+    ps = [C.psnr(a, b) for a, b in zip(trace, ref_trace)]
+    print(("fp8" if fp8 else "bf16") + " psnr after steps 1..4:", [round(x, 1) for x in ps])
+    assert len(ps) == 4
+    if fp8:
+        stats(out.videos, ref, "5B width x 3 layers x 4 steps, fp8 QKV/FFN, final latents", rel_max=3e-2, psnr_min=45.0)
+        assert min(ps) >= 45.0
+    else:
+        stats(out.videos, ref, "5B width x 3 layers x 4 steps, final latents")
+        assert min(ps) >= 40.0
+
+
+def test_5b_width_three_layers_one_forward_at_2912_tokens():
+    """The same 3-layer 5B-width model, ONE forward on a [2,48,25,16,28] latent (L = 25 x 8 x 14 + the 8 x 14 reference slab = 2912
+    tokens, the per-rank token count at 8 GPUs; two prompts of different length, per-token timesteps) vs the fp32 oracle: three
+    blocks of residual-stream accumulation at true width (the one-layer tests cannot see a block feeding a block)."""
+    cfg, sd, m = _three_layer_5b(seed=6)
+    case = C.dit_case(cfg, 16, frames=25, h=16, w=28, batch=2, text_lens=(77, 126))
+    dcase = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    out = m(**dcase)
+    assert m.engine().cond["L"] == 2912
+    with torch.no_grad():
+        want = O.dit_forward(sd, cfg, **case)
+    stats(out, want, "three-layer 5B-width model, L = 2912")
