@@ -112,6 +112,34 @@ def time_kernel(fn, iters=10, warm=2):
     return s.elapsed_time(e) * 1e-3 / iters
 
 
+def self_attention_in_step(pipe, step_index, B):
+    """The dominant kernel timed where it runs: HIP events (torch's current stream = the stream every flexam_* call launches on)
+    around every self-attention call of ONE more denoise step, outside the timed region.  Returns the mean over the calls that run
+    the whole batch (29 of 30: block 0's call covers one sample when the CFG pair shares its self-attention half) in seconds --
+    the figure rocprofv3 --kernel-trace reports as that kernel's average inside the step.  The isolated back-to-back timing
+    (kernel_rooflines) runs at another clock: inside the step the clock is set by the GEMMs around the call."""
+    from flexam_amd import hip
+    real, marks = hip.attn_fwd, []
+
+    def timed_attn(q, k, v, *a, **kw):
+        if k.shape[1] <= 1024 or q.shape[1] != k.shape[1]:          # text cross-attention / partial calls: not the kernel in question
+            return real(q, k, v, *a, **kw)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = real(q, k, v, *a, **kw)
+        e.record()
+        marks.append((q.shape[0], s, e))
+        return out
+    hip.attn_fwd = timed_attn
+    try:
+        pipe.denoise_step(step_index)
+        torch.cuda.synchronize()
+    finally:
+        hip.attn_fwd = real
+    full = [s.elapsed_time(e) * 1e-3 for b, s, e in marks if b == B]
+    return {"sec": sum(full) / len(full), "calls": len(full), "calls_other_batch": len(marks) - len(full)} if full else None
+
+
 def kernel_rooflines(eng, B, L, lc):
     """Live per-launch timing of the hot kernels at this run's shapes, on the engine's own buffers."""
     from flexam_amd import hip
@@ -361,11 +389,39 @@ def multi_gpu_check(pipe, model, inp, cond, step_index, total_steps, world, rank
     dist.all_gather_object(rels, rel)
     worst = max(rels)
     ok = bool(agree and worst <= tol and math.isfinite(worst))
-    if os.environ.get("FLEXAM_BENCH_FORCE_CHECK_FAIL") == "1" and os.environ.get("FLEXAM_SP_OVERLAP") != "0":
+    if (os.environ.get("FLEXAM_BENCH_TEST_HOOKS") == "1" and os.environ.get("FLEXAM_BENCH_FORCE_CHECK_FAIL") == "1"
+            and os.environ.get("FLEXAM_SP_OVERLAP") != "0"):
         ok = False                       # test hook (tests/test_bench_launch.py): exercises the launcher's fallback attempt
     return {"ok": ok, "ranks": world, "ranks_agree": bool(agree), "rel_rms_vs_single_gpu": rel, "worst_rank_rel_rms": worst, "tolerance": tol,
             "what": "DiT head output of one denoise step per CFG row (before the guidance combine): N-rank layout vs the same step on "
                     "one GPU (no collective), every rank; checksums of the N ranks' latents"}
+
+
+def visible_gpus_without_hip():
+    """GPUs this process may use, counted from the KFD topology in sysfs (nodes with SIMDs), cut by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES when they are plain index lists.  No HIP / HSA call: the launcher must not initialise the runtime before
+    it starts the ranks (torch.cuda.device_count() only avoids HIP while its amdsmi path works).  None when sysfs says nothing."""
+    import glob
+    n = 0
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                     # no KFD driver: no AMD GPU on this host
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            if all(x.strip().isdigit() for x in ids):
+                n = min(n, len(ids))
+    return n
 
 
 def launch_ranks(args):
@@ -388,10 +444,10 @@ def launch_ranks(args):
         s.close()
         return port
 
-    n_dev = torch.cuda.device_count()               # counting devices does not initialise the GPU on this image
+    n_dev = visible_gpus_without_hip()               # None: cannot tell without touching HIP -> the rank children report it
     env0 = dict(os.environ)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if n_dev < args.gpus and env0.get("FLEXAM_BENCH_ONE_DEVICE") != "1":
+    if n_dev is not None and n_dev < args.gpus and env0.get("FLEXAM_BENCH_ONE_DEVICE") != "1":
         raise SystemExit(f"--gpus {args.gpus} but only {n_dev} GPU(s) are visible (FLEXAM_BENCH_ONE_DEVICE=1 FLEXAM_BENCH_BACKEND=gloo "
                          f"runs the rank code path on one device for validation; such a line is marked invalid)")
     attempts = [("default", {})]
@@ -474,10 +530,14 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a collective that one rank never joins must end the attempt long before the launcher's limit (600 s), so that the
+        # conservative second attempt still fits the driver's window
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("FLEXAM_BENCH_PG_TIMEOUT", "150")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
 
     from flexam_amd import Wan2_2FunControlPipeline_FlexAM
     from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
@@ -510,41 +570,70 @@ def main():
             cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples fully pipelined (attention per sample)", "ulysses", False, "2", None))
         if cfg["num_heads"] % (world // 2) == 0:
             cands.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, "1", None))
-        layout_probe = {"candidates": [], "steps": 2}
+        # Per-candidate guard: a candidate that raises (every rank the same way: configuration errors) or whose FIRST step takes
+        # longer than the budget is recorded in `skipped` and the probe goes on; all ranks decide on all-reduced values.  A rank that
+        # dies or hangs alone cannot be skipped over in-process: the process-group timeout (FLEXAM_BENCH_PG_TIMEOUT) ends the attempt
+        # and the launcher's second attempt runs the conservative exchange without a probe.
+        budget = float(os.environ.get("FLEXAM_BENCH_PROBE_BUDGET", "20"))       # seconds for a candidate's first step (single GPU: 0.27 s)
+        layout_probe = {"candidates": [], "steps": 2, "first_step_budget_sec": budget}
+
+        def agreed_max(x):
+            tt = torch.tensor([x], device=device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+
         for name, mode, cfgp, ovl, pcs in cands:
             os.environ["FLEXAM_SP_MODE"], os.environ["FLEXAM_SP_OVERLAP"] = mode, ovl
             os.environ.pop("FLEXAM_SP_PIECES", None)
             if pcs is not None:
                 os.environ["FLEXAM_SP_PIECES"] = pcs
-            try:                                          # a layout this build refuses (raised identically on every rank) is skipped, not fatal
+            t_c = time.perf_counter()
+            try:
+                if os.environ.get("FLEXAM_BENCH_TEST_HOOKS") == "1" and os.environ.get("FLEXAM_BENCH_PROBE_RAISE") == str(cands.index((name, mode, cfgp, ovl, pcs))):
+                    raise RuntimeError("test hook: this candidate raises on every rank")
                 model.enable_multi_gpus_inference(cfg_parallel=cfgp)
                 model._engine = None                      # the engine (buffers, per-clip state) is rebuilt for the layout on its next use
                 pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
                 pipe.denoise_step(0)
-                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                first = agreed_max(time.perf_counter() - t_c)
+                if first > budget:
+                    layout_probe.setdefault("skipped", []).append({"layout": name, "error": f"first step took {first:.1f} s (> {budget:.0f} s budget)",
+                                                                    "wall_sec": first})
+                    continue
+                dist.barrier(); torch.cuda.synchronize()
                 tq = time.perf_counter()
                 for i in range(2):
                     pipe.denoise_step(1 + i)
                 torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-                tt = torch.tensor([time.perf_counter() - tq], device=device, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                layout_probe["candidates"].append({"layout": name, "ms_per_step": float(tt.item()) / 2 * 1e3, "mode": mode, "cfg_parallel": cfgp, "overlap": ovl, "pieces": pcs})
-            except (NotImplementedError, ValueError) as e:
-                layout_probe.setdefault("skipped", []).append({"layout": name, "error": f"{type(e).__name__}: {e}"})
-        best = min(layout_probe["candidates"], key=lambda c: c["ms_per_step"])       # identical on every rank (all-reduced times)
-        if os.environ.get("FLEXAM_BENCH_LAYOUT_FORCE"):                              # test hook: run candidate i whatever the probe measured
-            best = layout_probe["candidates"][int(os.environ["FLEXAM_BENCH_LAYOUT_FORCE"])]
-        layout_probe["chosen"] = best["layout"]
-        os.environ["FLEXAM_SP_MODE"] = best["mode"]
-        if best["overlap"] == "1":
-            os.environ.pop("FLEXAM_SP_OVERLAP", None)      # the default; left unset so that a failed self-check can still fall back to 0
-        else:
-            os.environ["FLEXAM_SP_OVERLAP"] = best["overlap"]
-        os.environ.pop("FLEXAM_SP_PIECES", None)
-        if best["pieces"] is not None:
-            os.environ["FLEXAM_SP_PIECES"] = best["pieces"]
-        model.enable_multi_gpus_inference(cfg_parallel=best["cfg_parallel"])
+                ms = agreed_max(time.perf_counter() - tq) / 2 * 1e3
+                layout_probe["candidates"].append({"layout": name, "ms_per_step": ms, "mode": mode, "cfg_parallel": cfgp, "overlap": ovl, "pieces": pcs,
+                                                   "wall_sec": round(time.perf_counter() - t_c, 2)})
+            except Exception as e:                        # noqa: BLE001  (raised identically on every rank, or the PG timeout ends the attempt)
+                layout_probe.setdefault("skipped", []).append({"layout": name, "error": f"{type(e).__name__}: {e}", "wall_sec": round(time.perf_counter() - t_c, 2)})
+        test_hooks = os.environ.get("FLEXAM_BENCH_TEST_HOOKS") == "1"
+        if layout_probe["candidates"]:
+            best = min(layout_probe["candidates"], key=lambda c: c["ms_per_step"])       # identical on every rank (all-reduced times)
+            if test_hooks and os.environ.get("FLEXAM_BENCH_LAYOUT_FORCE"):               # test hook: run candidate i whatever the probe measured
+                best = layout_probe["candidates"][int(os.environ["FLEXAM_BENCH_LAYOUT_FORCE"])]
+            layout_probe["chosen"] = best["layout"]
+            os.environ["FLEXAM_SP_MODE"] = best["mode"]
+            if best["overlap"] == "1":
+                os.environ.pop("FLEXAM_SP_OVERLAP", None)      # the default; left unset so that a failed self-check can still fall back to 0
+            else:
+                os.environ["FLEXAM_SP_OVERLAP"] = best["overlap"]
+            os.environ.pop("FLEXAM_SP_PIECES", None)
+            if best["pieces"] is not None:
+                os.environ["FLEXAM_SP_PIECES"] = best["pieces"]
+            model.enable_multi_gpus_inference(cfg_parallel=best["cfg_parallel"])
+        else:                                             # every candidate refused or over budget: keep the default layout
+            layout_probe["chosen"] = "none measured: default layout"
+            for k in ("FLEXAM_SP_MODE", "FLEXAM_SP_OVERLAP", "FLEXAM_SP_PIECES"):
+                os.environ.pop(k, None)
+            model.enable_multi_gpus_inference(cfg_parallel=None)
         model._engine = None
+        from flexam_amd.dist import live_subgroups
+        layout_probe["communicators"] = 1 + live_subgroups()     # the world group + the cached CFG-half groups (created once per member set)
     pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
     torch.cuda.synchronize()
     tp0 = time.perf_counter()                       # second call: buffers exist, this is the per-clip cost of the step-invariant work
@@ -606,6 +695,9 @@ def main():
     lc = L // eng.sp_size
     b_local = 1 if eng.cfg_size == 2 else B
     kern = None if args.no_kernel_timing else kernel_rooflines(eng, b_local, L, lc)
+    attn_in_step = None
+    if kern is not None and world == 1:
+        attn_in_step = self_attention_in_step(pipe, (args.warmup + args.steps + 2) % total_steps, b_local)
     if kern is not None and pipe._state.get("known") is not None:
         kern["cfg_euler_blend"] = sampler_step_roofline(pipe)
     check = None
@@ -619,6 +711,9 @@ def main():
         if not check["ok"] and os.environ.get("FLEXAM_BENCH_SPAWNED") != "1" and eng.sp_size > 1 and not pinned:
             inproc_fallback = {"attempt": "default", "check": check, "ms_per_step": elapsed / args.steps * 1e3}
             os.environ["FLEXAM_SP_PIECES"], os.environ["FLEXAM_SP_OVERLAP"] = "1", "0"
+            os.environ.pop("FLEXAM_SP_MODE", None)        # the conservative form IS the K|V all-gather, whatever the probe had picked
+            model.enable_multi_gpus_inference(cfg_parallel=None)
+            model._engine = None
             pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
             eng = model.engine()
             elapsed = timed(pipe)
@@ -635,6 +730,7 @@ def main():
 
     eng_cfg, eng_sp, eng_mode = eng.cfg_size, eng.sp_size, getattr(eng, "sp_mode", "-")
     eng_cross_lk = eng.cond.get("cross_lk")
+    eng_share0 = bool(getattr(eng, "share0_taken", False))      # what the engine DID in its last run, not what a switch asked for
     if eng_mode == "allgather":
         pcs = getattr(eng, "sp_pieces", 1)
         eng_mode = (f"K|V all-gather per block in {pcs} head-group piece(s), " +
@@ -670,7 +766,7 @@ def main():
         step_block_flops = blk * B * cfg["num_layers"]
         # Work the build removes is not counted as achieved FLOPs: with the CFG pair on one latent, block 0's q|k|v / o
         # projections and self-attention run once, not per sample (DiTEngine.run, share0)
-        shared0 = (world == 1 and os.environ.get("FLEXAM_SHARE_BLOCK0", "1") != "0" and cfg["num_layers"] > 0)
+        shared0 = eng_share0
         removed_flops = (8 * L * cfg["dim"] ** 2 + 4 * L * L * cfg["dim"]) if shared0 else 0
         # ... and the identical padded text rows are attended to as one weighted key (DiTEngine.set_conditioning, cross_lk)
         cross_lk = eng_cross_lk if eng_cross_lk else cfg["text_len"]
@@ -699,12 +795,16 @@ def main():
             "prepare_sec": prepare_sec,
             "clip_end_to_end": clip,
             "sec_per_clip": (enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
-            "dit_block_tflops": executed_block_flops * steps_per_sec / 1e12,
-            "dit_block_mfma_frac": executed_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
-            "dit_block_mfma_frac_note": ("EXECUTED block FLOPs (algorithmic 5.131 TF x 60 per step minus what the build removes -- the block-0 self-attention half "
-                                         "the CFG pair shares and the identical padded text keys of cross-attention: %.3f of %.1f TF) against the 2.5 PFLOP/s "
-                                         "bf16 peak" % (removed_flops / 1e12, step_block_flops / 1e12))
-                                        + (" (QKV / FFN ran on the 5 PFLOP/s fp8 pipe: not a roofline fraction)" if args.fp8 else ""),
+            "dit_block_executed_tflops": executed_block_flops * steps_per_sec / 1e12,
+            "dit_block_executed_mfma_frac": executed_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
+            "dit_block_algorithmic_tflops": step_block_flops * steps_per_sec / 1e12,
+            "dit_block_flops_note": ("executed = algorithmic block FLOPs (%.3f TF per block and sample x %d) minus what the build removes -- the block-0 self-attention "
+                                     "half the CFG pair shares (taken: %s) and the identical padded text keys of cross-attention (keys attended: %d of %d): %.3f of "
+                                     "%.1f TF per step; the fraction is executed FLOPs against the 2.5 PFLOP/s bf16 peak.  The algorithmic figure counts work that "
+                                     "did not run: it is a throughput in the reference's units, not a roofline fraction (rounds 1-2 reported it as "
+                                     "dit_block_tflops with every FLOP executed)"
+                                     % (blk / 1e12, B * cfg["num_layers"], shared0, cross_lk, cfg["text_len"], removed_flops / 1e12, step_block_flops / 1e12))
+                                    + (" (QKV / FFN ran on the 5 PFLOP/s fp8 pipe: not a roofline fraction)" if args.fp8 else ""),
             "finite": finite,
             "mask": args.mask, "timestep_rows_per_sample": rows_u,
             "host_enqueue_ms_per_step": host_enqueue * 1e3,
@@ -733,20 +833,28 @@ def main():
                           if os.path.exists(q)), "")
             if world == 1 and (args.frames, args.height, args.width) == (97, 512, 896) and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0, true> (self-attention, head_dim 128, q pre-scaled by its RMSNorm weight)", "achieved": a["tflops"],
-                                  "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic,
+            sec_live = attn_in_step["sec"] if attn_in_step else a["sec"]
+            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0, true> (self-attention, head_dim 128, q pre-scaled by its RMSNorm weight)",
+                                  "achieved": a["flops"] / sec_live / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["flops"] / sec_live / 1e12 / PEAK_BF16_TFLOPS,
+                                  "traffic": traffic,
                                   "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the launches of one call (" + os.path.basename(tpath) + ")",
-                                  "launch_ms": a["sec"] * 1e3, "flops_per_launch": a["flops"],
+                                  "launch_ms": sec_live * 1e3, "flops_per_launch": a["flops"],
+                                  "timed": ("IN the step: HIP events around the %d whole-batch self-attention calls of one denoise step (the other %d call(s) run one "
+                                            "sample: block 0 shared by the CFG pair); this is what rocprofv3 --kernel-trace --stats of the same command averages for "
+                                            "the kernel (+ the 20 us merge)" % (attn_in_step["calls"], attn_in_step["calls_other_batch"])) if attn_in_step
+                                           else "isolated back-to-back launches (no in-step timing in this run)",
+                                  "isolated_launch_ms": a["sec"] * 1e3, "isolated_frac": a["tflops"] / PEAK_BF16_TFLOPS,
+                                  "isolated_note": "8 back-to-back launches on the step's own buffers: runs at the clock the kernel holds alone, not the step's",
                                   "launch_note": "one self-attention call = ONE attn_fwd_kernel<0, true> launch (the full rounds of work units and, on the same "
                                                  "XCDs behind them, the last partial round with its keys cut in 3) + attn_merge_kernel; launch_ms is the whole "
-                                                 "call = its AverageNs in rocprofv3 + the merge (profiles before r3o: two attn_fwd_kernel rows per call)"}
+                                                 "call = its AverageNs in rocprofv3 + the merge"}
             result["kernels"] = {k: ({"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1), "bound": "mfma",
                                       "peak": PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS,
                                       "frac": round(v["tflops"] / (PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS), 4)} if "flops" in v else
                                      {"ms": round(v["sec"] * 1e3, 4), "gbs": round(v["bytes"] / v["sec"] / 1e9, 1), "bound": "hbm",
                                       "frac": round(v["bytes"] / v["sec"] / 1e9 / PEAK_HBM_GBS, 4)}) for k, v in kern.items()}
             result["kernels_note"] = ("live per-launch timing at this run's shapes; mfma rows: algorithmic FLOPs / 2.5 PFLOP/s, hbm rows: "
-                                      "algorithmic bytes (SURVEY 8d) / 8 TB/s; counter-side traffic and MFMA-busy: profiles/r2*_block_kernels_pmc.*")
+                                      "algorithmic bytes (SURVEY 8d) / 8 TB/s; counter-side traffic and MFMA-busy: profiles/r4*_block_kernels_pmc.txt")
         if base is not None:
             result["cpu_baseline"] = base
         print(json.dumps(result))

@@ -31,8 +31,6 @@ int flexam_current_device() {
   return dev < FLEXAM_MAX_DEVICES ? dev : FLEXAM_MAX_DEVICES - 1;
 }
 
-static thread_local int g_cu_budget = 0;                 // flexam_set_cu_budget: 0 = the whole device
-
 int flexam_num_cus() {
   static int cus[FLEXAM_MAX_DEVICES] = {};               // filled on first use per device (benign race: same value)
   const int dev = flexam_current_device();
@@ -42,14 +40,10 @@ int flexam_num_cus() {
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) n = prop.multiProcessorCount / 8 * 8;
     cus[dev] = n;
   }
-  return (g_cu_budget >= 8 && g_cu_budget < cus[dev]) ? g_cu_budget : cus[dev];
+  return cus[dev];
 }
 
-extern "C" int flexam_set_cu_budget(int n_cus) {
-  if (n_cus != 0 && (n_cus < 8 || n_cus % 8)) return flexam_fail(FLEXAM_E_ARG, "set_cu_budget: %d is not 0 or a multiple of 8", n_cus);
-  g_cu_budget = n_cus;
-  return FLEXAM_OK;
-}
+extern "C" int flexam_device_cus(void) { return flexam_num_cus(); }
 
 extern "C" const char* flexam_last_error(void) { return g_err; }
 extern "C" int flexam_version(void) { return FLEXAM_HIP_VERSION; }

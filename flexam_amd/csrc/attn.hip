@@ -59,7 +59,6 @@ struct AttnParams {
   // n_slots: slots the merge kernel adds up
   int partial, slot0, n_slots;
   float last_key_bias;  // added to the score of key Lk - 1 in exp2 units (log2 of its multiplicity), 0 = none: see flexam_attn_fwd_lastkey
-  int prio_young;       // tuning switch (FLEXAM_ATTN_PRIO=1): s_setprio 1 for waves 4-7, the arbitration losers of every segment (guide, two waves per SIMD, item 4)
 };
 
 // byte offset of 16-byte chunk `ch` (0..15) of key row `row` in a [64][128] bf16 tile, image (b)
@@ -168,7 +167,6 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  if (p.prio_young && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
   // workgroups bid = 8 * local + xcd go to XCD `xcd` in the order of `local`: an XCD walks a contiguous eighth of the work list
   auto eighth = [](int n, int xcd, int local) -> int {      // index into a list of n items, -1 past this XCD's share
@@ -1061,10 +1059,6 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.ws_o = ws_o; p.ws_ml = ws_ml;
   p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits; p.whole_units = 0;
   p.last_key_bias = last_key_bias;
-  {
-    const char* e = getenv("FLEXAM_ATTN_PRIO");           // read per call: tools/ab_attn_prio.py flips it inside one process
-    p.prio_young = e ? atoi(e) : 0;
-  }
   FX_REQUIRE((int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB

@@ -34,7 +34,6 @@
 namespace {
 
 constexpr int BN = 256, BK = 64;
-constexpr int GEMM_STAGGER_DEFAULT = 0;    // gate-residual launches (see the kernel top); FLEXAM_GEMM_STAGGER overrides for every epilogue
 constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB per operand tile (A: up to 256 rows)
 
 struct GemmParams {
@@ -58,7 +57,6 @@ struct GemmParams {
   // (gemm_splitk_finish_kernel) adds the slices up in slice order and runs the epilogue
   int units, split_full, split_s;
   float* ws;
-  int stagger;             // start-up delay of workgroup class (blockIdx / 8) % 4 in units of ~1 us (0 = none): de-phases the epilogues of the persistent workgroups
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -79,13 +77,11 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // full last round (launch() picks MT).  (A 4-wave variant with 128x128 outputs per wave, one wave per SIMD and
 // AGPR accumulators ran at a higher clock -- a third fewer LDS bytes per MFMA -- but lower MFMA occupancy, 5-8 %
 // slower overall: profiles/r1e_gemm_notes.txt; it is in the history, not in the tree.)
-// M32: the wave's 16*MT x 64 outputs as 32 x 32 MFMA tiles (v_mfma_f32_32x32x16_bf16, even MT) instead of 16 x 16 ones
-// (v_mfma_f32_16x16x32_bf16).  Same matrix-pipe time, LDS image, fragment bytes and accumulator registers, but half as many MFMA
-// instructions: a 16x16x32 holds the SIMD's vector issue for 8 of its 16 cycles, a 32x32x16 for 8 of its 32, which leaves the
-// LDS-DMA issues (~40 cycles each) and fragment reads of the K loop room beside them (tools/probes/issue_probe.hip: -7 % cycles
-// for the K loop's instruction mix).  Everything outside the MFMA calls is written once over "row tiles" of RT rows:
-//   lane -> row (lane % RT) of a row tile and column group g = lane / RT; a lane holds, for every 4-column unit v < NV of the
-//   wave's 64 columns, the 4 consecutive columns 4*NG*v + 4*g .. +3 of that row   (16x16: RT 16, NG 4, NV 4; 32x32: RT 32, NG 2, NV 8)
+// The MFMA is v_mfma_f32_16x16x32_bf16.  (A 32x32x16 form of the same kernel -- half as many MFMA instructions, 10 % fewer cycles --
+// ran 3-4 % slower on every DiT shape: the power-capped clock falls 13 %; profiles/r1e_gemm_notes.txt #15.  Not in the tree.)
+// Everything outside the MFMA calls is written over "row tiles" of RT = 16 rows: lane -> row (lane % RT) of a row tile and column
+// group g = lane / RT; a lane holds, for every 4-column unit v < NV of the wave's 64 columns, the 4 consecutive columns
+// 4*NG*v + 4*g .. +3 of that row (NG = 4, NV = 4).
 // TAIL: the instance that runs the K slices of the tail tiles (units >= split_full) and parks their partial sums; it has no
 // epilogue (gemm_splitk_finish_kernel runs it).  The TAIL = false instance runs the whole tiles only.  Two instances instead of
 // one kernel with both paths: with the slab stores between the K loop and the epilogues hipcc spills 30-50 registers in the
@@ -93,15 +89,14 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // WMW x (8 / WMW) waves, NTW 16-wide n-tiles per wave: 2 x 4 waves x 4 n-tiles = the (32 MT) x 256 tile of the DiT shapes; 4 x 2
 // waves x 5 n-tiles = a (64 MT) x 160 tile for output widths that are multiples of 160 but not of 256 (the VAE encoder's 160 / 320 /
 // 640 channels, which fill 62.5 % / 62.5 % / 83 % of 256-wide tiles).  The 160-wide shape stores through the generic epilogue (its
-// 80-column wave rows do not fit the 128-byte LDS turn-around) and has no 32 x 32 form.
-template <int EPI, typename OutT, int MT, bool M32, bool TAIL = false, int WMW = 2, int NTW = 4>
+// 80-column wave rows do not fit the 128-byte LDS turn-around).
+template <int EPI, typename OutT, int MT, bool TAIL = false, int WMW = 2, int NTW = 4>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
-  static_assert(!M32 || MT % 2 == 0, "32 x 32 tiles need an even number of 16-row m-tiles per wave");
-  static_assert((WMW == 2 && NTW == 4) || (WMW == 4 && NTW == 5 && !M32 && MT <= 4), "supported wave layouts: 2 x 4 x 4 n-tiles, 4 x 2 x 5 n-tiles");
+  static_assert((WMW == 2 && NTW == 4) || (WMW == 4 && NTW == 5 && MT <= 4), "supported wave layouts: 2 x 4 x 4 n-tiles, 4 x 2 x 5 n-tiles");
   constexpr bool STD = WMW == 2 && NTW == 4;   // the 256-wide shape with LDS-staged epilogues
   constexpr int WNW = 8 / WMW;              // waves along N
   constexpr int BN_ = WNW * NTW * 16;       // columns of this tile shape
-  constexpr int RT = M32 ? 32 : 16;         // rows per row tile
+  constexpr int RT = 16;                    // rows per row tile
   constexpr int NRT = 16 * MT / RT;         // row tiles per wave
   constexpr int NG = 64 / RT;               // column groups (lane / RT)
   constexpr int NV = NTW * 4 / NG;          // 4-column units per lane
@@ -121,13 +116,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   asm volatile("" : "+s"(wave));
   const int wm = wave / WNW, wn = wave % WNW;
 
-  // All persistent workgroups run tiles of the same length, so without this they reach their epilogues together: every CU then
-  // waits on HBM for its tile's X rows at 1/256 of the chip's bandwidth while its matrix pipe idles.  A one-off start-up offset
-  // of a fraction of the epilogue's length per class spreads the epilogues of an XCD's workgroups over time.
-  if (p.stagger > 0) {
-    const int d = ((blockIdx.x >> 3) & 3) * p.stagger;
-    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(32);
-  }
   // ---- persistent workgroups over an XCD-aware, grouped tile order: workgroup w lives on XCD w & 7 (round-robin
   // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
   // stride gridDim/8, so the tiles resident on an XCD at any time are neighbours in the list (shared A / W panels in
@@ -177,23 +165,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   };
 
   // ---- fragment read offsets (bytes inside a tile): row = base16 + (lane&15), chunk = (lane>>4) + 4*ks
-  // 16x16x32: row lane%16, 16-byte chunk lane/16 of a 32-deep K half; 32x32x16: row lane%32, chunk lane/32 of a 16-deep K step.
+  // row lane%16, 16-byte chunk lane/16 of a 32-deep K half.
   // Rebuilt at the top of every unit from a fresh lane id: alive in the K loop only, not across the epilogue (where they were
   // spilled and came back behind a vmcnt(0) that drained the epilogue's stores in front of the next K loop).
-  int frag_off[M32 ? 4 : 2];
+  int frag_off[2];
   auto frag_setup = [&]() {
     const int lf = fresh_lane();
     const int sw = ((lf & (RT - 1)) >> 1) & 7;
 #pragma unroll
-    for (int ks = 0; ks < (M32 ? 4 : 2); ++ks)
-      frag_off[ks] = (lf & (RT - 1)) * 128 + ((((M32 ? 2 * ks + (lf >> 5) : 4 * ks + (lf >> 4))) ^ sw) << 4);
+    for (int ks = 0; ks < 2; ++ks)
+      frag_off[ks] = (lf & (RT - 1)) * 128 + (((4 * ks + (lf >> 4)) ^ sw) << 4);
   };
   // ---- bias of the wave's 64 columns through LDS (standard tile shape).  A plain bias load at the top of the epilogue sits BEHIND
   // the next unit's 16 prefetched LDS-DMA pieces in the wave's in-order vmcnt queue: the first use of the bias waited for all of
   // them (s_waitcnt vmcnt(0): a full DMA latency with the matrix pipe idle, once per tile).  Instead one 256-byte LDS-DMA per unit,
   // issued IN FRONT of the unit's K block 0 pieces (so every wait that covers K block 0 covers it), into one of two slots (unit
   // parity: the next unit's bias is on its way while this unit's epilogue reads its own).
-  constexpr bool BIAS_LDS = STD && !TAIL && !M32;
+  constexpr bool BIAS_LDS = STD && !TAIL;
   constexpr int BIAS_OFF = 4 * TILE_BYTES + 8 * STG_WAVE;       // [2 slots][8 waves][64 floats]
   auto bias_dma = [&](int n0, int slot) {
     if constexpr (BIAS_LDS) {
@@ -238,32 +226,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   tile_origin(tile, m0, n0);
   if (!staged) stage_setup(m0, n0);
 
-  f32x4 acc[M32 ? 1 : MT][NTW];              // 16x16 tiles: [m-tile][n-tile]
-  f32x16 acc32[M32 ? MT / 2 : 1][2];         // 32x32 tiles: [row tile][column tile]
-  if constexpr (M32) {
+  f32x4 acc[MT][NTW];                        // 16x16 tiles: [m-tile][n-tile]
 #pragma unroll
-    for (int i = 0; i < MT / 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  // the 4 consecutive columns of unit v in row tile t (see the kernel header), whatever the MFMA shape
-  auto accv = [&](int t, int v) -> f32x4 {
-    if constexpr (M32) {
-      f32x4 r;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = acc32[t][v >> 2][4 * (v & 3) + j];
-      return r;
-    } else {
-      return acc[t][v];
-    }
-  };
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the 4 consecutive columns of unit v in row tile t (see the kernel header)
+  auto accv = [&](int t, int v) -> f32x4 { return acc[t][v]; };
 
   // piece i (i < PA: A rows i*64.., else W rows (i-PA)*64..) of the tile at A K-offset ka / W K-offset kw -> LDS buffer `buf`.
   // Inline asm: the scalar-base form (uniform 64-bit base + one 32-bit VGPR offset) keeps the per-thread
@@ -282,20 +251,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     if (!ABLATE(p, 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n_c)::value) : "memory");
     if (!ABLATE(p, 2)) __syncthreads();
   };
-  // fragment j (< NF = MT + 4) of the set of K half hf.  16x16x32: j < 4 -> W n-tile j, else A m-tile j-4, all 32 deep.
-  // 32x32x16: two 16-deep K steps, each [W column tile 0, W column tile 1, A row tile 0 .. MT/2-1], in the order the MFMAs want them.
+  // fragment j (< NF = MT + NTW) of the set of K half hf: j < NTW -> W n-tile j, else A m-tile j - NTW, all 32 deep
   auto frag = [&](const char* buf, int hf, int j) -> bf16x8 {
-    if constexpr (M32) {
-      constexpr int PER = 2 + MT / 2;
-      const int ks2 = j / PER, rem = j % PER;
-      const int fo = frag_off[2 * hf + ks2];
-      return rem < 2 ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + rem * 4096 + fo)
-                     : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (rem - 2) * 4096 + fo);
-    } else {
-      const int fo = frag_off[hf];
-      return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
-                     : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
-    }
+    const int fo = frag_off[hf];
+    return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
+                   : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
   };
   // fragments 2g, 2g+1 of a set
   // (PER fragments per MFMA group so that the MT groups of a phase cover all NF: 2 for every 256-wide shape, 3 for the 160-wide one)
@@ -307,16 +267,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   };
   // MFMA group g (of MT per K half, 64 matrix-pipe cycles each) on fragment set f
   auto mfma_group = [&](int g, const bf16x8 (&f)[NF]) {
-    if constexpr (M32) {
-      constexpr int MR = MT / 2, PER = 2 + MR;
-      const int ks2 = g / MR, r = g % MR;
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-        acc32[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ks2 * PER + c], f[ks2 * PER + 2 + r], acc32[r][c], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[nt], f[NTW + g], acc[g][nt], 0, 0, 0);
-    }
+    for (int nt = 0; nt < NTW; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[nt], f[NTW + g], acc[g][nt], 0, 0, 0);
   };
 
   // ---- main loop: two LDS buffers, two fragment sets (F0: k 0..31, F1: k 32..63 of a K block).  Per K block:
@@ -618,10 +570,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 // Second half of the tail split-K: one workgroup per (tail tile, row tile t).  Thread `te` owns the same 16-byte elements the
 // main kernel's thread `te` parked -- (row tile t, unit v) at ((t*NV+v)*512 + te)*4 of every slice's slab -- sums the slices in
 // slice order and applies the epilogue (bias, GELU-tanh, fp32 gated residual, bf16 / fp32 store) in the accumulator layout.
-template <int EPI, typename OutT, int MT, bool M32, int WMW = 2, int NTW = 4>
+template <int EPI, typename OutT, int MT, int WMW = 2, int NTW = 4>
 __global__ __launch_bounds__(512) void gemm_splitk_finish_kernel(GemmParams p) {
   constexpr int WNW = 8 / WMW, BN_ = WNW * NTW * 16;
-  constexpr int RT = M32 ? 32 : 16, NRT = 16 * MT / RT, NG = 64 / RT, NV = NTW * 4 / NG, BM_ = WMW * 16 * MT, SLAB = 256 * BN;
+  constexpr int RT = 16, NRT = 16 * MT / RT, NG = 64 / RT, NV = NTW * 4 / NG, BM_ = WMW * 16 * MT, SLAB = 256 * BN;
   const int te = threadIdx.x, lane = te & 63, wave = te >> 6, wm = wave / WNW, wn = wave % WNW;
   const int tr = blockIdx.x / NRT, t = blockIdx.x % NRT;
   const int tile = p.split_full + tr;
@@ -699,11 +651,11 @@ void plan_split(const GemmWorkspace& g_ws, int tiles, int nk, int& S, int& rem, 
   if (cost) *cost = best;
 }
 
-template <int EPI, typename OutT, int MT, bool M32, int WMW = 2, int NTW = 4>
+template <int EPI, typename OutT, int MT, int WMW = 2, int NTW = 4>
 int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
-  auto kern = gemm_bf16_kernel<EPI, OutT, MT, M32, false, WMW, NTW>;
+  auto kern = gemm_bf16_kernel<EPI, OutT, MT, false, WMW, NTW>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};          // per device: the attribute belongs to the device's copy of the code object
-  const int smem = 4 * TILE_BYTES + 8 * (M32 ? 32 : 16) * 128 + (M32 ? 0 : 2 * 8 * 256);   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots per wave
+  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 2 * 8 * 256;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots per wave
   const int dev = flexam_current_device();
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -728,7 +680,7 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
   if (p.split_full > 0) hipLaunchKernelGGL(kern, dim3(grid_for_units(p.split_full)), dim3(512), smem, s, p, a_koff);
   if (split_s > 1) {
     // the K slices of the tail tiles, then (stream-ordered) their sum in slice order + the epilogue
-    auto tail = gemm_bf16_kernel<EPI_NONE, float, MT, M32, true, WMW, NTW>;
+    auto tail = gemm_bf16_kernel<EPI_NONE, float, MT, true, WMW, NTW>;
     static bool tail_attr[FLEXAM_MAX_DEVICES] = {};
     if (!tail_attr[dev]) {
       if (hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -736,20 +688,14 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
       tail_attr[dev] = true;
     }
     hipLaunchKernelGGL(tail, dim3(grid_for_units(rem * split_s)), dim3(512), smem, s, p, a_koff);
-    hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI, OutT, MT, M32, WMW, NTW>), dim3(rem * (M32 ? MT / 2 : MT)), dim3(512), 0, s, p);
+    hipLaunchKernelGGL((gemm_splitk_finish_kernel<EPI, OutT, MT, WMW, NTW>), dim3(rem * MT), dim3(512), 0, s, p);
   }
   return flexam_check_launch("flexam_gemm_bf16");
 }
 
-// FLEXAM_GEMM_M32=1 runs even tile heights on 32 x 32 MFMA tiles.  Off by default: correct (same tests), and faster in the
-// instruction-mix probe and 10 % fewer cycles in the real kernel, but the power-capped clock falls 13 %: 3-4 % SLOWER on every DiT shape (notes #15).
 template <int EPI, typename OutT, int MT>
 int launch_mt(const GemmParams& p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
-  if constexpr (MT % 2 == 0) {
-    static const int m32 = [] { const char* e = getenv("FLEXAM_GEMM_M32"); return e ? atoi(e) : 0; }();
-    if (m32) return launch_shape<EPI, OutT, MT, true>(p, g_ws, a_koff, s);
-  }
-  return launch_shape<EPI, OutT, MT, false>(p, g_ws, a_koff, s);
+  return launch_shape<EPI, OutT, MT>(p, g_ws, a_koff, s);
 }
 
 // Tile height: rounds of 256 concurrently resident workgroups x relative cost of one tile (MT m-tiles of MFMA work
@@ -796,10 +742,6 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
     p.gm = g ? atoi(g) : (EPI == EPI_GATE_RESIDUAL && a_koff == nullptr ? (p.K >= 8192 ? 1 : 16) : 4);
     if (p.gm < 1) p.gm = 4;
   }
-  {
-    const char* st = getenv("FLEXAM_GEMM_STAGGER");      // read per call: tools/ab_stagger.py flips it inside one process
-    p.stagger = st ? atoi(st) : (EPI == EPI_GATE_RESIDUAL ? GEMM_STAGGER_DEFAULT : 0);
-  }
 #ifdef FLEXAM_GEMM_ABLATE
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
   p.debug = dbg ? atoi(dbg) : 0;
@@ -811,7 +753,7 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
     const int mode = e ? atoi(e) : 1;
     const bool narrow = p.N <= 160;                      // one 160-wide tile column instead of a 256-wide one (VAE head convs: 12 / 96 channels)
     const bool mult160 = p.N % 160 == 0 && p.N % 256 != 0 && (p.N <= 480 || mode == 2);
-    if (mode && (narrow || mult160)) return launch_shape<EPI, OutT, 4, false, 4, 5>(p, g_ws, a_koff, s);
+    if (mode && (narrow || mult160)) return launch_shape<EPI, OutT, 4, 4, 5>(p, g_ws, a_koff, s);
   }
   switch (pick_mt(g_ws, p.M, p.tiles_n, p.K / BK)) {
     case 7: return launch_mt<EPI, OutT, 7>(p, g_ws, a_koff, s);

@@ -24,6 +24,26 @@ import torch
 import torch.distributed as dist
 
 
+_SUBGROUPS = {}      # member tuple -> process group: a communicator is made once per member set and process
+
+
+def subgroup(members) -> "dist.ProcessGroup":
+    """The process group of `members` (global ranks), created on first use and cached: torch.distributed.new_group builds a new
+    communicator on every call (collective over ALL ranks, never freed), so a caller that re-selects a layout -- bench.py's layout
+    probe, repeated enable_multi_gpus_inference calls -- must not create them again.  Every rank must ask for the same member sets in
+    the same order the first time (new_group's own rule)."""
+    key = tuple(int(r) for r in members)
+    g = _SUBGROUPS.get(key)
+    if g is None:
+        g = _SUBGROUPS[key] = dist.new_group(list(key))
+    return g
+
+
+def live_subgroups() -> int:
+    """Number of sub-communicators this process has created through subgroup() (the world group is not counted)."""
+    return len(_SUBGROUPS)
+
+
 def chunk_bounds(seq_len: int, rank: int, world: int) -> Tuple[int, int]:
     """[start, end) of this rank's token chunk.  The sequence must divide evenly (11648 = 8 * 1456)."""
     if seq_len % world:

@@ -160,7 +160,8 @@ class DiTEngine:
             raise ValueError(f"FLEXAM_SP_MODE={mode!r}: expected 'ulysses' or 'allgather'")
         self.sp_mode = mode if (mode == "allgather" or self.nh % max(sp_size, 1) == 0) else "allgather"
         # local-chunk-first attention under the K|V all-gather (0: wait for the gather, then one attention call)
-        self.sp_overlap_level = int(os.environ.get("FLEXAM_SP_OVERLAP", "1"))      # all-to-all mode: 1 / 2, see _ulysses_attention
+        ov = os.environ.get("FLEXAM_SP_OVERLAP", "1").strip().lower()              # "0" / "off" / "false": off; "2": the pipelined all-to-all form;
+        self.sp_overlap_level = 0 if ov in ("0", "off", "false", "no", "") else (2 if ov == "2" else 1)      # anything else: on (1)
         self.sp_overlap = self.sp_overlap_level != 0
         # the K|V gather is cut into `sp_pieces` groups of heads, one collective each: the attention of a group starts when ITS
         # piece has landed, the later pieces travel underneath it (1: one gather per block and CFG row)
@@ -303,14 +304,12 @@ class DiTEngine:
         return self.cond
 
     # ------------------------------------------------------------------ workspace
-    def _workspace(self, B, lc, lane: int = 0):
-        """Activation buffers of one run; `lane` > 0: a second, independent set for a run that is in flight on another stream at
-        the same time (the dual-stream CFG step).  Buffers of other shapes are dropped when a new shape arrives."""
-        key = (B, lc) if lane == 0 else (B, lc, lane)
+    def _workspace(self, B, lc):
+        """Activation buffers of one run.  Buffers of other shapes are dropped when a new shape arrives."""
+        key = (B, lc)
         if key not in self._ws:
             dev, d, m = self.device, self.dim, B * lc
-            if any(k[:2] != (B, lc) for k in self._ws):
-                self._ws = {}
+            self._ws = {}
             self._ws[key] = dict(
                 x=torch.empty(m, d, device=dev, dtype=F32), h=torch.empty(m, d, device=dev, dtype=BF16),
                 qkv=torch.empty(m, 3 * d, device=dev, dtype=BF16), ao=torch.empty(m, d, device=dev, dtype=BF16),
@@ -336,16 +335,11 @@ class DiTEngine:
         return e, e0.view(R, 6, d)
 
     def run(self, x: torch.Tensor, t_rows: torch.Tensor, row_index: Optional[torch.Tensor], rows_per_batch: int,
-            only_row: Optional[int] = None, teacache=None, cond_flag: bool = True, rows_shared: bool = False, lane: int = 0,
-            fork: Optional[dict] = None) -> torch.Tensor:
+            only_row: Optional[int] = None, teacache=None, cond_flag: bool = True, rows_shared: bool = False) -> torch.Tensor:
         """x [Bx, 48, F, H, W] (Bx = B, or 1 when all rows share the latent); t_rows [R] distinct
         timesteps with R = B * rows_per_batch table rows (rows of batch b are b*rows_per_batch ..);
         row_index int32 [B * L] global table row per token, or None (then token (b, l) uses row b).
-        Returns the head output tokens fp32 [B, Lc, 4*out_dim] of this rank's token chunk.
-        lane / fork: the dual-stream CFG step (pipeline.denoise_step): two single-row runs in flight at once on two streams, each
-        with its own workspace (`lane`).  fork = dict(role, buf, event): the "producer" copies its residual stream behind block 0's
-        self-attention half -- identical for both rows -- into `buf` and records `event`; the "consumer" skips its stem and that
-        half, waits for the event and starts from the copy."""
+        Returns the head output tokens fp32 [B, Lc, 4*out_dim] of this rank's token chunk."""
         cd, dev, d = self.cond, self.device, self.dim
         B, L, lvid, ref_len = cd["B"], cd["L"], cd["lvid"], cd["ref_len"]
         # only_row: run a single conditioning row (cfg_skip: the unconditional row is dropped, cfg_optimization.py:5-37);
@@ -361,17 +355,14 @@ class DiTEngine:
             raise RuntimeError(f"sequence length {L} is not divisible by the sequence-parallel size {sp}")
         lc = L // sp
         tok0 = rank * lc
-        ws = self._workspace(B, lc, lane)
-        role = fork["role"] if fork else None
-        if role is not None and not (self.fused and sp == 1 and B == 1 and teacache is None):
-            raise RuntimeError("dual-stream runs are single-row, single-GPU, fused-path runs")
+        ws = self._workspace(B, lc)
         xres, hbuf, qkv, ao, ffn, head = ws["x"], ws["h"], ws["qkv"], ws["ao"], ws["ffn"], ws["head"]
         xr = xres.view(B, lc, d)
 
         # ---- stem: patch embedding of the noisy latent (+ cached static channels), ref tokens
         bx = x.shape[0]
         full = torch.empty(L, d, device=dev, dtype=F32) if sp > 1 else None
-        for b in range(0 if role == "consumer" else bx):
+        for b in range(bx):
             pa = cd["patch_a"][b if cd["nb"] > 1 else 0]
             hip.patchify(x[b].to(dev).contiguous(), pa, col0=0)
             dst = full if sp > 1 else xr[b]
@@ -386,6 +377,7 @@ class DiTEngine:
         # attention and projection work of a step; every later operation sees the text and runs per sample)
         share0 = (self.fused and B == 2 and bx == 1 and sp == 1 and rows_shared and cd.get("dens_same", False) and teacache is None
                   and os.environ.get("FLEXAM_SHARE_BLOCK0", "1") != "0")
+        self.share0_taken = bool(share0)
         if not share0:
             for b in range(bx, B):
                 xr[b].copy_(xr[0])
@@ -443,22 +435,14 @@ class DiTEngine:
             else:
                 T = tab[i]
             fp8_here = self.fp8
-            if i == 0 and role == "consumer":                   # the other stream's run computed this half: start from its copy
-                torch.cuda.current_stream().wait_event(fork["event"])
-                xres.copy_(fork["buf"])
             nb = 1 if (share0 and i == 0) else B               # samples that run the self-attention half of this block (share0: above)
             mb = nb * lc
             ri = row_index[:mb] if row_index is not None else None
-            skip_sa = i == 0 and role == "consumer"
-            if skip_sa:
-                pass
-            elif fp8_here:                                 # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
+            if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
                 a8, sa = self._ln_fp8(xres[:mb], ws, hbuf[:mb], shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
             else:
                 hip.ln_modulate(xres[:mb], out=hbuf[:mb], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
-            if skip_sa:
-                pass
-            elif sp > 1 and self.sp_mode == "ulysses":
+            if sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
                 # returned blocks in place (flexam_amd/dist.py)
                 a_o, koff_o = self._ulysses_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, B, lc, tok0)
@@ -478,9 +462,6 @@ class DiTEngine:
                 hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
                 if nb < B:
                     xr[1].copy_(xr[0])
-                if i == 0 and role == "producer":           # the other stream's run starts from here
-                    fork["buf"].copy_(xres)
-                    fork["event"].record(torch.cuda.current_stream())
             # cross-attention on the text context (K/V precomputed per clip)
             hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
             qc = qkv[:, 0:d]

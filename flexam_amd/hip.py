@@ -22,7 +22,7 @@ _SIGNATURES = {
     "flexam_arch": ([], c_char_p),
     "flexam_last_error": ([], c_char_p),
     "flexam_device_check": ([], c_int),
-    "flexam_set_cu_budget": ([_I], c_int),
+    "flexam_device_cus": ([], c_int),
     "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _L, _P], c_int),
     "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P], c_int),
     "flexam_quantize_rows_fp8": ([_P, _L, _P, _L, _P, _L, _I, _P], c_int),
@@ -127,18 +127,9 @@ def device_check():
     _check(lib().flexam_device_check(), "flexam_device_check")
 
 
-_CU_BUDGET = 0
-
-
-def set_cu_budget(n_cus: int = 0):
-    """Compute units the following launches plan for (0 = all): see flexam_set_cu_budget in flexam_hip.h."""
-    global _CU_BUDGET
-    _check(lib().flexam_set_cu_budget(int(n_cus)), "flexam_set_cu_budget")
-    _CU_BUDGET = int(n_cus)
-
-
-def cu_budget() -> int:
-    return _CU_BUDGET if _CU_BUDGET else 256
+def num_cus() -> int:
+    """Compute units the library plans its grids for on the current device (flexam_device_cus: 256 on MI355X)."""
+    return int(lib().flexam_device_cus())
 
 
 # ----------------------------------------------------------------------------- GEMM
@@ -312,7 +303,7 @@ def attn_fwd(q, k, v, out=None, softmax_scale=None, kv_splits=None, split_from_u
     scale = ATTN_PRESCALED if prescaled else (softmax_scale if softmax_scale is not None else D ** -0.5)
     units = B * H * ((Lq + 255) // 256)
     if kv_splits is None:
-        S, from_unit = attn_split_plan(B * H, Lq, Lk, cu_budget())
+        S, from_unit = attn_split_plan(B * H, Lq, Lk, num_cus())
     else:
         S, from_unit = int(kv_splits), (0 if split_from_unit is None else int(split_from_unit))
     if S <= 1:

@@ -242,58 +242,12 @@ class Wan2_2FunControlPipeline_FlexAM:
             self._teacache_tick(tr.teacache)
             return self._sampler_update(i, head[0], None)
         tc = tr.teacache
-        if (os.environ.get("FLEXAM_DUAL_STREAM") == "1" and st["cfg"] and st["nrow"] == 2 and tc is None and not skip_uncond
-                and eng.cfg_size == 1 and eng.sp_size == 1 and eng.fused and eng.cond.get("dens_same", False)):
-            tok_u, tok_c = self._dual_stream_heads(eng, t_rows)
-            return self._sampler_update(i, tok_u, tok_c)
         head = eng.gather_tokens(eng.run(st["latents"].unsqueeze(0), t_rows, st["row_index"], st["U"], teacache=tc, rows_shared=True))
         self._teacache_tick(tc)
         # head: [rows, L, 192] with rows = (uncond, cond) after the gather, whatever the parallel layout
         if skip_uncond:                                  # CFG-parallel ranks: both rows were computed anyway, take cond
             return self._sampler_update(i, head[1], None)
         return self._sampler_update(i, head[0], head[1] if st["cfg"] else None)
-
-    _lanes = None
-
-    def _dual_stream_heads(self, eng, t_rows):
-        """The CFG pair as TWO single-row DiT runs in flight at once on two HIP streams (experimental, FLEXAM_DUAL_STREAM=1).
-        Why: every MFMA kernel of the step runs at the chip's power limit (a pure MFMA loop on half of the CUs
-        alone reaches 94 % of its peak clock, on all CUs 73-78 %), while the LayerNorm / RMSNorm / RoPE launches between them
-        draw little and leave the matrix pipes idle.  Two sequences that are out of phase put one row's bandwidth-bound
-        launches beside the other row's GEMMs and attention.  Each persistent GEMM plans for half of the CUs
-        (flexam_set_cu_budget) so that both sequences are resident; the second row takes block 0's self-attention half --
-        identical for both rows -- from the first (which also staggers the two by that much)."""
-        from . import hip as H
-        st = self._state
-        U = st["U"]
-        n_tok = st["row_index"].numel() // st["nrow"]
-        ri = st["row_index"][:n_tok]
-        dev = st["latents"].device
-        if self._lanes is None:
-            self._lanes = dict(streams=(torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)), buf=None)
-        if self._lanes["buf"] is None or self._lanes["buf"].shape != (n_tok, eng.dim):
-            self._lanes["buf"] = torch.empty(n_tok, eng.dim, device=dev, dtype=F32)
-        main = torch.cuda.current_stream()
-        start, fork_ev = torch.cuda.Event(), torch.cuda.Event()
-        start.record(main)
-        x = st["latents"].unsqueeze(0)
-        rows_t = t_rows[:U]
-        heads, done = [], []
-        H.set_cu_budget(H.cu_budget() // 2)
-        try:
-            for lane, s in enumerate(self._lanes["streams"]):
-                s.wait_event(start)
-                with torch.cuda.stream(s):
-                    fork = dict(role="producer" if lane == 0 else "consumer", buf=self._lanes["buf"], event=fork_ev)
-                    heads.append(eng.run(x, rows_t, ri, U, only_row=lane, lane=lane, fork=fork))
-                    e = torch.cuda.Event()
-                    e.record(s)
-                    done.append(e)
-        finally:
-            H.set_cu_budget(0)
-        for e in done:
-            main.wait_event(e)
-        return heads[0][0], heads[1][0]
 
     @staticmethod
     def _teacache_tick(tc):

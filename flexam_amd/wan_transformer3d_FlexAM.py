@@ -487,22 +487,42 @@ class WanTransformer3DModel_FlexAM(nn.Module):
                 self._engine.enable_fp8(True)
         return self._engine
 
+    def trust_conditioning_identity(self, on: bool = True):
+        """Opt-in shortcut for callers that pass the SAME conditioning tensor objects on every step and never write them behind
+        PyTorch's back: when every tensor of a call is the very object of the last call (same storage, same version counter) the
+        content key of that call is reused and forward() makes no readback.  Off by default: `_version` only counts PyTorch's own
+        in-place operations -- a buffer refilled through `.data`, DLPack, a raw pointer (this library's own out= kernels) or another
+        framework keeps its version, and the shortcut would then serve the previous clip's per-clip state.  `invalidate_conditioning()`
+        drops the remembered identity by hand."""
+        self._trust_ident = bool(on)
+        self._cond_ident = None
+
+    def invalidate_conditioning(self):
+        """Forget the last call's conditioning (its content key and, with trust_conditioning_identity, its identity)."""
+        self._cond_key = None
+        self._cond_ident = None
+
     def _conditioning_key(self, context, y, full_ref, additional_control, density, latent_shape):
         """Content key of the step-invariant inputs.  The reference sampler rebuilds them with torch.cat on every step
-        (PIPE.py:850-886), so identity says nothing about a change -- but identity DOES prove "unchanged": when every tensor is the
-        very object of the last call (same storage, same version counter) the key of that call is reused with no device work.
-        Otherwise one checksum launch per tensor into one buffer and ONE readback (~120 MB hashed in microseconds, against the
-        cnn-block, the text MLP and 30 cross-K/V GEMMs a hit saves).  The RoPE variant is part of the key: the rotation tables
-        live in the per-clip state."""
+        (PIPE.py:850-886), so identity says nothing about a change: one checksum launch per tensor into one buffer and ONE readback
+        (~120 MB hashed in microseconds, against the cnn-block, the text MLP and 30 cross-K/V GEMMs a hit saves).  The RoPE variant
+        is part of the key: the rotation tables live in the per-clip state.  With trust_conditioning_identity(True) a call whose
+        tensors are the very objects of the last call (weak references still alive, same storage, same version counter) skips
+        the readback; nothing is kept alive for it."""
+        import weakref
         from . import hip
         tensors = [v for v in (y, full_ref, additional_control, density, *context) if v is not None]
-        ident = (tuple(latent_shape), self._riflex, tuple((id(v), v.data_ptr(), v._version, tuple(v.shape), v.dtype) for v in tensors),
-                 tuple(v is None for v in (y, full_ref, additional_control, density)))
-        if self._cond_ident is not None and self._cond_ident[0] == ident:
-            return self._cond_ident[1]
+        nones = tuple(v is None for v in (y, full_ref, additional_control, density))
+        trust = getattr(self, "_trust_ident", False)
+        if trust:
+            ident = (tuple(latent_shape), self._riflex, nones, tuple((v.data_ptr(), v._version, tuple(v.shape), v.dtype) for v in tensors))
+            last = self._cond_ident
+            if (last is not None and last[0] == ident and len(last[2]) == len(tensors)
+                    and all(r() is v for r, v in zip(last[2], tensors))):
+                return last[1]
         sums = hip.checksums(tensors)
-        key = (tuple(latent_shape), self._riflex, ident[3], tuple((tuple(v.shape), str(v.dtype), c) for v, c in zip(tensors, sums)))
-        self._cond_ident = (ident, key, tensors)          # the tensors are kept alive so that id() / data_ptr() cannot be recycled
+        key = (tuple(latent_shape), self._riflex, nones, tuple((tuple(v.shape), str(v.dtype), c) for v, c in zip(tensors, sums)))
+        self._cond_ident = (ident, key, [weakref.ref(v) for v in tensors]) if trust else None
         return key
 
     # ------------------------------------------------------------------ feature switches (reference API)
@@ -584,7 +604,8 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         if cfg_parallel:
             sp = world // 2
             members = dist.get_process_group_ranks(group) if group is not None else list(range(world))
-            halves = [dist.new_group(members[i * sp:(i + 1) * sp]) for i in range(2)]     # every rank creates both
+            from .dist import subgroup
+            halves = [subgroup(members[i * sp:(i + 1) * sp]) for i in range(2)]     # every rank creates both, once per process
             self._parallel = dict(sp_group=halves[rank // sp], sp_rank=rank % sp, sp_size=sp, world_group=group, world_size=world,
                                   cfg_size=2, cfg_row=rank // sp)
             self.sp_world_size, self.sp_world_rank = sp, rank % sp

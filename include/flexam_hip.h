@@ -38,14 +38,12 @@ extern "C" {
 int flexam_version(void);
 const char* flexam_arch(void);          /* "gfx950" */
 const char* flexam_last_error(void);
-int flexam_device_check(void);
+int flexam_device_check(void);        /* FLEXAM_E_ARCH unless the current device is gfx950 */
 
-/* Compute units the calling thread's following launches plan for (0 = the whole device, the default; else a multiple of 8):
- * persistent GEMM grids, tail split-K and tile-height plans use it instead of the device's CU count.  For a caller that runs two
- * independent launch sequences on two streams at once (the two CFG samples of a denoise step, DiTEngine's dual-stream mode): with
- * one persistent workgroup per CU a 256-workgroup GEMM would hold every CU and the other stream's kernels could not run beside
- * it.  Host-side planning only: nothing is reserved on the device. */
-int flexam_set_cu_budget(int n_cus);          /* FLEXAM_E_ARCH unless the current device is gfx950 */
+/* Compute units of the current device that the library plans its grids for (the device's CU count rounded down to a multiple
+ * of 8: one persistent workgroup per CU, blockIdx & 7 = XCD; 256 on MI355X).  Callers that plan work units themselves -- the
+ * key split of flexam_attn_fwd_splitkv -- use the same figure. */
+int flexam_device_cus(void);
 
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]); A, W bf16 row-major with K contiguous (nn.Linear
  * weight layout), fp32 accumulate on MFMA; C bf16 (out_f32 = 0) or fp32 (out_f32 = 1).

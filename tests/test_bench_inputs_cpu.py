@@ -48,14 +48,13 @@ def test_block_flops_match_the_survey_figures():
     assert abs(tf - 5.131) < 2e-3                                                # 5.131 TFLOP per block and sample
 
 
-def test_attention_split_plan_follows_the_cu_budget():
+def test_attention_split_plan_follows_the_cu_count():
     from flexam_amd import hip
     # DiT self-attention, CFG pair: 2208 units = 8 full rounds of 256 + 160 -> only the last round is split
     s, start = hip.attn_split_plan(48, 11648, 11648, 256)
     assert start == 2048 and s >= 2
-    # one row on half of the CUs (the dual-stream step): 1104 units = 8 rounds of 128 + 80
+    # one row planned for 128 CUs: 1104 units = 8 rounds of 128 + 80
     s, start = hip.attn_split_plan(24, 11648, 11648, 128)
     assert start == 1024 and s >= 2
     # a whole number of rounds: nothing to split
     assert hip.attn_split_plan(16, 4096, 4096, 256) == (1, 256)
-    assert hip.cu_budget() == 256

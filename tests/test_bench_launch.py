@@ -47,7 +47,8 @@ def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
     if world >= 4 and not env:             # nothing pinned: two steps of every candidate layout were timed and the fastest one ran
         lp = res["layout_probe"]
         assert len(lp["candidates"]) == 4 and lp["chosen"] in [c["layout"] for c in lp["candidates"]]
-        assert all(c["ms_per_step"] > 0 for c in lp["candidates"])
+        assert all(c["ms_per_step"] > 0 and c["wall_sec"] > 0 for c in lp["candidates"])
+        assert lp["communicators"] <= 3, lp                 # world + the two CFG halves, however many layouts were selected
     else:
         assert "layout_probe" not in res
 
@@ -56,7 +57,7 @@ def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
 def test_launcher_falls_back_to_the_conservative_exchange_when_the_check_fails():
     """A failed self-check of the first attempt (forced here) must cost one more attempt with FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0,
     not the measurement: the forwarded line is the second attempt's, says so, and keeps the first attempt's verdict."""
-    r = _run(["--gpus", "4", *SMALL], {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1"})
+    r = _run(["--gpus", "4", *SMALL], {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_TEST_HOOKS": "1", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1"})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -86,7 +87,7 @@ def _torchrun(world, args, env_extra, timeout=900):
 def test_ranks_started_by_torchrun_remeasure_on_the_conservative_exchange_when_the_check_fails():
     """Under the caller's own torch.distributed.run there is no parent to start a second attempt: a failed self-check (forced) makes the
     SAME processes switch to FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0, measure again and check again; the line keeps the first verdict."""
-    r = _torchrun(4, SMALL, {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1"})
+    r = _torchrun(4, SMALL, {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_TEST_HOOKS": "1", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1"})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1
@@ -113,3 +114,23 @@ def test_bench_under_rccl_when_the_box_has_two_gpus():
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert res["n_gpus"] == 2 and res["rccl_ranks"] == 2 and res["check"]["ok"] and "invalid" not in res
+
+
+@pytest.mark.gpu
+def test_probe_skips_a_candidate_that_raises_or_blows_its_budget_and_goes_on():
+    """r3 verdict item 4: a candidate that raises is recorded in layout_probe.skipped and the probe continues (test hook: candidate 1
+    raises a RuntimeError on every rank); a first step over the budget skips the candidate too -- with a zero budget nothing is
+    measured, the default layout runs, and the line still carries a passed self-check."""
+    base = {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_TEST_HOOKS": "1"}
+    r = _run(["--gpus", "4", *SMALL], {**base, "FLEXAM_BENCH_PROBE_RAISE": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    lp = res["layout_probe"]
+    assert len(lp["candidates"]) == 3 and len(lp["skipped"]) == 1 and "RuntimeError" in lp["skipped"][0]["error"]
+    assert lp["chosen"] in [c["layout"] for c in lp["candidates"]] and res["check"]["ok"] and lp["communicators"] <= 3
+    r = _run(["--gpus", "4", *SMALL], {**base, "FLEXAM_BENCH_PROBE_BUDGET": "0"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    lp = res["layout_probe"]
+    assert lp["candidates"] == [] and len(lp["skipped"]) == 4 and lp["chosen"].startswith("none measured")
+    assert res["check"]["ok"] and res["config"]["parallelism"].startswith("cfg2 x sp2")

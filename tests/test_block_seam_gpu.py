@@ -218,3 +218,41 @@ def test_state_dict_round_trip_with_aliased_qkv():
     for k, v in sd.items():
         assert got[k].shape == v.shape
         torch.testing.assert_close(got[k].float().cpu(), v.to(torch.bfloat16).float(), rtol=0, atol=0)
+
+
+def test_conditioning_rewritten_behind_pytorchs_back_is_seen_unless_identity_is_trusted():
+    """r3 advisor (medium): a persistent conditioning buffer refilled without a version bump (`.data`, a raw pointer, another
+    framework) must NOT be served the previous clip's per-clip state.  Default: every forward() hashes the conditioning (one
+    readback), so the rewrite is seen.  With trust_conditioning_identity(True) the caller has promised not to do that: the
+    shortcut takes the same objects for unchanged (documented), and invalidate_conditioning() is the way out."""
+    cfg = dict(O.DIT_TINY)
+    m, sd = build(cfg, 7)
+    case = C.dit_case(cfg, 43)
+    d = to_dev(case)
+    eng = m.engine()
+    n0 = eng.n_conditioning
+    m(**d)
+    m(**d)
+    assert eng.n_conditioning == n0 + 1                    # same content: one set_conditioning
+    v = d["y"]._version
+    d["y"].data[:, 60] += 0.5                              # rewritten in place, version counter untouched
+    assert d["y"]._version == v
+    out = m(**d)
+    assert eng.n_conditioning == n0 + 2                    # ... and still seen
+    case2 = dict(case, y=case["y"].clone())
+    case2["y"][:, 60] += 0.5
+    check(out, O.dit_forward(sd, cfg, **case2), "conditioning rewritten through .data")
+    m.trust_conditioning_identity(True)
+    m(**d)
+    m(**d)                                                 # same objects: no hash, no readback, same state
+    assert eng.n_conditioning == n0 + 2
+    d["y"].data[:, 61] += 0.5                              # the documented hazard: not seen ...
+    m(**d)
+    assert eng.n_conditioning == n0 + 2
+    m.invalidate_conditioning()                            # ... until the caller says so
+    out = m(**d)
+    assert eng.n_conditioning == n0 + 3
+    case2["y"][:, 61] += 0.5
+    check(out, O.dit_forward(sd, cfg, **case2), "after invalidate_conditioning")
+    m.trust_conditioning_identity(False)
+    assert m._cond_ident is None

@@ -314,3 +314,36 @@ def _head_group_pieces(rank, world):
 def test_head_group_pieces_and_chunk_arrival_orders(world):
     errs = run_world(_head_group_pieces, world)
     assert max(errs) < 1e-5, errs
+
+
+def _layout_reselection(rank, world):
+    """What bench.py's layout probe does to the communicators: every candidate layout and then the winner call
+    enable_multi_gpus_inference -- twice over (the probe run twice in one process)."""
+    from flexam_amd.dist import live_subgroups
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+    cfg = dict(O.DIT_TINY, num_layers=1)
+    kw = dict(cfg)
+    kw.pop("eps")
+    m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    seen = []
+    for _ in range(2):                                     # the whole probe, twice
+        for cfgp in (True, True, False, False, True, None):
+            m.enable_multi_gpus_inference(cfg_parallel=cfgp)
+            par = m._parallel
+            seen.append((par.get("cfg_size", 1), par["sp_size"], live_subgroups()))
+            if par.get("cfg_size", 1) == 2:                # the cached half group is a working communicator of the right members
+                t = torch.tensor([float(rank)])
+                dist.all_reduce(t, group=par["sp_group"])
+                half = rank // (world // 2)
+                assert float(t) == sum(range(half * (world // 2), (half + 1) * (world // 2)))
+    return seen
+
+
+def test_cfg_half_groups_are_created_once_per_member_set():
+    """r3 verdict item 4: enable_multi_gpus_inference created two new process groups on EVERY call; a layout probe of four candidates
+    plus the winner left a dozen communicators alive on the first RCCL run.  Now the halves are cached by member tuple: the world
+    group + 2, however often a layout is selected."""
+    res = run_world(_layout_reselection, world=4)
+    for seen in res:
+        assert max(n for _, _, n in seen) == 2 and seen[-1][2] == 2
+        assert [c for c, _, _ in seen[:6]] == [2, 2, 1, 1, 2, 2]          # None -> the default for 4 ranks with the all-gather: 2 x 2

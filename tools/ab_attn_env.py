@@ -1,4 +1,4 @@
-"""Dev tool: same-process A/B of one attention launcher switch read per call (FLEXAM_ATTN_FUSED_TAIL, FLEXAM_ATTN_PRIO ...) on the
+"""Dev tool: same-process A/B of one attention launcher switch read per call (FLEXAM_ATTN_FUSED_TAIL, FLEXAM_ATTN_BODY ...) on the
 self-attention shapes of 1 / 2 / 4 / 8 ranks (B, Lq) with all keys.  usage: ab_attn_env.py VAR v1 v2 ...; checks that the arms agree."""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

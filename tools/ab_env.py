@@ -1,4 +1,4 @@
-"""Dev tool: one environment switch of the GEMM launcher (read per call: FLEXAM_GEMM_GM, FLEXAM_GEMM_STAGGER, FLEXAM_GEMM_MT ...) on the
+"""Dev tool: one environment switch of the GEMM launcher (read per call: FLEXAM_GEMM_GM, FLEXAM_GEMM_MT ...) on the
 DiT shapes, round-robin in one process, medians.  usage: ab_env.py VAR v1 v2 ..."""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
