@@ -149,6 +149,9 @@ __device__ __forceinline__ float pair_sum(float x) {
 // (A 4-wave x 64-row variant -- each K/V fragment feeding two MFMAs -- was tried in r1: hipcc cannot keep
 //  Q in the accumulator file and spills 150+ VGPRs; see DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
+#ifndef A32_DEFER
+#define A32_DEFER 4      // scores of a half tile whose exp2 / sum / pack wait for part A of the next step (see stepA); 0 = none
+#endif
 constexpr int NT = 512;
 constexpr int NSLOT = 4;
 constexpr int V_RING = NSLOT * KV_TILE_BYTES;   // LDS: [4 K slots][4 V slots]
@@ -381,9 +384,31 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   // A half-tile step g in two parts.  Part A: first half of S(g+1) on the matrix pipe (fragments read during the previous step) |
   // row maximum of S(g) on the VALU, and the (rare) deferred rescale.  Part B: second half of S(g+1) and PV(g-1) on the matrix pipe |
   // exp2 / row sum / pack of S(g) on the VALU.
+  // DEF scores of every half are exponentiated one part later -- in part A of the NEXT step, whose 4 MFMAs otherwise run beside a
+  // dependent chain of 9 maxima only -- instead of in part B beside 12 MFMAs, 16 exp2, 16 adds and 8 packs: P(g) is not needed
+  // before PV(g) in part B of step g+1.  They wait in s_pend in the units of the reference of their own step; finish_pending runs
+  // BEFORE the next step's rescale decision, so a rescale finds them where it expects them: in l_run and in the packed pf_prev.
+  // 4 of 16: +0.8 ... 1.0 % alone, -0.6 ... -0.9 % on the step; 6: about the same; 2 and 8: nothing (profiles/r4g_*).
+  constexpr int DEF = PRE ? A32_DEFER : 0;
+  float s_pend[DEF > 0 ? DEF : 1];
+#pragma unroll
+  for (int i = 0; i < (DEF > 0 ? DEF : 1); ++i) s_pend[i] = -INFINITY;
+  auto finish_pending = [&]() __attribute__((always_inline)) {
+    if constexpr (DEF > 0) {
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < DEF; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(s_pend[i]);
+        ps = i == 0 ? pv : ps + pv;
+        pf_prev[1][8 - DEF + i] = f2bf(pv);
+      }
+      l_run += ps;
+    }
+  };
   auto stepA = [&](int g, f32x16& s_cur, f32x16& s_nxt) __attribute__((always_inline)) {
     mask_half(g, s_cur);             // keys past Lk -> -inf (uniform branch, only taken in the last tile)
     qk_mma(IC<0>{}, kf_pre, s_nxt);
+    finish_pending();
     const float m0 = vmax8(s_cur[0], s_cur[1], s_cur[2], s_cur[3], s_cur[4], s_cur[5], s_cur[6], s_cur[7]);
     const float m1 = vmax8(s_cur[8], s_cur[9], s_cur[10], s_cur[11], s_cur[12], s_cur[13], s_cur[14], s_cur[15]);
     // the test needs no row maximum: any(lane maximum > THR) over the wave is any(row maximum > THR); the exchange between the
@@ -441,14 +466,17 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     qk_read(IC<((g8 + 2) & 7)>{}, IC<0>{}, kf_pre);          // for the next step's part A
     const float mc = PRE ? 0.f : m_run * c;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    for (int e = 0; e < 16 - DEF; ++e) {
       const float pv = PRE ? __builtin_amdgcn_exp2f(s_cur[e]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[e], c, -mc));
       psum = e == 0 ? pv : psum + pv;                       // (0 + x is an instruction: x may be -0 as far as the compiler knows)
       pn[e >> 3][e & 7] = f2bf(pv);
     }
+#pragma unroll
+    for (int i = 0; i < DEF; ++i) s_pend[i] = s_cur[16 - DEF + i];
     l_run += psum;
     pf_prev[0] = pn[0];            // PV(g-1) above consumed the old value (program order)
-    pf_prev[1] = pn[1];
+#pragma unroll
+    for (int e = 0; e < 8 - DEF; ++e) pf_prev[1][e] = pn[1][e];      // the other DEF elements: finish_pending
     // pin the softmax results here: hipcc otherwise sinks the whole exp chain below the next step's branch
     asm volatile("" : "+v"(pf_prev[0]), "+v"(pf_prev[1]), "+v"(l_run));
     // Block B schedule: hipcc otherwise emits the 12 MFMAs first and the exp chain after them, leaving the matrix
@@ -457,7 +485,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < 12; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 4 : 5, 0);   // VALU (exp2 / fma / add / cvt)
+      __builtin_amdgcn_sched_group_barrier(0x002, PRE ? (DEF >= 4 ? 3 : 4) : 5, 0);   // VALU (exp2 / fma / add / cvt)
     }
   };
 
@@ -466,17 +494,22 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   // copy with two conditional barrier sites -1.4 % alone and +1.1 % on the step.
   auto tile = [&](int t, auto t4_c) __attribute__((always_inline)) {       // t4 = t mod 4 as a compile-time constant
     constexpr int t4 = decltype(t4_c)::value;
-    if (t > 0) {
-      // top of 64-key tile t: tile t+1 (issued one tile ago) has landed and becomes visible; the slot of tile
-      // t-2 (last read by the PV of its second half, in the previous step) is free again
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // K pieces of tile t+2 now, its V pieces between the two half-tile steps: two short bursts of LDS-DMA issue per tile instead
-    // of one of four per wave right after the barrier (-1.2...-1.6 % time; placements inside the steps' MFMA blocks were slower)
-    if (t + 2 < ntiles) issue_tile(t + 2, 1);
+    auto top = [&](int tt) __attribute__((always_inline)) {
+      if (tt > 0) {
+        // top of 64-key tile tt: tile tt+1 (issued one tile ago) has landed and becomes visible; the slot of tile
+        // tt-2 (last read by the PV of its second half) is free again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // K pieces of tile tt+2 now, its V pieces half a tile later: two short bursts of LDS-DMA issue per tile instead
+      // of one of four per wave right after the barrier (-1.2...-1.6 % time; placements inside the steps' MFMA blocks were slower)
+      if (tt + 2 < ntiles) issue_tile(tt + 2, 1);
+    };
+    // (every wave with its barrier between parts A and B of the odd step instead: +1.1 % alone, -0.7 % on the step, not additive
+    //  with the deferred scores: profiles/r4g_*)
+    top(t);
     stepA(2 * t, s_a, s_b);
     stepB(IC<2 * t4>{}, s_a, s_b);
     if (t + 2 < ntiles) issue_tile(t + 2, 2);
@@ -495,6 +528,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   if (rem > 1) tile(t + 1, IC<1>{});
   if (rem > 2) tile(t + 2, IC<2>{});
   // pending PV of the last half (2*ntiles - 1): its slot is (ntiles - 1) & 3
+  finish_pending();
   switch ((ntiles - 1) & 3) {
     case 0: pv_half(IC<1>{}); break;
     case 1: pv_half(IC<3>{}); break;
