@@ -152,6 +152,18 @@ __device__ __forceinline__ float pair_sum(float x) {
 #ifndef A32_DEFER
 #define A32_DEFER 4      // scores of a half tile whose exp2 / sum / pack wait for part A of the next step (see stepA); 0 = none
 #endif
+#ifdef FLEXAM_ATTN_STAMPS      // diagnostic builds only (MI355X_MICROARCH.md, DVFS give-back item 6): the in-kernel clock of the main loop
+__device__ unsigned long long g_attn_stamps[2 * 8192];      // per workgroup: shader cycles and 100 MHz ticks across the tile loop; read by nobody on the device
+#define ATTN_STAMP_BEGIN() const unsigned long long st0_ = __builtin_amdgcn_s_memtime(), sr0_ = __builtin_amdgcn_s_memrealtime()
+#define ATTN_STAMP_END()                                                             \
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {                                       \
+    g_attn_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0_;             \
+    g_attn_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0_;     \
+  }
+#else
+#define ATTN_STAMP_BEGIN()
+#define ATTN_STAMP_END()
+#endif
 constexpr int NT = 512;
 constexpr int NSLOT = 4;
 constexpr int V_RING = NSLOT * KV_TILE_BYTES;   // LDS: [4 K slots][4 V slots]
@@ -516,6 +528,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     stepA(2 * t + 1, s_b, s_a);
     stepB(IC<2 * t4 + 1>{}, s_b, s_a);
   };
+  ATTN_STAMP_BEGIN();
   int t = 0;
   for (; t + 4 <= ntiles; t += 4) {
     tile(t, IC<0>{});
@@ -535,6 +548,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     case 2: pv_half(IC<5>{}); break;
     default: pv_half(IC<7>{}); break;
   }
+  ATTN_STAMP_END();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: O[q][32dt + 8i + 4h + (0..3)] = o_acc[dt][4i + (0..3)] / l
@@ -580,462 +594,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The same pipeline on v_mfma_f32_16x16x32_bf16 (half the cycles per instruction, twice the instructions; the chip holds a
-// higher clock on this shape under its power limit: MI355X_MICROARCH.md, DVFS give-back item 7).  What changes with the shape:
-//  * S^T tiles are [16 keys][16 queries]: lane (i = lane & 15, g4 = lane >> 4) holds 4 keys of query i per tile, and the wave's 32
-//    query rows x 32 keys of a half tile are 2 (kt) x 2 (qt) tiles -- a lane holds 8 scores of each of TWO query rows.  A row's
-//    scores sit in the four lanes {i, i+16, i+32, i+48}; the common path needs no cross-lane step at all: the rescale test is
-//    any(lane maximum > THR) over the wave, row sums stay per-lane partial sums until the epilogue, and the packed P registers
-//    ARE the B operand of O^T += V^T.P^T (k slot 8*g4 + e of a 32-key step = key 16*(e >> 2) + 4*sigma(g4) + (e & 3));
-//  * the key a lane group holds is permuted (sigma swaps the two bits of g4) so that the two 4-row blocks a 32-lane half reads with
-//    ds_read_b64_tr_b16 are 8 rows apart: conflict-free on image (b) (cdna_hip_programming.md T10); the K ring has its own swizzle
-//    (chunk ^ (row & 15)): the 16-row A-operand read is 2-way on image (b) and conflict-free on this one (tools/lds_sim.py);
-//  * O^T is 8 (d) x 2 (q) tiles of 16 x 16: a lane holds 4 consecutive d of a row per tile; the epilogue turns the wave's 32 x 128
-//    block around in LDS and stores whole 256-byte rows.
-// ------------------------------------------------------------------------------------------------
-#ifndef A16_KPRE
-#define A16_KPRE 2
+#ifdef FLEXAM_ATTN_BODY16
+#include "attn_body16.inc"
 #endif
-#ifndef A16_ROWSUM_MFMA
-#define A16_ROWSUM_MFMA 0
-#endif
-#ifndef A16_SCHED
-#define A16_SCHED 0
-#endif
-__device__ __forceinline__ int sigma4(int g) { return ((g & 1) << 1) | (g >> 1); }
-
-template <int KIND, bool PRE>
-__global__ __launch_bounds__(NT, 2) void attn_fwd16_kernel(AttnParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 K tiles][4 V tiles], each a ring
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, g4 = lane >> 4;
-  const int sg = sigma4(g4);
-
-  auto eighth = [](int n, int xcd, int local) -> int {      // index into a list of n items, -1 past this XCD's share
-    const int q = n >> 3, rr = n & 7;
-    if (local >= q + (xcd < rr ? 1 : 0)) return -1;
-    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
-  };
-  int split = 0, ul, unit, tps = p.tiles_per_split, partial = p.partial;
-  {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int wmax = (p.whole_units + 7) >> 3;
-    if (local < wmax) {
-      unit = eighth(p.whole_units, xcd, local);
-      if (unit < 0) return;
-      ul = unit;
-      tps = (p.Lk + KVBLK - 1) / KVBLK;
-      partial = 0;
-    } else {
-      const int j = eighth(p.n_units * p.kv_splits, xcd, local - wmax);
-      if (j < 0) return;
-      split = j / p.n_units;
-      ul = j - split * p.n_units;
-      unit = p.unit0 + ul;
-    }
-  }
-  const int qb = unit % p.q_blocks;
-  const int bh = unit / p.q_blocks;
-  const int head = bh % p.H, b = bh / p.H;
-
-  const bf16* qbase = p.q + (int64_t)b * p.q_bs + head * HD;
-  const char* kbase = (const char*)(p.k + (int64_t)b * p.k_bs + head * HD);
-  const char* vbase = (const char*)(p.v + (int64_t)b * p.v_bs + head * HD);
-
-  // ---- Q fragments (B operand of S^T = K.Q^T): lane (i, g4) holds Q[q0 + 16 qt + i][32 ds + 8 g4 .. + 7]
-  const int q0 = qb * QBLK + wave * 32;
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const int qrow = min(q0 + 16 * qt + li, p.Lq - 1);
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *(const bf16x8*)(qbase + (int64_t)qrow * p.q_rs + ds * 32 + g4 * 8);
-  }
-
-  // ---- LDS read addresses.  K: A-operand row i of a 16-key tile is key 4 sigma(i >> 2) + (i & 3); chunk 4 ds + g4 of that row sits
-  //      at slot chunk ^ row.  V: lane 4 q' + p' of group g4 supplies row 4 sigma(g4) + q', columns 16 dt + 4 p' .. of image (b).
-  const char* kaddr[4];
-  {
-    const int krow = 4 * sigma4(li >> 2) + (li & 3);
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) kaddr[ds] = smem + 256 * krow + 16 * ((4 * ds + g4) ^ krow);
-  }
-  const char* vaddr[8];
-  {
-    const int q_ = li >> 2, p_ = li & 3;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) vaddr[dt] = smem + V_RING + kv_off(4 * sg + q_, 2 * dt + (p_ >> 1)) + 8 * (p_ & 1);
-  }
-
-  // ---- LDS-DMA staging (as in the 32x32 kernel; the K pieces carry the K swizzle)
-  const int tiles_all = (p.Lk + KVBLK - 1) / KVBLK;
-  const int t0 = split * tps;
-  const int ntiles = min(tps, tiles_all - t0);
-  const unsigned k_step = (unsigned)(KVBLK * p.k_rs * 2), v_step = (unsigned)(KVBLK * p.v_rs * 2);
-  // piece i (rows 32 i .. 32 i + 31 of the tile) differs from piece 0 by a uniform 32 rows (both swizzles repeat every 16 rows): it
-  // rides on the scalar base, ONE per-lane offset register per ring
-  unsigned k_go, v_go;
-  {
-    const int row = tid >> 4;
-    k_go = (unsigned)row * (k_step >> 6) + (unsigned)(((tid & 15) ^ (row & 15)) * 16);           // k_step / 64 = bytes per key row
-    v_go = (unsigned)row * (v_step >> 6) + (unsigned)(((tid & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 16);
-  }
-  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-  auto issue_tile = [&](int t, int parts = 3) {      // parts: 1 = K, 2 = V
-    const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * KV_TILE_BYTES + wave * 1024);
-    const int tg = t0 + t;
-    if ((tg + 1) * KVBLK <= p.Lk) {
-      const char* kt = kbase + (size_t)((unsigned)tg * k_step);
-      const char* vt = vbase + (size_t)((unsigned)tg * v_step);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (parts & 1) lds_dma16_sbase(kt + (size_t)(i * (k_step >> 1)), k_go, slot + i * 8192);
-        if (parts & 2) lds_dma16_sbase(vt + (size_t)(i * (v_step >> 1)), v_go, slot + V_RING + i * 8192);
-      }
-    } else {                                 // last, partial tile: rows past Lk re-read the last key (masked later)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (tid + NT * i) >> 4;
-        const int kcol = ((tid & 15) ^ (row & 15)) * 16;
-        const int vcol = ((tid & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 16;
-        const int key = min(tg * KVBLK + row, p.Lk - 1);
-        if (parts & 1) lds_dma16(kbase + ((int64_t)key * p.k_rs * 2 + kcol), slot + i * 8192);
-        if (parts & 2) lds_dma16(vbase + ((int64_t)key * p.v_rs * 2 + vcol), slot + V_RING + i * 8192);
-      }
-    }
-  };
-
-  // row references (PRE: in exp2 units, the initial accumulator of every S^T chain; else the running row maximum in raw units),
-  // one per query tile of the lane
-  f32x4 negref[2];
-  float ref[2] = {0.f, 0.f}, m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-#if A16_ROWSUM_MFMA
-  // row sums on the matrix pipe: l^T += 1 . P^T beside O^T += V^T . P^T (one more 16 x 16 tile per query tile and 32 keys instead of
-  // 16 v_add per lane); every register of the tile, in every lane group, then holds the whole row sum of query lane & 15
-  f32x4 l_acc[2];
-  bf16x8 ones;
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) l_acc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-  asm volatile("" : "+v"(ones));
-#endif
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) negref[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const float c = p.scale_log2e;
-
-  // K fragments of key tile kt (16 keys) of half tile `ghalf` -> registers: 4 reads, each feeds both query tiles
-  auto qk_read = [&](auto ghalf_c, auto kt_c, bf16x8 (&kf)[4], int ds_lo = 0, int ds_hi = 4) {
-    constexpr int ghalf = decltype(ghalf_c)::value, kt = decltype(kt_c)::value;
-    constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
-    constexpr int imm = slot * KV_TILE_BYTES + (ghalf & 1) * 8192 + kt * 4096;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds)
-      if (ds >= ds_lo && ds < ds_hi) kf[ds] = *(const bf16x8*)(kaddr[ds] + imm);
-  };
-  // ... and the 8 MFMAs of the two S^T tiles (qt = 0, 1) of that key tile
-  auto qk_mma = [&](const bf16x8 (&kf)[4], f32x4 (&sk)[2]) {
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds)
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        if (ds == 0) {
-          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-          sk[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf[qt][ds], PRE ? negref[qt] : zero, 0, 0, 0);
-        } else {
-          sk[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ds], qf[qt][ds], sk[qt], 0, 0, 0);
-        }
-      }
-  };
-  constexpr int KPRE = A16_KPRE;   // fragments of key tile 0 of the NEXT half tile read one step ahead (all 4 do not fit the register file)
-  bf16x8 kf_pre[4];
-  const float last_bias = PRE ? p.last_key_bias : p.last_key_bias / p.scale_log2e;
-  auto mask_half = [&](int g, f32x4 (&s)[2][2]) {
-    const int gg = 2 * t0 + g;
-    if ((gg + 1) * 32 > p.Lk || g >= 2 * ntiles || (p.last_key_bias != 0.f && (gg + 1) * 32 == p.Lk)) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int key = gg * 32 + 16 * kt + 4 * sg + e;
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) {
-            if (key >= p.Lk || g >= 2 * ntiles) s[kt][qt][e] = -INFINITY;
-            else if (key == p.Lk - 1) s[kt][qt][e] += last_bias;
-          }
-        }
-    }
-  };
-  f32x4 o_acc[8][2];
-#pragma unroll
-  for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 pf_prev[2];       // packed P of the previous half: the B operand of its 32-key step, one per query tile
-  auto pv_half = [&](auto ghalf_c) {
-    constexpr int ghalf = decltype(ghalf_c)::value;
-    constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
-    constexpr int imm = slot * KV_TILE_BYTES + (ghalf & 1) * 8192;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[dt] + imm));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[dt] + imm + 4096));
-      const bf16x4 lo_b = __builtin_bit_cast(bf16x4, lo), hi_b = __builtin_bit_cast(bf16x4, hi);
-      bf16x8 vf;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vf[e] = lo_b[e];
-        vf[4 + e] = hi_b[e];
-      }
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) o_acc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf_prev[qt], o_acc[dt][qt], 0, 0, 0);
-    }
-#if A16_ROWSUM_MFMA
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) l_acc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf_prev[qt], l_acc[qt], 0, 0, 0);
-#endif
-  };
-  // a query row's value from its four lanes (rare path only)
-  auto row_max = [&](float x) -> float {
-    x = fmaxf(x, __shfl_xor(x, 16, 64));
-    return fmaxf(x, __shfl_xor(x, 32, 64));
-  };
-
-  // ---- prologue
-  *(u32x4*)(smem + V_RING + (NSLOT - 1) * KV_TILE_BYTES + 8192 + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
-  issue_tile(0);
-  if (ntiles > 1) issue_tile(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 s_a[2][2], s_b[2][2];         // scores of the current / next half [kt][qt], ping-ponged statically
-  {
-    bf16x8 kf[4];
-    qk_read(IC<0>{}, IC<0>{}, kf);
-    qk_mma(kf, s_a[0]);
-    qk_read(IC<0>{}, IC<1>{}, kf);
-    qk_mma(kf, s_a[1]);
-  }
-  qk_read(IC<1>{}, IC<0>{}, kf_pre, 0, KPRE);
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pf_prev[qt][e] = (bf16)0.f;
-
-  auto step = [&](int g, auto g8_c, f32x4 (&s_cur)[2][2], f32x4 (&s_nxt)[2][2]) {
-    constexpr int g8 = decltype(g8_c)::value;
-    mask_half(g, s_cur);
-    // ---- A: key tile 0 of S(g+1) on the matrix pipe (fragments read during the previous step) | lane maxima of S(g) on the VALU
-    qk_read(IC<((g8 + 1) & 7)>{}, IC<0>{}, kf_pre, KPRE, 4);     // the rest of key tile 0's fragments
-    qk_mma(kf_pre, s_nxt[0]);
-    float mq[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-      mq[qt] = vmax8(s_cur[0][qt][0], s_cur[0][qt][1], s_cur[0][qt][2], s_cur[0][qt][3], s_cur[1][qt][0], s_cur[1][qt][1], s_cur[1][qt][2],
-                     s_cur[1][qt][3]);
-    bf16x8 pn[2];
-    float psum[2];
-    // ---- deferred rescale (always taken for half 0).  The row sums (which already hold P(g-1)) move to the new reference here; O
-    // moves BEHIND block B, once the pending P(g-1) -- still in the old units -- has been multiplied into it: no unpack / rescale /
-    // repack of the packed P registers, and the 64 multiplies sit where the fewest registers are live.
-    bool resc = false;
-    float alpha[2] = {1.f, 1.f};
-    if constexpr (PRE) {
-      // PRE: the scores of this half and the finished key tile 0 of the next half move too; key tile 1 of the next half starts
-      // from the new reference
-      if (g == 0 || __any(vmax(mq[0], mq[1]) > RESCALE_THR_LOG2)) {
-        resc = true;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          const float mx = row_max(mq[qt]);
-          const float delta = g == 0 ? mx : fmaxf(mx, 0.f);
-          alpha[qt] = g == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
-          ref[qt] += delta;
-#if !A16_ROWSUM_MFMA
-          l_run[qt] *= alpha[qt];
-#endif
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            s_cur[0][qt][e] -= delta;
-            s_cur[1][qt][e] -= delta;
-            s_nxt[0][qt][e] -= delta;
-            negref[qt][e] = -ref[qt];
-          }
-        }
-      }
-    } else {
-      if (__any((vmax(mq[0] - m_run[0], mq[1] - m_run[1])) * c > RESCALE_THR_LOG2)) {
-        resc = true;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          const float m_new = fmaxf(m_run[qt], row_max(mq[qt]));
-          alpha[qt] = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
-#if !A16_ROWSUM_MFMA
-          l_run[qt] *= alpha[qt];
-#endif
-          m_run[qt] = m_new;
-        }
-      }
-    }
-    // ---- B: key tile 1 of S(g+1) and PV(g-1) on the matrix pipe | exp2 / partial row sums / pack of S(g) on the VALU
-    {
-      bf16x8 kf[4];
-      qk_read(IC<((g8 + 1) & 7)>{}, IC<1>{}, kf);
-      qk_mma(kf, s_nxt[1]);
-    }
-    pv_half(IC<((g8 + 7) & 7)>{});
-    qk_read(IC<((g8 + 2) & 7)>{}, IC<0>{}, kf_pre, 0, KPRE);          // for the next step's block A
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const float mc = PRE ? 0.f : m_run[qt] * c;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pv = PRE ? __builtin_amdgcn_exp2f(s_cur[kt][qt][e]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s_cur[kt][qt][e], c, -mc));
-#if !A16_ROWSUM_MFMA
-          psum[qt] = (kt == 0 && e == 0) ? pv : psum[qt] + pv;
-#endif
-          pn[qt][4 * kt + e] = f2bf(pv);
-        }
-#if !A16_ROWSUM_MFMA
-      l_run[qt] += psum[qt];
-#endif
-    }
-    pf_prev[0] = pn[0];            // PV(g-1) above consumed the old value (program order)
-    pf_prev[1] = pn[1];
-#if A16_ROWSUM_MFMA
-    asm volatile("" : "+v"(pf_prev[0]), "+v"(pf_prev[1]));
-#else
-    asm volatile("" : "+v"(pf_prev[0]), "+v"(pf_prev[1]), "+v"(l_run[0]), "+v"(l_run[1]));
-#endif
-    // Block B schedule: 24 (26) MFMAs (16 cycles each), 24 LDS reads, ~42 (26) VALU operations
-#if A16_SCHED == 0
-#pragma unroll
-    for (int i = 0; i < 24 + 2 * A16_ROWSUM_MFMA; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, PRE ? 2 : 3, 0);   // VALU
-    }
-#elif A16_SCHED == 1      // one VALU per MFMA for as long as they last
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-    }
-#pragma unroll
-    for (int i = 16; i < 24 + 2 * A16_ROWSUM_MFMA; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-    }
-#elif A16_SCHED == 2      // no forced interleave: hipcc's own order
-#endif
-    if (resc) {                    // rare: O (now holding P(g-1).V(g-1) in the old units) to the new reference
-      asm volatile("; O to the new reference" ::: "memory");     // a real branch: hipcc otherwise multiplies by 1.0 on every step
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o_acc[dt][qt][e] *= alpha[qt];
-#if A16_ROWSUM_MFMA
-#pragma unroll
-        for (int e = 0; e < 4; ++e) l_acc[qt][e] *= alpha[qt];
-#endif
-      }
-    }
-  };
-
-  auto tile = [&](int t, auto t4_c) {
-    constexpr int t4 = decltype(t4_c)::value;
-    if (t > 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (t + 2 < ntiles) issue_tile(t + 2, 1);
-    step(2 * t, IC<2 * t4>{}, s_a, s_b);
-    if (t + 2 < ntiles) issue_tile(t + 2, 2);
-    step(2 * t + 1, IC<2 * t4 + 1>{}, s_b, s_a);
-  };
-  int t = 0;
-  for (; t + 4 <= ntiles; t += 4) {
-    tile(t, IC<0>{});
-    tile(t + 1, IC<1>{});
-    tile(t + 2, IC<2>{});
-    tile(t + 3, IC<3>{});
-  }
-  const int rem = ntiles - t;
-  if (rem > 0) tile(t, IC<0>{});
-  if (rem > 1) tile(t + 1, IC<1>{});
-  if (rem > 2) tile(t + 2, IC<2>{});
-  switch ((ntiles - 1) & 3) {
-    case 0: pv_half(IC<1>{}); break;
-    case 1: pv_half(IC<3>{}); break;
-    case 2: pv_half(IC<5>{}); break;
-    default: pv_half(IC<7>{}); break;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  // ---- epilogue: O[q0 + 16 qt + i][16 dt + 4 g4 + (0..3)] = o_acc[dt][qt][0..3] / l
-  float l_tot[2];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-#if A16_ROWSUM_MFMA
-    l_tot[qt] = l_acc[qt][0];
-#else
-    float x = l_run[qt];
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    l_tot[qt] = x;
-#endif
-  }
-  if (partial) {                           // partial result of this key range; attn_merge_kernel finishes the softmax
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int rr = wave * 32 + 16 * qt + li;
-      if (qb * QBLK + rr < p.Lq) {
-        const int64_t row = ((int64_t)(p.slot0 + split) * p.n_units + ul) * QBLK + rr;
-        float* orow = p.ws_o + row * HD + 4 * g4;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) *(f32x4*)(orow + 16 * dt) = o_acc[dt][qt];
-        if (g4 == 0) *(f32x2*)(p.ws_ml + row * 2) = (f32x2){PRE ? ref[qt] : m_run[qt], l_tot[qt]};
-      }
-    }
-    return;
-  }
-  // the wave's 32 x 128 bf16 block goes through its own 8 KiB of the K ring (every wave is past its last K read behind the barrier):
-  // 8-byte pieces in, whole rows out (16 bytes per lane, 4 rows of 256 bytes per store instruction)
-  __syncthreads();
-  char* stage = smem + wave * 8192;
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    const float inv_l = 1.0f / l_tot[qt];
-    const int rr = 16 * qt + li;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      bf16x4 ov;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = f2bf(o_acc[dt][qt][e] * inv_l);
-      *(bf16x4*)(stage + 256 * rr + ((32 * dt + 8 * g4) ^ (li << 4))) = ov;
-    }
-  }
-  // (a wave reads back only what it wrote itself: program order + the compiler's lgkmcnt are enough)
-  bf16* obase = p.o + (int64_t)b * p.o_bs + head * HD + li * 8;
-#pragma unroll
-  for (int ps = 0; ps < 8; ++ps) {
-    const int rr = 4 * ps + g4;
-    const u32x4 ov = *(const u32x4*)(stage + 256 * rr + 16 * (li ^ (rr & 15)));
-    const int qi = q0 + rr;
-    if (qi < p.Lq) *(u32x4*)(obase + (int64_t)qi * p.o_rs) = ov;
-  }
-}
 
 // out[b][q][head][:] = sum_s w_s O_s / sum_s w_s l_s with w_s = exp2((m_s - max_s m_s) * scale_log2e) for the rows of the
 // launch's units; one wave per row, two columns per lane
@@ -1097,12 +658,15 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
-  const char* be = getenv("FLEXAM_ATTN_BODY");          // A/B switch (read per call): 16 = the 16x16x32 body, default 32x32x16
-  const bool body16 = be && atoi(be) == 16;
-  auto kern = body16 ? (cross ? (p.prescaled ? attn_fwd16_kernel<1, true> : attn_fwd16_kernel<1, false>)
-                              : (p.prescaled ? attn_fwd16_kernel<0, true> : attn_fwd16_kernel<0, false>))
-                     : (cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
-                              : (p.prescaled ? attn_fwd_kernel<0, true> : attn_fwd_kernel<0, false>));
+  auto kern = cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
+                    : (p.prescaled ? attn_fwd_kernel<0, true> : attn_fwd_kernel<0, false>);
+  bool body16 = false;
+#ifdef FLEXAM_ATTN_BODY16                              // diagnostic builds only (attn_body16.inc): the 16x16x32 body, selected per call
+  const char* be = getenv("FLEXAM_ATTN_BODY");
+  body16 = be && atoi(be) == 16;
+  if (body16) kern = cross ? (p.prescaled ? attn_fwd16_kernel<1, true> : attn_fwd16_kernel<1, false>)
+                           : (p.prescaled ? attn_fwd16_kernel<0, true> : attn_fwd16_kernel<0, false>);
+#endif
   static bool attr_set[FLEXAM_MAX_DEVICES][8] = {};      // per device and kernel instance
   const int which = (cross ? 1 : 0) + (p.prescaled ? 2 : 0) + (body16 ? 4 : 0);
   const int dev = flexam_current_device();
@@ -1178,6 +742,13 @@ extern "C" int flexam_attn_fwd_partial(const void* q, int64_t q_bs, int64_t q_rs
   return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, 0, 0, B, H, Lq, Lk, head_dim, softmax_scale, kv_splits, 0, ws_o,
                   ws_ml, stream, slot0);
 }
+
+#ifdef FLEXAM_ATTN_STAMPS
+// diagnostic builds only (not declared in flexam_hip.h): copies the per-workgroup stamps of the last attention launch to the host
+extern "C" int flexam_debug_attn_stamps(unsigned long long* out, int n_workgroups) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), (size_t)n_workgroups * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int flexam_attn_merge(void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int head_dim, float softmax_scale,
                                  int n_slots, const float* ws_o, const float* ws_ml, void* stream) {

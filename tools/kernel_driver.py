@@ -5,6 +5,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from flexam_amd import hip as H
+if os.environ.get("FLEXAM_DRIVER_LIB"):          # a diagnostic build of the library (tools/build_attn_variants.py) instead of the tree's
+    H.load_library(os.environ["FLEXAM_DRIVER_LIB"])
 
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 L, B, d, f, T, nh = 11648, 2, 3072, 14336, 512, 24

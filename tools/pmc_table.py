@@ -21,11 +21,11 @@ def demangle(name: str) -> str:
             return out
     except Exception:
         pass
-    m = re.match(r"_ZN12_GLOBAL__N_1\d+(gemm_bf16_kernel|gemm_splitk_finish_kernel)ILi(\d)E(DF16b|f)Li(\d)ELb(\d)E(?:Lb(\d)E)?", name)
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+(gemm_bf16_kernel|gemm_splitk_finish_kernel)ILi(\d)E(DF16b|f)Li(\d)E(?:Lb(\d)E)?", name)
     if m:
         epi = {"0": "EPI_NONE", "1": "EPI_GELU", "2": "EPI_GATE_RESIDUAL"}[m.group(2)]
-        return (f"{m.group(1)}<{epi}, {'bf16' if m.group(3) == 'DF16b' else 'float'}, MT={m.group(4)}, M32={m.group(5)}"
-                + (f", TAIL={m.group(6)}" if m.group(6) is not None else "") + ">")
+        return (f"{m.group(1)}<{epi}, {'bf16' if m.group(3) == 'DF16b' else 'float'}, MT={m.group(4)}"
+                + (f", TAIL={m.group(5)}" if m.group(5) is not None else "") + ">")
     return name
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
