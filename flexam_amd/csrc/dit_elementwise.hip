@@ -25,7 +25,8 @@ __global__ __launch_bounds__(64) void ln_modulate_wave_kernel(const float* __res
                                                               int64_t tab_ld, const int32_t* __restrict__ row_index,
                                                               int64_t rows_per_batch, const float* __restrict__ ln_w,
                                                               const float* __restrict__ ln_b, bf16* __restrict__ out, int64_t ldo,
-                                                              float* __restrict__ row_scale = nullptr) {
+                                                              float* __restrict__ row_scale = nullptr, float* __restrict__ next_scale = nullptr,
+                                                              float next_wnorm = 0.f, float next_bias = 0.f) {
   // Access shape (tools/ab_rowkernels.py, r3): a lane owns 4 consecutive floats of every 256-float segment, so one load
   // instruction of the wave covers 1 KiB without gaps (the earlier 8-floats-per-lane shape read it as two half-dense
   // instructions: -9.6 % time), and ONE wave per workgroup, so no row waits for the slowest of four (-9.3 % on its own).
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64) void ln_modulate_wave_kernel(const float* __res
     sh = shift + r * tab_ld;
     sc = scale + r * tab_ld;
   }
-  float amax = 0.f;
+  float amax = 0.f, ssq = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
@@ -68,7 +69,10 @@ __global__ __launch_bounds__(64) void ln_modulate_wave_kernel(const float* __res
     if constexpr (FP8) {
       v[i] = y;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(y[j]));
+      for (int j = 0; j < 4; ++j) {
+        amax = fmaxf(amax, fabsf(y[j]));
+        ssq += y[j] * y[j];
+      }
     } else {
       bf16x4 o;
 #pragma unroll
@@ -82,6 +86,14 @@ __global__ __launch_bounds__(64) void ln_modulate_wave_kernel(const float* __res
     const float qs = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
     const float inv = 1.0f / qs;
     if (lane == 0) row_scale[m] = qs;
+    if (next_scale) {
+      // A scale for the e4m3 OUTPUT of the GEMM this row feeds, known before that GEMM runs: |gelu(a . w_j + b_j)| <= |a|_2 |w_j|_2 + |b_j|
+      // (Cauchy-Schwarz; |a|_2 of the quantised row <= 1.07 |y|_2: 2^-4 relative rounding + subnormal steps), so the consumer of
+      // that output needs no absmax pass over it.  The bound is loose (~ sqrt(C) above a typical value), which an 8-bit FLOAT
+      // absorbs: values keep their 3 mantissa bits down to 2^-14 of the bound.
+      const float l2 = __builtin_sqrtf(wave_sum(ssq));
+      if (lane == 0) next_scale[m] = fmaxf((l2 * 1.07f * next_wnorm + next_bias) * (1.0f / 448.0f), 1e-30f);
+    }
     uint8_t* qrow = (uint8_t*)out + m * ldo;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -623,8 +635,10 @@ extern "C" int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C,
 
 extern "C" int flexam_ln_modulate_fp8(const float* x, int64_t ldx, int64_t M, int C, float eps, const float* shift, const float* scale,
                                       int64_t tab_ld, const int32_t* row_index, int64_t rows_per_batch, const float* ln_w,
-                                      const float* ln_b, void* q_out, int64_t ldq, float* row_scale, void* stream) {
+                                      const float* ln_b, void* q_out, int64_t ldq, float* row_scale, float* next_scale, float next_wnorm,
+                                      float next_bias, void* stream) {
   FX_REQUIRE(x && q_out && row_scale && M > 0, FLEXAM_E_ARG, "ln_modulate_fp8: null pointer or empty");
+  FX_REQUIRE(!next_scale || (next_wnorm >= 0.f && next_bias >= 0.f), FLEXAM_E_ARG, "ln_modulate_fp8: negative norm bound");
   FX_REQUIRE(C % 512 == 0 && C <= 4096, FLEXAM_E_SHAPE, "ln_modulate_fp8: row width %d must be a multiple of 512, at most 4096", C);
   FX_REQUIRE(ldx % 4 == 0 && ldq % 8 == 0, FLEXAM_E_SHAPE, "ln_modulate_fp8: ldx%%4, ldq%%8 required");
   FX_REQUIRE((shift == nullptr) == (scale == nullptr) && (ln_w == nullptr) == (ln_b == nullptr), FLEXAM_E_ARG,
@@ -635,7 +649,7 @@ extern "C" int flexam_ln_modulate_fp8(const float* x, int64_t ldx, int64_t M, in
 #define LN_WAVE8(NV8_)                                                                                                                   \
   case NV8_:                                                                                                                            \
     hipLaunchKernelGGL((ln_modulate_wave_kernel<NV8_, true>), grid, block, 0, (hipStream_t)stream, x, ldx, M, eps, shift, scale, tab_ld, \
-                       row_index, rows_per_batch, ln_w, ln_b, (bf16*)q_out, ldq, row_scale);                                            \
+                       row_index, rows_per_batch, ln_w, ln_b, (bf16*)q_out, ldq, row_scale, next_scale, next_wnorm, next_bias);         \
     break;
   switch (C / 512) { LN_WAVE8(1) LN_WAVE8(2) LN_WAVE8(3) LN_WAVE8(4) LN_WAVE8(5) LN_WAVE8(6) LN_WAVE8(7) LN_WAVE8(8) }
 #undef LN_WAVE8

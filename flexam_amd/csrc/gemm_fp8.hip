@@ -39,6 +39,7 @@ struct Gemm8Params {
   const float* bias;
   const float* sa;         // [M] activation row scales
   const float* sw;         // [N] weight row (output channel) scales
+  const float* so;         // EPI_GELU_Q: [M] scales of the e4m3 output rows (C = e4m3 bytes, ldc in bytes)
   int64_t lda, ldw, ldc;   // bytes == elements
   int M, N, K;
   int tiles_m, tiles_n;
@@ -55,7 +56,7 @@ struct Gemm8Params {
 template <int V>
 using IC = std::integral_constant<int, V>;
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2, EPI_GELU_Q = 3 };      // GELU_Q: GELU, then e4m3 / out_scale[m] (the next GEMM's A operand)
 
 template <int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
     for (int c = 0; c < 2; ++c) frag_off[c] = (lf & 15) * 128 + (((2 * (lf >> 4) + c) ^ sw) << 4);
   };
   bool staged = false, pend = false;
-  constexpr int PEND = (EPI == EPI_GATE_RESIDUAL ? 4 : 2) * MT;
+  constexpr int PEND = (EPI == EPI_GATE_RESIDUAL ? 4 : EPI == EPI_GELU_Q ? 1 : 2) * MT;      // stores a wave issues in an interior epilogue
   const int nk = p.K / BKB;
 
   for (int it = 0; it < n_units; ++it) {
@@ -199,6 +200,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
     const uint32_t r0 = (uint32_t)min(mr, p.M - 1) * 4u, r1 = (uint32_t)min(mr + 64, p.M - 1) * 4u;
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(r0), "s"(p.sa), "s"(dst + 512) : "memory");
     if (16 * MT > 64) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(r1), "s"(p.sa), "s"(dst + 768) : "memory");
+    if constexpr (EPI == EPI_GELU_Q) {                   // the output row scales of the wave's 16 MT rows: a second kilobyte per wave
+      const uint32_t dst2 = (uint32_t)(uintptr_t)LDS_PTR(smem) + 4 * TILE_BYTES + 8 * STG_WAVE + 8 * 1024 + wave * 512;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(r0), "s"(p.so), "s"(dst2) : "memory");
+      if (16 * MT > 64) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(r1), "s"(p.so), "s"(dst2 + 256) : "memory");
+    }
   }
   frag_setup();
 #pragma unroll
@@ -344,7 +350,51 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
       continue;
     }
   }
-  if constexpr (EPI != EPI_GATE_RESIDUAL) {
+  if constexpr (EPI == EPI_GELU_Q) {
+    // e4m3 output rows: a lane packs its 4 columns of (m-tile t, n-tile v) into one dword; the wave's 16 x 64 bytes of an m-tile are
+    // turned around in its staging slice (16-byte chunks XOR-swizzled by row pairs) and leave as 16 rows of 64 contiguous bytes
+    const float* so_l = (const float*)(smem + 4 * TILE_BYTES + 8 * STG_WAVE + 8 * 1024 + wave * 512);
+    if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
+      const int rd_row = le >> 2, rd_c = le & 3;
+      uint8_t* crow = (uint8_t*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 16;
+#pragma unroll
+      for (int t = 0; t < NRT; ++t) {
+        const float inv = __builtin_amdgcn_rcpf(so_l[16 * t + (le & 15)]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const f32x4 y4 = yv(t, v);
+          int w = 0;
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_tanh(y4[0]) * inv, gelu_tanh(y4[1]) * inv, w, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_tanh(y4[2]) * inv, gelu_tanh(y4[3]) * inv, w, true);
+          *(int*)(stg + wr_row * 64 + ((v ^ ((wr_row >> 1) & 3)) << 4) + wr_g * 4) = w;
+        }
+        const u32x4 o = *(const u32x4*)(stg + rd_row * 64 + ((rd_c ^ ((rd_row >> 1) & 3)) << 4));
+        *(u32x4*)(crow + (int64_t)(t * 16) * p.ldc) = o;
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));
+      pend = true;
+      continue;
+    }
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {                      // boundary tiles: 4 bytes per lane, bounds-checked
+      const int m = mrow + t * 16;
+      if (m >= p.M) continue;
+      const float inv = __builtin_amdgcn_rcpf(so_l[16 * t + (le & 15)]);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int n = ncol + v * 16;
+        if (n >= p.N) continue;
+        const f32x4 y4 = yv(t, v);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_tanh(y4[0]) * inv, gelu_tanh(y4[1]) * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(gelu_tanh(y4[2]) * inv, gelu_tanh(y4[3]) * inv, w, true);
+        *(int*)((uint8_t*)p.C + (int64_t)m * p.ldc + n) = w;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    continue;
+  }
+  if constexpr (EPI != EPI_GATE_RESIDUAL && EPI != EPI_GELU_Q) {
     if (m0 + BM_ <= p.M && n0 + BN <= p.N) {
       const int rd_row = le >> 3, rd_c = le & 7;
       bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
@@ -468,7 +518,7 @@ template <int EPI, int MT>
 int launch_shape8(Gemm8Params p, hipStream_t s) {
   auto kern = gemm_fp8_kernel<EPI, MT>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};
-  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 8 * 1024;      // K-block buffers, output staging, epilogue constants
+  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 8 * 1024 + (EPI == EPI_GELU_Q ? 8 * 512 : 0);      // K-block buffers, output staging, epilogue constants (+ output row scales)
   const int dev = flexam_current_device();
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -527,6 +577,18 @@ extern "C" int flexam_gemm_fp8(const void* A, int64_t lda, const float* a_scale,
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.tiles_n = (int)((N + BN - 1) / BN);
   return epilogue == EPI_GELU ? launch8<EPI_GELU>(p, (hipStream_t)stream) : launch8<EPI_NONE>(p, (hipStream_t)stream);
+}
+
+extern "C" int flexam_gemm_fp8_gelu_q(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw, const float* w_scale,
+                                      const float* bias, const float* out_scale, void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
+                                      void* stream) {
+  if (int rc = check8(A, lda, W, ldw, a_scale, w_scale, M, N, K)) return rc;
+  FX_REQUIRE(Q && out_scale && ldq % 16 == 0 && (uintptr_t)Q % 16 == 0, FLEXAM_E_ARG, "gemm_fp8_gelu_q: bad output (e4m3 rows, 16-byte aligned)");
+  Gemm8Params p{};
+  p.A = (const uint8_t*)A; p.W = (const uint8_t*)W; p.C = Q; p.bias = bias; p.sa = a_scale; p.sw = w_scale; p.so = out_scale;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldq; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_n = (int)((N + BN - 1) / BN);
+  return launch8<EPI_GELU_Q>(p, (hipStream_t)stream);
 }
 
 extern "C" int flexam_gemm_fp8_gate_residual(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw,

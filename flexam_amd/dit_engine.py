@@ -190,18 +190,31 @@ class DiTEngine:
                 q = {}
                 for name in ("wqkv", "w1", "w2"):
                     q[name], q["s_" + name] = hip.quantize_rows_fp8(p[name])
+                # bounds for the a-priori scale of FFN1's e4m3 output (flexam_ln_modulate_fp8, next_scale): the largest L2 norm of a
+                # DEQUANTISED w1 row (what the MFMA multiplies) and the largest |bias|; two floats per layer, read back once
+                deq = q["w1"].view(torch.float8_e4m3fn).float() * q["s_w1"][:, None]
+                q["w1_norm"] = float(deq.norm(dim=1).max()) * 1.001
+                q["b1_max"] = float(p["b1"].abs().max()) if p["b1"] is not None else 0.0
+                del deq
                 self._fp8_w.append(q)
         self.fp8 = bool(on)
         self._ws.clear()
 
-    def _ln_fp8(self, xres, ws, hbuf, **kw):
+    def _ln_fp8(self, xres, ws, hbuf, nxt=None, **kw):
         """LN + modulate as the fp8 GEMMs' A operand: one launch at widths the wave-per-row kernel covers (multiples of 512, the 5B
-        model's 3072), the bf16 row kernel followed by the row quantiser otherwise."""
-        d = self.dim
+        model's 3072), the bf16 row kernel followed by the row quantiser otherwise.  nxt = (w_norm_max, bias_max) of the GEMM the
+        rows feed: the launch then also writes the a-priori output scales of that GEMM into ws["so"] (fused form only; returns
+        whether it did)."""
+        d, m = self.dim, xres.shape[0]
         if d % 512 == 0 and d <= 4096:
-            return hip.ln_modulate_fp8(xres, ws["a8"][:, :d], ws["sa"], eps=self.eps, **kw)
+            if nxt is not None:
+                hip.ln_modulate_fp8(xres, ws["a8d"][:m], ws["sa"][:m], eps=self.eps, next_scale=ws["so"][:m], next_wnorm=nxt[0], next_bias=nxt[1], **kw)
+                return ws["a8d"][:m], ws["sa"][:m], True
+            a8, sa = hip.ln_modulate_fp8(xres, ws["a8d"][:m], ws["sa"][:m], eps=self.eps, **kw)
+            return a8, sa, False
         hip.ln_modulate(xres, out=hbuf, eps=self.eps, **kw)
-        return hip.quantize_rows_fp8(hbuf, ws["a8"][:, :d], ws["sa"])
+        a8, sa = hip.quantize_rows_fp8(hbuf, ws["a8d"][:m], ws["sa"][:m])
+        return a8, sa, False
 
     def set_sequence_parallel(self, group, rank: int, size: int):
         self.set_parallel(group, rank, size)
@@ -316,7 +329,8 @@ class DiTEngine:
                 ffn=torch.empty(m, self.ffn, device=dev, dtype=BF16),
                 head=torch.empty(m, self.head_w.shape[0], device=dev, dtype=F32))
             if self.fp8:
-                self._ws[key].update(a8=torch.empty(m, self.ffn, device=dev, dtype=torch.uint8), sa=torch.empty(m, device=dev, dtype=F32))
+                self._ws[key].update(a8=torch.empty(m, self.ffn, device=dev, dtype=torch.uint8), sa=torch.empty(m, device=dev, dtype=F32),
+                                     a8d=torch.empty(m, d, device=dev, dtype=torch.uint8), so=torch.empty(m, device=dev, dtype=F32))
         return self._ws[key]
 
     # ------------------------------------------------------------------ per-step
@@ -439,7 +453,7 @@ class DiTEngine:
             mb = nb * lc
             ri = row_index[:mb] if row_index is not None else None
             if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
-                a8, sa = self._ln_fp8(xres[:mb], ws, hbuf[:mb], shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
+                a8, sa, _ = self._ln_fp8(xres[:mb], ws, hbuf[:mb], shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
             else:
                 hip.ln_modulate(xres[:mb], out=hbuf[:mb], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
             if sp > 1 and self.sp_mode == "ulysses":
@@ -478,9 +492,16 @@ class DiTEngine:
             # FFN
             if self.fp8:
                 w8 = self._fp8_w[i]
-                a8, sa = self._ln_fp8(xres, ws, hbuf, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
-                hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
-                a8, sa = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
+                # FFN1 writes FFN2's e4m3 operand itself: its output row scales are known before it runs (a bound from the row's L2
+                # norm, written by the LN launch), so there is no absmax / quantise pass over the [M, 14336] intermediate
+                a8, sa, bound = self._ln_fp8(xres, ws, hbuf, nxt=(w8["w1_norm"], w8["b1_max"]), shift=T[:, 3], scale=T[:, 4],
+                                             row_index=row_index, rows_per_batch=rpb)
+                if bound:
+                    hip.gemm_fp8_gelu_q(a8, sa, w8["w1"], w8["s_w1"], p["b1"], ws["so"], ws["a8"])
+                    a8, sa = ws["a8"], ws["so"]
+                else:                                      # widths the fused LN launch does not cover: bf16 intermediate + row quantiser
+                    hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
+                    a8, sa = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
                 hip.gemm_fp8_gate_residual(a8, sa, w8["w2"], w8["s_w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
             else:
                 hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)

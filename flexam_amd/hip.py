@@ -28,13 +28,14 @@ _SIGNATURES = {
     "flexam_quantize_rows_fp8": ([_P, _L, _P, _L, _P, _L, _I, _P], c_int),
     "flexam_gemm_fp8": ([_P, _L, _P, _P, _L, _P, _P, _P, _L, _L, _L, _L, _I, _P], c_int),
     "flexam_gemm_fp8_gate_residual": ([_P, _L, _P, _P, _L, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P], c_int),
+    "flexam_gemm_fp8_gelu_q": ([_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _L, _L, _L, _P], c_int),
     "flexam_attn_fwd": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _P], c_int),
     "flexam_attn_fwd_lastkey": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _F, _P], c_int),
     "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_fwd_partial": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_merge": ([_P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
-    "flexam_ln_modulate_fp8": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P], c_int),
+    "flexam_ln_modulate_fp8": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _F, _F, _P], c_int),
     "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
     "flexam_rmsnorm_rope": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
     "flexam_rmsnorm_rope_scatter": ([_P, _L, _P, _P, _L, _P, _P, _L, _P, _P, _P, _L, _L, _I, _L, _L, _I, _F, _P, _P, _L, _L, _I, _P], c_int),
@@ -226,6 +227,18 @@ def gemm_fp8(a8, a_scale, w8, w_scale, bias=None, out=None, epilogue=EPI_NONE):
     return out
 
 
+def gemm_fp8_gelu_q(a8, a_scale, w8, w_scale, bias, out_scale, q_out):
+    """q_out[M,N] (e4m3 bytes) = e4m3(gelu_tanh((a8 @ w8^T) * scales + bias) / out_scale[:, None]): FFN1 writing FFN2's A operand."""
+    M, K, lda = _rows(a8)
+    N, wk, ldw = _rows(w8)
+    qm, qn, ldq = _rows(q_out)
+    if wk != K or qm != M or qn != N:
+        raise RuntimeError("gemm_fp8_gelu_q: shape mismatch")
+    _check(lib().flexam_gemm_fp8_gelu_q(_ptr(a8, U8), lda, _ptr(a_scale, F32), _ptr(w8, U8), ldw, _ptr(w_scale, F32), _ptr(bias, F32),
+                                        _ptr(out_scale, F32), _ptr(q_out, U8), ldq, M, N, K, _stream()), "flexam_gemm_fp8_gelu_q")
+    return q_out
+
+
 def gemm_fp8_gate_residual(a8, a_scale, w8, w_scale, bias, x, gate=None, gate_row=None, rows_per_batch=0):
     """x[M,N] (fp32, in place) += bf16((a8 @ w8^T) * scales + bias) * gate[row]."""
     M, K, lda = _rows(a8)
@@ -383,13 +396,17 @@ def ln_modulate(x, out=None, eps=1e-6, shift=None, scale=None, row_index=None, r
     return out
 
 
-def ln_modulate_fp8(x, q_out, row_scale, eps=1e-6, shift=None, scale=None, row_index=None, rows_per_batch=0, ln_w=None, ln_b=None):
-    """ln_modulate with the output written as e4m3 bytes q_out [M, C] (uint8, row stride free) + row_scale [M] fp32."""
+def ln_modulate_fp8(x, q_out, row_scale, eps=1e-6, shift=None, scale=None, row_index=None, rows_per_batch=0, ln_w=None, ln_b=None,
+                    next_scale=None, next_wnorm=0.0, next_bias=0.0):
+    """ln_modulate with the output written as e4m3 bytes q_out [M, C] (uint8, row stride free) + row_scale [M] fp32.  next_scale [M]
+    (optional): the output scale of the GEMM + GELU this row feeds (gemm_fp8_gelu_q), from the row's L2 norm and the bounds
+    next_wnorm >= max |w_j|_2, next_bias >= max |b_j| of that GEMM (see flexam_hip.h)."""
     M, C, ldx = _rows(x)
     tab_ld = shift.stride(0) if shift is not None else 0
     _check(lib().flexam_ln_modulate_fp8(_ptr(x, F32), ldx, M, C, eps, _ptr(shift, F32), _ptr(scale, F32), tab_ld, _ptr(row_index, I32),
                                         rows_per_batch, _ptr(ln_w, F32), _ptr(ln_b, F32), _ptr(q_out, torch.uint8), q_out.stride(0),
-                                        _ptr(row_scale, F32), _stream()), "flexam_ln_modulate_fp8")
+                                        _ptr(row_scale, F32), _ptr(next_scale, F32), float(next_wnorm), float(next_bias), _stream()),
+           "flexam_ln_modulate_fp8")
     return q_out, row_scale
 
 

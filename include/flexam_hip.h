@@ -88,6 +88,12 @@ int flexam_gemm_fp8(const void* A, int64_t lda, const float* a_scale, const void
 int flexam_gemm_fp8_gate_residual(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw, const float* w_scale,
                                   const float* bias, float* X, int64_t ldx, const float* gate, int64_t gate_ld,
                                   const int32_t* gate_row, int64_t rows_per_batch, int64_t M, int64_t N, int64_t K, void* stream);
+/* The fp8 FFN without a quantise pass between its two GEMMs: Q[m,n] = e4m3(gelu_tanh((A8 . W8^T) * a_scale[m] * w_scale[n] + bias[n])
+ * / out_scale[m]) -- the A operand of the next flexam_gemm_fp8* call with a_scale = out_scale.  out_scale [M] comes from
+ * flexam_ln_modulate_fp8 (next_scale: a bound on the row's outputs, so nothing saturates).  Q: e4m3 bytes, ldq % 16 == 0. */
+int flexam_gemm_fp8_gelu_q(const void* A, int64_t lda, const float* a_scale, const void* W, int64_t ldw, const float* w_scale,
+                           const float* bias, const float* out_scale, void* Q, int64_t ldq, int64_t M, int64_t N, int64_t K,
+                           void* stream);
 
 /* Flash attention forward, head_dim 128, non-causal, keys [0, Lk): o = softmax(q k^T * scale) v.
  * q/k/v/o are [B, L, H, 128] views given by batch stride `*_bs` and row stride `*_rs` (elements);
@@ -144,9 +150,13 @@ int flexam_ln_modulate(const float* x, int64_t ldx, int64_t M, int C, float eps,
 
 /* The same row operation with the output quantised for flexam_gemm_fp8: q_out[m,:] = e4m3(y / row_scale[m]), row_scale[m] =
  * absmax(y[m,:]) / 448 (C a multiple of 512, at most 4096): the fp8 variant's QKV / FFN1 inputs without a second pass. */
+/* next_scale (optional, [M]): a scale for the e4m3 OUTPUT of the GEMM + GELU this row feeds (flexam_gemm_fp8_gelu_q), known before
+ * that GEMM runs: next_scale[m] = (1.07 |y[m,:]|_2 * next_wnorm + next_bias) / 448 with next_wnorm >= max_j |w_j|_2 of the
+ * (dequantised) weight rows and next_bias >= max_j |b_j| -- by Cauchy-Schwarz no output element exceeds 448 next_scale[m]. */
 int flexam_ln_modulate_fp8(const float* x, int64_t ldx, int64_t M, int C, float eps, const float* shift, const float* scale,
                            int64_t tab_ld, const int32_t* row_index, int64_t rows_per_batch, const float* ln_w, const float* ln_b,
-                           void* q_out, int64_t ldq, float* row_scale, void* stream);
+                           void* q_out, int64_t ldq, float* row_scale, float* next_scale, float next_wnorm, float next_bias,
+                           void* stream);
 
 /* x_f32[m,:] += y_bf16[m,:] * gate[row(m),:] (gate NULL = 1).  wan_transformer3d_FlexAM.py:456,461,468. */
 int flexam_gate_residual(float* x, int64_t ldx, const void* y, int64_t ldy, const float* gate, int64_t gate_ld,

@@ -269,3 +269,38 @@ def test_fp8_row_scales_meet_outlier_channels_at_5b_width():
     assert res["outliers"][2] <= 3e-2 and res["outliers"][3] >= 40.0, res["outliers"]
     assert res["plain"][2] <= 3e-2 and res["plain"][3] >= 40.0, res["plain"]
     assert res["outliers"][2] <= 2.0 * res["plain"][2], res
+
+
+@pytest.mark.parametrize("m,n,c", [(448, 1024, 512), (700, 14336, 3072)])
+def test_ffn1_writes_ffn2s_e4m3_operand_with_an_a_priori_row_scale(H, m, n, c):
+    """The fp8 FFN without a quantise pass: flexam_ln_modulate_fp8 also writes next_scale[m] = (1.07 |y|_2 wnorm + bmax) / 448 and
+    flexam_gemm_fp8_gelu_q stores e4m3(gelu(z) / next_scale[m]).  (1) the bound holds: no output byte saturates (|q| < 448);
+    (2) dequantised, the output equals the bf16-output form of the same GEMM to e4m3's rounding (2^-4 relative per element where
+    the value is in the normal range: rel-RMS a few percent); (3) weights with outlier rows (x 50) loosen the bound, not the result."""
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(m, c, generator=g) * 2 + 0.3).to(dev())
+    tab = (torch.randn(4, 2, c, generator=g) * 0.5 + torch.tensor([0.0, 1.0]).view(1, 2, 1)).to(dev())
+    rows = torch.randint(0, 4, (m,), generator=g, dtype=torch.int32).to(dev())
+    w = torch.randn(n, c, generator=g) * c ** -0.5
+    w[[3, n // 2, n - 5]] *= 50.0
+    b = (torch.randn(n, generator=g) * 0.1).to(dev())
+    w8, sw = H.quantize_rows_fp8(w.to(torch.bfloat16).to(dev()))
+    deq = w8.view(F8).float() * sw[:, None]
+    wnorm, bmax = float(deq.norm(dim=1).max()) * 1.001, float(b.abs().max())
+    a8 = torch.empty(m, c, device=dev(), dtype=torch.uint8)
+    sa = torch.empty(m, device=dev(), dtype=torch.float32)
+    so = torch.empty(m, device=dev(), dtype=torch.float32)
+    H.ln_modulate_fp8(x, a8, sa, shift=tab[:, 0], scale=tab[:, 1], row_index=rows, next_scale=so, next_wnorm=wnorm, next_bias=bmax)
+    want = H.gemm_fp8(a8, sa, w8, sw, b, epilogue=H.EPI_GELU_TANH).float()          # the bf16-output form
+    q = torch.empty(m, n, device=dev(), dtype=torch.uint8)
+    H.gemm_fp8_gelu_q(a8, sa, w8, sw, b, so, q)
+    qf = q.view(F8).float()
+    assert bool(torch.isfinite(qf).all()) and float(qf.abs().max()) < 448.0          # never on the clamp
+    assert float((want.abs().amax(dim=1) / (so * 448.0)).max()) <= 1.0               # the bound itself
+    got = qf * so[:, None]
+    rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    big = want.abs() > want.abs().amax(dim=1, keepdim=True) * 2.0 ** -6
+    rel_big = ((got - want).abs() / want.abs().clamp_min(1e-30))[big].max().item()
+    print(f"M={m} N={n} C={c}: e4m3 output vs bf16 output rel-rms {rel:.3e}, worst relative error on values within 2^-6 of the row maximum {rel_big:.3e}; "
+          f"bound / row maximum: median {float((so * 448.0 / want.abs().amax(dim=1)).median()):.1f}")
+    assert rel < 5e-2 and rel_big < 0.14
