@@ -14,6 +14,8 @@ from types import SimpleNamespace
 from typing import Optional, Union
 
 import numpy as np
+import math
+
 import torch
 
 from . import hip
@@ -62,14 +64,20 @@ class FlowDPMSolverMultistepScheduler:
             algorithm_type = "dpmsolver++"
         if solver_type in ("logrho", "bh1", "bh2"):
             solver_type = "midpoint"
-        if algorithm_type != "dpmsolver++" or solver_type not in ("midpoint", "heun") or prediction_type != "flow_prediction" \
-                or thresholding or use_dynamic_shifting or final_sigmas_type != "zero" or solver_order not in (1, 2, 3):
-            raise NotImplementedError("FlowDPMSolverMultistepScheduler (HIP): dpmsolver++ with midpoint/heun, orders 1-3, "
-                                      "flow_prediction, final sigma zero only")
+        # What the reference class itself can run (fm_solvers.py:148-175, 249-275): "dpmsolver" / "sde-dpmsolver" demand
+        # final_sigmas_type "sigma_min", whose branch reads an `alphas_cumprod` the flow scheduler never defines (AttributeError in
+        # set_timesteps), so the x0-prediction forms are the whole usable surface: dpmsolver++ (orders 1-3) and sde-dpmsolver++
+        # (orders 1-2: the reference's third-order update has no SDE form), midpoint / heun, with or without dynamic thresholding.
+        if algorithm_type not in ("dpmsolver++", "sde-dpmsolver++") or solver_type not in ("midpoint", "heun") \
+                or prediction_type != "flow_prediction" or use_dynamic_shifting or final_sigmas_type != "zero" \
+                or solver_order not in (1, 2, 3) or (algorithm_type == "sde-dpmsolver++" and solver_order == 3):
+            raise NotImplementedError("FlowDPMSolverMultistepScheduler (HIP): dpmsolver++ (orders 1-3) / sde-dpmsolver++ (orders 1-2) with "
+                                      "midpoint / heun, flow_prediction, final sigma zero (the forms the reference class can run)")
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type,
-                                      shift=shift, use_dynamic_shifting=False, thresholding=False, algorithm_type=algorithm_type,
-                                      solver_type=solver_type, lower_order_final=lower_order_final, euler_at_final=euler_at_final,
-                                      final_sigmas_type="zero")
+                                      shift=shift, use_dynamic_shifting=False, thresholding=bool(thresholding),
+                                      dynamic_thresholding_ratio=dynamic_thresholding_ratio, sample_max_value=sample_max_value,
+                                      algorithm_type=algorithm_type, solver_type=solver_type, lower_order_final=lower_order_final,
+                                      euler_at_final=euler_at_final, final_sigmas_type="zero")
         self.sigmas = _base_sigmas(num_train_timesteps, shift)
         self.timesteps = self.sigmas * num_train_timesteps
         self.sigma_min, self.sigma_max = self.sigmas[-1].item(), self.sigmas[0].item()
@@ -101,7 +109,7 @@ class FlowDPMSolverMultistepScheduler:
     def scale_model_input(self, sample, *args, **kwargs):
         return sample
 
-    def _terms(self, sample):
+    def _terms(self, sample, noise=None):
         i, n, sg, cfg = self._step_index, len(self.timesteps), self.sigmas, self.config
         final = i == n - 1                                               # final_sigmas_type == "zero": last step is first order
         second = i == n - 2 and cfg.lower_order_final and n < 15
@@ -109,8 +117,18 @@ class FlowDPMSolverMultistepScheduler:
         alpha_t = 1.0 - sig_t
         lam_s0 = _lam(sig_s0)
         h = _lam(sig_t) - lam_s0
-        e = _expm1(-h)
         m = self.model_outputs
+        if cfg.algorithm_type == "sde-dpmsolver++":                      # fm_solvers.py:473-477, 568-580
+            if sig_t == 0.0:                                             # last step: h = inf, exp(-h) = 0 -> x_t = x0, no noise left
+                return [(1.0, m[-1])]
+            em, e2 = math.exp(-h), -_expm1(-2.0 * h)                     # exp(-h), 1 - exp(-2h)
+            out = [(sig_t / sig_s0 * em, sample), (sig_t * math.sqrt(e2), noise)]
+            if cfg.solver_order == 1 or self.lower_order_nums < 1 or final:
+                return out + [(alpha_t * e2, m[-1])]
+            r0 = (lam_s0 - _lam(float(sg[i - 1]))) / h
+            c1 = 0.5 * alpha_t * e2 if cfg.solver_type == "midpoint" else alpha_t * (e2 / (-2.0 * h) + 1.0)
+            return out + [(alpha_t * e2 + c1 / r0, m[-1]), (-c1 / r0, m[-2])]
+        e = _expm1(-h)
         base = [(sig_t / sig_s0, sample)]
         if cfg.solver_order == 1 or self.lower_order_nums < 1 or final:
             return base + [(-alpha_t * e, m[-1])]
@@ -142,13 +160,32 @@ class FlowDPMSolverMultistepScheduler:
         out_dtype = model_output.dtype
         v, sample = _as_f32(model_output), _as_f32(sample)
         x0 = hip.lincomb(torch.empty_like(sample), [(1.0, sample), (-float(self.sigmas[self._step_index]), v)])
+        if self.config.thresholding:
+            x0 = self._threshold_sample(x0)
         self.model_outputs = self.model_outputs[1:] + [x0]
-        prev = hip.lincomb(torch.empty_like(sample), self._terms(sample))
+        noise = None
+        if self.config.algorithm_type == "sde-dpmsolver++":              # fm_solvers.py:761-771: drawn on the generator's device
+            if variance_noise is not None:
+                noise = _as_f32(variance_noise.to(sample.device))
+            else:
+                gdev = generator.device if generator is not None else sample.device
+                noise = torch.randn(sample.shape, generator=generator, device=gdev, dtype=F32).to(sample.device)
+        prev = hip.lincomb(torch.empty_like(sample), self._terms(sample, noise))
         if self.lower_order_nums < self.config.solver_order:
             self.lower_order_nums += 1
         self._step_index += 1
         prev = prev.to(out_dtype)
         return SchedulerOutput(prev_sample=prev) if return_dict else (prev,)
+
+    def _threshold_sample(self, x0: torch.Tensor) -> torch.Tensor:
+        """Dynamic thresholding of the x0 prediction (fm_solvers.py:291-326): per batch item, s = the `dynamic_thresholding_ratio`
+        quantile of |x0| clamped to [1, sample_max_value]; x0 <- clamp(x0, -s, s) / s.  A handful of PyTorch tensor operations on
+        the latent (the quantile is a sort of 0.1 M values), once per step of an option the demo pipelines never select."""
+        b = x0.shape[0]
+        flat = x0.reshape(b, -1)
+        s = torch.quantile(flat.abs(), self.config.dynamic_thresholding_ratio, dim=1)
+        s = torch.clamp(s, min=1, max=self.config.sample_max_value).unsqueeze(1)
+        return (torch.clamp(flat, -s, s) / s).reshape(x0.shape).contiguous()
 
     def __len__(self):
         return self.config.num_train_timesteps

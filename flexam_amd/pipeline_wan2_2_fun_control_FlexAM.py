@@ -269,7 +269,8 @@ class Wan2_2FunControlPipeline_FlexAM:
         if "velocity" not in st:
             st["velocity"] = torch.empty_like(st["latents"])
         v = hip.cfg_velocity(tok_uncond, tok_cond, st["ref_len"], st["guidance"], st["velocity"])
-        new = self.scheduler.step(v.unsqueeze(0), self.scheduler.timesteps[i], st["latents"].unsqueeze(0), return_dict=False)[0]
+        new = self.scheduler.step(v.unsqueeze(0), self.scheduler.timesteps[i], st["latents"].unsqueeze(0), **st.get("step_kwargs", {}),
+                                  return_dict=False)[0]
         st["latents"].copy_(new[0])
         if st["mask"] is not None:
             hip.mask_blend(st["latents"], st["known"], st["mask"])
@@ -311,6 +312,9 @@ class Wan2_2FunControlPipeline_FlexAM:
             conditioning = self.encode_conditioning(video, mask_video, control_video, depth_video, cos_control_videos, ref_image,
                                                     height, width, shape)
         self.prepare(latents, conditioning, ctx_c, ctx_u, density, guidance_scale, num_inference_steps, timesteps, shift)
+        # PIPE.py:417-433, 836, 931: the generator reaches scheduler.step of the schedulers that take one (the SDE sampler's noise)
+        import inspect
+        self._state["step_kwargs"] = ({"generator": generator} if "generator" in inspect.signature(self.scheduler.step).parameters else {})
         for i in range(self._num_timesteps):
             if self._interrupt:
                 continue

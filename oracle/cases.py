@@ -135,13 +135,24 @@ SOLVER_CASES = {                                    # name -> (kind, steps, shif
     "dpmpp_o2": ("dpm", 8, 5.0, {}),
     "dpmpp_o3": ("dpm", 12, 5.0, dict(solver_order=3)),
     "dpmpp_heun": ("dpm", 6, 5.0, dict(solver_type="heun")),
+    # the two corners of the DPM class the reference can run besides plain dpmsolver++ (r4): the SDE form (fm_solvers.py:473-477,
+    # 568-580; its noise comes from a torch.Generator seeded with SOLVER_NOISE_SEED, drawn on the CPU as the reference does when the
+    # generator is a CPU one) and dynamic thresholding of the x0 prediction (fm_solvers.py:291-326)
+    "sde_dpmpp_o2": ("dpm", 8, 5.0, dict(algorithm_type="sde-dpmsolver++")),
+    "sde_dpmpp_heun_o1": ("dpm", 6, 3.0, dict(algorithm_type="sde-dpmsolver++", solver_type="heun", solver_order=1)),
+    "sde_dpmpp_heun": ("dpm", 7, 5.0, dict(algorithm_type="sde-dpmsolver++", solver_type="heun")),
+    "dpmpp_thresholding": ("dpm", 6, 5.0, dict(thresholding=True, sample_max_value=1.5)),
 }
+SOLVER_NOISE_SEED = 77
+# seeds of the cases' inputs: the five r1 cases keep the ids they had (their position in the sorted names of that time)
+SOLVER_SEED_ID = {"dpmpp_heun": 0, "dpmpp_o2": 1, "dpmpp_o3": 2, "unipc_o2": 3, "unipc_o3": 4, "sde_dpmpp_o2": 5, "sde_dpmpp_heun_o1": 6,
+                  "sde_dpmpp_heun": 7, "dpmpp_thresholding": 8}
 
 
 def solver_case(name: str, shape=(1, 48, 3, 4, 6)):
     """Seeded start sample and per-step model outputs (velocity predictions) for a scheduler trace."""
     kind, steps, shift, kw = SOLVER_CASES[name]
-    g = torch.Generator().manual_seed(1000 + sorted(SOLVER_CASES).index(name))
+    g = torch.Generator().manual_seed(1000 + SOLVER_SEED_ID[name])
     x = randn(g, *shape)
     vs = [randn(g, *shape) for _ in range(steps)]
     return kind, steps, shift, kw, x, vs

@@ -178,8 +178,9 @@ def main():
             sch = ref.dpm.FlowDPMSolverMultistepScheduler(num_train_timesteps=1000, shift=1, **kw)
             ref.dpm.retrieve_timesteps(sch, device="cpu", sigmas=ref.dpm.get_sampling_sigmas(steps, shift))   # PIPE.py:609-614
         trace, cur = [], x.clone()
+        gen = torch.Generator().manual_seed(C.SOLVER_NOISE_SEED)         # consumed by the SDE cases only
         for i, t in enumerate(sch.timesteps):
-            cur = sch.step(vs[i], t, cur, return_dict=False)[0]
+            cur = sch.step(vs[i], t, cur, generator=gen, return_dict=False)[0]
             trace.append(cur.clone())
         _save("g10_solver_" + name, dict(sigmas=sch.sigmas.clone(), timesteps=sch.timesteps.clone(), trace=torch.stack(trace),
                                          in_sum=C.checksum(dict(x=x, **{f"v{i}": v for i, v in enumerate(vs)}))))

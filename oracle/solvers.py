@@ -143,26 +143,41 @@ class UniPC:
 
 
 class DPMSolverPP:
-    """dpmsolver++ (deterministic) of fm_solvers.py: step :706-798, updates :415-677."""
+    """dpmsolver++ (deterministic) and sde-dpmsolver++ of fm_solvers.py: step :706-798, updates :415-677; dynamic thresholding of
+    the x0 prediction :291-326.  (The class's other two algorithm types cannot run in the reference: they demand
+    final_sigmas_type "sigma_min", whose branch of set_timesteps reads an attribute the flow scheduler never defines.)"""
 
     def __init__(self, sigmas: Tensor, solver_order: int = 2, solver_type: str = "midpoint", lower_order_final: bool = True,
-                 euler_at_final: bool = False):
+                 euler_at_final: bool = False, algorithm_type: str = "dpmsolver++", thresholding: bool = False,
+                 dynamic_thresholding_ratio: float = 0.995, sample_max_value: float = 1.0):
         self.sigmas = [float(s) for s in sigmas]
         self.n = len(self.sigmas) - 1
         self.order, self.solver_type = solver_order, solver_type
         self.lower_order_final, self.euler_at_final = lower_order_final, euler_at_final
+        self.sde = algorithm_type == "sde-dpmsolver++"
+        self.thresholding, self.ratio, self.max_value = thresholding, dynamic_thresholding_ratio, sample_max_value
         self.m: List[Optional[Tensor]] = [None] * solver_order
         self.lower_order_nums, self.i = 0, 0
 
-    def terms(self, sample: Tensor) -> Terms:
+    def terms(self, sample: Tensor, noise: Optional[Tensor] = None) -> Terms:
         i, n = self.i, self.n
         final = i == n - 1                                               # final_sigmas_type == "zero" always lowers the last step
         second = i == n - 2 and self.lower_order_final and n < 15
         sig_t, sig_s0 = self.sigmas[i + 1], self.sigmas[i]
         alpha_t = 1.0 - sig_t
         h = _lam(sig_t) - _lam(sig_s0)
-        e = _expm1(-h)                                                   # exp(-h) - 1
         m0 = self.m[-1]
+        if self.sde:                                                     # :473-477 (first order), :568-580 (second order)
+            if sig_t == 0.0:                                             # h = inf: every factor of x and of the noise vanishes
+                return [(1.0, m0)]
+            em, e2 = math.exp(-h), -_expm1(-2.0 * h)                     # exp(-h), 1 - exp(-2h)
+            out = [(sig_t / sig_s0 * em, sample), (sig_t * math.sqrt(e2), noise)]
+            if self.order == 1 or self.lower_order_nums < 1 or final:
+                return out + [(alpha_t * e2, m0)]
+            r0 = (_lam(sig_s0) - _lam(self.sigmas[i - 1])) / h
+            c1 = 0.5 * alpha_t * e2 if self.solver_type == "midpoint" else alpha_t * (e2 / (-2.0 * h) + 1.0)
+            return out + [(alpha_t * e2 + c1 / r0, m0), (-c1 / r0, self.m[-2])]
+        e = _expm1(-h)                                                   # exp(-h) - 1
         base = [(sig_t / sig_s0, sample)]
         if self.order == 1 or self.lower_order_nums < 1 or final:
             return base + [(-alpha_t * e, m0)]
@@ -182,10 +197,16 @@ class DPMSolverPP:
         w1 = -c_d1 * r0 / (r0 + r1) - c_d2 / (r0 + r1)                  # coefficient of D1_1
         return base + [(-alpha_t * e + w0 / r0, m0), (-w0 / r0 + w1 / r1, m1), (-w1 / r1, m2)]
 
-    def step(self, model_output: Tensor, sample: Tensor) -> Tensor:
+    def step(self, model_output: Tensor, sample: Tensor, generator=None) -> Tensor:
         x0 = sample - self.sigmas[self.i] * model_output
+        if self.thresholding:                                            # :291-326
+            b = x0.shape[0]
+            flat = x0.reshape(b, -1)
+            s_ = torch.clamp(torch.quantile(flat.abs(), self.ratio, dim=1), min=1, max=self.max_value).unsqueeze(1)
+            x0 = (torch.clamp(flat, -s_, s_) / s_).reshape(x0.shape)
         self.m = self.m[1:] + [x0]
-        prev = apply(self.terms(sample))
+        noise = torch.randn(sample.shape, generator=generator, dtype=torch.float32) if self.sde else None      # :761-766
+        prev = apply(self.terms(sample, noise))
         if self.lower_order_nums < self.order:
             self.lower_order_nums += 1
         self.i += 1
@@ -196,8 +217,8 @@ class MultistepSchedule:
     """Adapter with the interface oracle.sampler.denoise_loop expects (`set_timesteps(n) -> timesteps`, `step(v, x)`),
     building the schedule the way the reference pipeline does for each family (PIPE.py:606-614)."""
 
-    def __init__(self, kind: str, shift: float = 5.0, **kw):
-        self.kind, self.shift, self.kw = kind, shift, kw
+    def __init__(self, kind: str, shift: float = 5.0, generator=None, **kw):
+        self.kind, self.shift, self.kw, self.generator = kind, shift, kw, generator
         self.solver = None
 
     def set_timesteps(self, num_steps: int) -> Tensor:
@@ -210,4 +231,4 @@ class MultistepSchedule:
         return ts
 
     def step(self, v: Tensor, x: Tensor) -> Tensor:
-        return self.solver.step(v, x)
+        return self.solver.step(v, x, generator=self.generator) if self.kind != "unipc" else self.solver.step(v, x)

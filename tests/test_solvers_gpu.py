@@ -33,8 +33,9 @@ def test_solver_traces_match_reference_golden(golden, name):
         retrieve_timesteps(sch, device="cuda:0", sigmas=get_sampling_sigmas(steps, shift))
     assert torch.equal(sch.sigmas.cpu(), fx["sigmas"]) and torch.equal(sch.timesteps.cpu(), fx["timesteps"])
     cur = x.cuda()
+    gen = torch.Generator().manual_seed(C.SOLVER_NOISE_SEED)             # the SDE cases draw their noise from it, on the CPU like the reference
     for i, t in enumerate(sch.timesteps):
-        cur = sch.step(vs[i].cuda(), t, cur, return_dict=False)[0]
+        cur = sch.step(vs[i].cuda(), t, cur, generator=gen, return_dict=False)[0]
         want = fx["trace"][i]
         err = (cur.cpu() - want).abs().max().item()
         assert err <= 2e-5 * max(1.0, want.abs().max().item()), (name, i, err)
@@ -68,7 +69,8 @@ def test_solver_kernels_match_torch():
         H.lincomb(out, [(1.0, dts[0])] * 9)
 
 
-@pytest.mark.parametrize("kind,kw", [("unipc", {}), ("dpm", {}), ("dpm", dict(solver_order=3))])
+@pytest.mark.parametrize("kind,kw", [("unipc", {}), ("dpm", {}), ("dpm", dict(solver_order=3)), ("dpm", dict(algorithm_type="sde-dpmsolver++")),
+                                     ("dpm", dict(thresholding=True, sample_max_value=2.0))])
 def test_sampler_loop_with_multistep_solver_matches_oracle(kind, kw):
     from flexam_amd import Wan2_2FunControlPipeline_FlexAM, Wan2_2Transformer3DModel_FlexAM
     from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
@@ -84,9 +86,9 @@ def test_sampler_loop_with_multistep_solver_matches_oracle(kind, kw):
     steps = 5
     out = pipe(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
                num_inference_steps=steps, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent",
-               shift=5).videos.float().cpu()
+               shift=5, generator=torch.Generator().manual_seed(C.SOLVER_NOISE_SEED)).videos.float().cpu()
     ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
-    ref = S.denoise_loop(lambda **k: O.dit_forward(sd, cfg, **k), SV.MultistepSchedule(kind, 5.0, **kw), steps, sc["latents"],
+    ref = S.denoise_loop(lambda **k: O.dit_forward(sd, cfg, **k), SV.MultistepSchedule(kind, 5.0, generator=torch.Generator().manual_seed(C.SOLVER_NOISE_SEED), **kw), steps, sc["latents"],
                          sc["context_uncond"], sc["context_cond"], sc["control_latents"], sc["additional_control"], ml,
                          sc["masked_video_latents"], sc["ref_latents"], mask, pinned, 0.1, 6.0)
     p = C.psnr(out, ref)
