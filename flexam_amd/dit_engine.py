@@ -178,7 +178,7 @@ class DiTEngine:
         self._ws.clear()
 
     def enable_fp8(self, on: bool = True):
-        """QKV and FFN projections on the fp8 (OCP e4m3) MFMA path: weights quantised once per output channel, activations per
+        """QKV (self-attention q|k|v, cross-attention q) and FFN projections on the fp8 (OCP e4m3) MFMA path: weights quantised once per output channel, activations per
         row and per call (flexam_quantize_rows_fp8), fp32 accumulation, the same fused epilogues.  Attention, the output / cross
         projections, norms, modulation and the residual stream are unchanged.  BASELINE.json configs[4] ("fp8 MFMA QKV/FFN
         variant"); the reference's own fp8 mode only stores weights in fp8 (FlexAM/utils/fp8_optimization.py:1-57)."""
@@ -188,7 +188,7 @@ class DiTEngine:
             self._fp8_w = []
             for p in self.blocks:
                 q = {}
-                for name in ("wqkv", "w1", "w2"):
+                for name in ("wqkv", "cwq", "w1", "w2"):
                     q[name], q["s_" + name] = hip.quantize_rows_fp8(p[name])
                 # bounds for the a-priori scale of FFN1's e4m3 output (flexam_ln_modulate_fp8, next_scale): the largest L2 norm of a
                 # DEQUANTISED w1 row (what the MFMA multiplies) and the largest |bias|; two floats per layer, read back once
@@ -477,9 +477,13 @@ class DiTEngine:
                 if nb < B:
                     xr[1].copy_(xr[0])
             # cross-attention on the text context (K/V precomputed per clip)
-            hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
             qc = qkv[:, 0:d]
-            hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
+            if self.fp8:                                   # the Q projection of cross-attention on the fp8 pipe as well (its K|V are per clip)
+                a8, sa, _ = self._ln_fp8(xres, ws, hbuf, ln_w=p["n3w"], ln_b=p["n3b"])
+                hip.gemm_fp8(a8, sa, self._fp8_w[i]["cwq"], self._fp8_w[i]["s_cwq"], p["cbq"], out=qc)
+            else:
+                hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
+                hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
             hip.rmsnorm_rope(qc, p["cnq"], eps=self.eps)
             kv = cd["cross_kv"][i][rsel]
             if cd.get("cross_lk"):                          # the identical padded text rows as ONE weighted key
