@@ -509,6 +509,9 @@ class DiTEngine:
                 hip.gemm_fp8_gate_residual(a8, sa, w8["w2"], w8["s_w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
             else:
                 hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
+                # (FFN1 -> FFN2 per row chunk, so that the [M, 14336] intermediate stays in the Infinity Cache: the clock rises with the
+                #  saved HBM traffic, but tile quantisation and launch ramps cost more: +0.5 / +1.6 / +7.1 % of a step at 2 / 4 / 7 chunks,
+                #  profiles/r4p_ffn_row_chunks.txt)
                 hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
                 hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
         if teacache is not None and calc:                  # residual = x_after_blocks - x_before (FX.py:1048-1051), kept on the GPU
