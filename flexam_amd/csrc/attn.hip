@@ -154,14 +154,20 @@ __device__ __forceinline__ float pair_sum(float x) {
 #endif
 #ifdef FLEXAM_ATTN_STAMPS      // diagnostic builds only (MI355X_MICROARCH.md, DVFS give-back item 6): the in-kernel clock of the main loop
 __device__ unsigned long long g_attn_stamps[2 * 8192];      // per workgroup: shader cycles and 100 MHz ticks across the tile loop; read by nobody on the device
-#define ATTN_STAMP_BEGIN() const unsigned long long st0_ = __builtin_amdgcn_s_memtime(), sr0_ = __builtin_amdgcn_s_memrealtime()
+__device__ unsigned long long g_attn_barrier_wait[8 * 8192];   // per workgroup and wave: shader cycles spent in the tile loop's s_barrier
+#define ATTN_STAMP_DECL() unsigned long long st0_ = 0, sr0_ = 0, bw_ = 0
+#define ATTN_STAMP_BEGIN() st0_ = __builtin_amdgcn_s_memtime(), sr0_ = __builtin_amdgcn_s_memrealtime()
+#define ATTN_STAMP_BARRIER(stmt) { const unsigned long long b0_ = __builtin_amdgcn_s_memtime(); stmt; bw_ += __builtin_amdgcn_s_memtime() - b0_; }
 #define ATTN_STAMP_END()                                                             \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) g_attn_barrier_wait[8 * blockIdx.x + (threadIdx.x >> 6)] = bw_;  \
   if (threadIdx.x == 0 && blockIdx.x < 8192) {                                       \
     g_attn_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0_;             \
     g_attn_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0_;     \
   }
 #else
+#define ATTN_STAMP_DECL()
 #define ATTN_STAMP_BEGIN()
+#define ATTN_STAMP_BARRIER(stmt) stmt
 #define ATTN_STAMP_END()
 #endif
 constexpr int NT = 512;
@@ -178,10 +184,15 @@ constexpr float RESCALE_THR_LOG2 = 8.0f;
 template <int KIND, bool PRE>
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 K tiles][4 V tiles], each a ring
+  ATTN_STAMP_DECL();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
+  // (Wave priorities: at equal priority the older half of the workgroup (waves 0-3) wins every arbitration against its SIMD partners,
+  //  runs ahead and waits ~800 cycles per tile at the barrier; a static priority for waves 4-7 mirrors that, and every scheme that
+  //  balances the halves -- priority in one part of the step only, turns by step or by tile -- is slower: while the leader waits its
+  //  partner has the SIMD to itself.  profiles/r4u_attn_wave_priority_modes_and_barrier_wait.txt)
 
   // workgroups bid = 8 * local + xcd go to XCD `xcd` in the order of `local`: an XCD walks a contiguous eighth of the work list
   auto eighth = [](int n, int xcd, int local) -> int {      // index into a list of n items, -1 past this XCD's share
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
         // tt-2 (last read by the PV of its second half) is free again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        ATTN_STAMP_BARRIER(__builtin_amdgcn_s_barrier());
         __builtin_amdgcn_sched_barrier(0);
       }
       // K pieces of tile tt+2 now, its V pieces half a tile later: two short bursts of LDS-DMA issue per tile instead
@@ -747,6 +758,9 @@ extern "C" int flexam_attn_fwd_partial(const void* q, int64_t q_bs, int64_t q_rs
 // diagnostic builds only (not declared in flexam_hip.h): copies the per-workgroup stamps of the last attention launch to the host
 extern "C" int flexam_debug_attn_stamps(unsigned long long* out, int n_workgroups) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), (size_t)n_workgroups * 16) == hipSuccess ? 0 : -1;
+}
+extern "C" int flexam_debug_attn_barrier_wait(unsigned long long* out, int n_workgroups) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_barrier_wait), (size_t)n_workgroups * 64) == hipSuccess ? 0 : -1;
 }
 #endif
 

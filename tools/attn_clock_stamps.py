@@ -7,8 +7,17 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 import torch
 from flexam_amd import hip as H
-lib = H.load_library(os.path.join(root, "tools", "probes", "libflexam_var_stamps.so"))
-lib.flexam_debug_attn_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+LIBS = sys.argv[1:] or ["stamps"]           # names of tools/probes/libflexam_var_<name>.so built with -DFLEXAM_ATTN_STAMPS
+lib = None
+
+
+def use(name):
+    global lib
+    lib = H.load_library(os.path.join(root, "tools", "probes", f"libflexam_var_{name}.so"))
+    lib.flexam_debug_attn_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+
+
+use(LIBS[0])
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 g = torch.Generator().manual_seed(0)
 L, d = 11648, 3072
@@ -17,7 +26,10 @@ q, k, v = (qkv[:, :, i * d:(i + 1) * d].unflatten(2, (24, 128)) for i in range(3
 o = torch.empty(2, L, 24, 128, dtype=BF, device=dev)
 NWG = 2048          # the whole-unit workgroups of a call (blockIdx < 2048 run all keys: 182 tiles)
 for rnd in range(2):
-    for body in ("32", "16"):
+    for name, body in ([(LIBS[0], "32"), (LIBS[0], "16")] if len(LIBS) == 1 else [(n, "32") for n in LIBS]):
+        use(name)
+        if len(LIBS) > 1:
+            print(f"-- {name}", flush=True)
         os.environ["FLEXAM_ATTN_BODY"] = body
         t0 = time.perf_counter()
         n = 0
@@ -36,5 +48,12 @@ for rnd in range(2):
         clk = [buf[2 * i] / buf[2 * i + 1] * 100.0 for i in range(NWG) if buf[2 * i + 1] > 0]
         cyc = [buf[2 * i] for i in range(NWG) if buf[2 * i + 1] > 0]
         ghz = statistics.median(clk) / 1e3
+        if body == "32" and hasattr(lib, "flexam_debug_attn_barrier_wait"):
+            lib.flexam_debug_attn_barrier_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            bb = (ctypes.c_ulonglong * (8 * NWG))()
+            if lib.flexam_debug_attn_barrier_wait(bb, NWG) == 0:
+                per_wave = [statistics.median(bb[8 * i + w] for i in range(NWG)) for w in range(8)]
+                print("   cycles in the tile loop's s_barrier per wave (median over workgroups, of %.0f kcycles): " % (statistics.median(cyc) / 1e3)
+                      + " ".join(f"w{w}:{v / 1e3:.1f}k" for w, v in enumerate(per_wave)), flush=True)
         print(f"body {body}x{body}: {us:8.1f} us/call   in-kernel clock {ghz:.3f} GHz (median of {len(clk)} workgroups, min {min(clk) / 1e3:.3f} max {max(clk) / 1e3:.3f})   "
               f"tile loop {statistics.median(cyc) / 1e3:8.1f} kcycles per work unit (182 tiles)   call = {us * ghz * 1e-3:.3f} Mcycles", flush=True)
