@@ -137,7 +137,9 @@ def self_attention_in_step(pipe, step_index, B):
     finally:
         hip.attn_fwd = real
     full = [s.elapsed_time(e) * 1e-3 for b, s, e in marks if b == B]
-    return {"sec": sum(full) / len(full), "calls": len(full), "calls_other_batch": len(marks) - len(full)} if full else None
+    every = [s.elapsed_time(e) * 1e-3 for b, s, e in marks]
+    return {"sec": sum(full) / len(full), "calls": len(full), "calls_other_batch": len(marks) - len(full),
+            "sec_all_calls": sum(every) / len(every)} if full else None
 
 
 def kernel_rooflines(eng, B, L, lc):
@@ -854,6 +856,9 @@ def main():
                                             "sample: block 0 shared by the CFG pair); this is what rocprofv3 --kernel-trace --stats of the same command averages for "
                                             "the kernel (+ the 20 us merge)" % (attn_in_step["calls"], attn_in_step["calls_other_batch"])) if attn_in_step
                                            else "isolated back-to-back launches (no in-step timing in this run)",
+                                  "launch_ms_all_calls": attn_in_step["sec_all_calls"] * 1e3 if attn_in_step else None,
+                                  "launch_ms_all_calls_note": "mean over ALL self-attention calls of that step (the one-sample call of block 0 included) + the merge: "
+                                                              "compare with the kernel's AverageNs in rocprofv3 --kernel-trace --stats of `bench.py --no-kernel-timing`",
                                   "isolated_launch_ms": a["sec"] * 1e3, "isolated_frac": a["tflops"] / PEAK_BF16_TFLOPS,
                                   "isolated_note": "8 back-to-back launches on the step's own buffers: runs at the clock the kernel holds alone, not the step's",
                                   "launch_note": "one self-attention call = ONE attn_fwd_kernel<0, true> launch (the full rounds of work units and, on the same "
