@@ -35,7 +35,6 @@ namespace {
 
 constexpr int BN = 256, BK = 64;
 constexpr int TILE_BYTES = 256 * BK * 2;   // 32 KiB per operand tile (A: up to 256 rows)
-constexpr int GEMM_2WG_DEFAULT = 0;        // see launch()
 
 struct GemmParams {
   const bf16* A;
@@ -58,7 +57,6 @@ struct GemmParams {
   // (gemm_splitk_finish_kernel) adds the slices up in slice order and runs the epilogue
   int units, split_full, split_s;
   float* ws;
-  int delay;               // NW = 4 instances: start-up delay of the second workgroup of every CU, in units of ~4 us (experiment)
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -84,6 +82,9 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // Everything outside the MFMA calls is written over "row tiles" of RT = 16 rows: lane -> row (lane % RT) of a row tile and column
 // group g = lane / RT; a lane holds, for every 4-column unit v < NV of the wave's 64 columns, the 4 consecutive columns
 // 4*NG*v + 4*g .. +3 of that row (NG = 4, NV = 4).
+// (A 4-wave instance on 128 x 128 tiles, 74 KiB of LDS, TWO workgroups per CU -- meant to run one workgroup's fp32 read-modify-write
+// epilogue under its neighbour's K loop for the N = K = 3072 gate-residual launches -- was built in r4: bit-exact, K loops +22 %, and
+// the epilogue stayed exposed, because it is the HBM time of X's 572 MB, not a per-CU latency: profiles/r4z_oproj_two_workgroups_per_cu.txt.)
 // TAIL: the instance that runs the K slices of the tail tiles (units >= split_full) and parks their partial sums; it has no
 // epilogue (gemm_splitk_finish_kernel runs it).  The TAIL = false instance runs the whole tiles only.  Two instances instead of
 // one kernel with both paths: with the slab stores between the K loop and the epilogues hipcc spills 30-50 registers in the
@@ -92,16 +93,11 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // waves x 5 n-tiles = a (64 MT) x 160 tile for output widths that are multiples of 160 but not of 256 (the VAE encoder's 160 / 320 /
 // 640 channels, which fill 62.5 % / 62.5 % / 83 % of 256-wide tiles).  The 160-wide shape stores through the generic epilogue (its
 // 80-column wave rows do not fit the 128-byte LDS turn-around).
-// NW = waves per workgroup.  8: one workgroup per CU (two waves per SIMD), the shapes above.  4: a 128 x 128 tile (MT = 4, 2 x 2
-// waves) in 74 KiB of LDS, TWO workgroups per CU: while one of them read-modify-writes its 128 KiB of fp32 X the other one is in
-// its K loop -- the gate-residual launches with a short K (o-projection, cross-attention o), where that epilogue is a fifth of a
-// tile's time.  Costs twice the LDS-DMA bytes and a third more fragment reads per MFMA.
-template <int EPI, typename OutT, int MT, bool TAIL = false, int WMW = 2, int NTW = 4, int NW = 8>
-__global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
+template <int EPI, typename OutT, int MT, bool TAIL = false, int WMW = 2, int NTW = 4>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
   static_assert((WMW == 2 && NTW == 4) || (WMW == 4 && NTW == 5 && MT <= 4), "supported wave layouts: 2 x 4 x 4 n-tiles, 4 x 2 x 5 n-tiles");
-  static_assert(NW == 8 || (NW == 4 && WMW == 2 && NTW == 4 && MT == 4 && !TAIL), "4 waves: the 128 x 128 tile only, no split-K");
-  constexpr bool STD = WMW == 2 && NTW == 4;   // the 64-columns-per-wave shapes with LDS-staged epilogues
-  constexpr int WNW = NW / WMW;             // waves along N
+  constexpr bool STD = WMW == 2 && NTW == 4;   // the 256-wide shape with LDS-staged epilogues
+  constexpr int WNW = 8 / WMW;              // waves along N
   constexpr int BN_ = WNW * NTW * 16;       // columns of this tile shape
   constexpr int RT = 16;                    // rows per row tile
   constexpr int NRT = 16 * MT / RT;         // row tiles per wave
@@ -109,12 +105,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
   constexpr int NV = NTW * 4 / NG;          // 4-column units per lane
   constexpr int STG_WAVE = RT * 128;        // epilogue staging per wave: one row tile of bf16 outputs (RT rows x 64 columns)
   constexpr int BM_ = WMW * 16 * MT;        // rows of this tile shape
-  constexpr int RP = NW * 8;                // rows per staging piece (one 16-byte chunk per thread)
-  constexpr int PA = (BM_ + RP - 1) / RP;   // staging pieces per thread for A
-  constexpr int PW = (BN_ + RP - 1) / RP;   // ... and for W
-  constexpr int TA = NW == 8 ? TILE_BYTES : BM_ * 128;   // LDS bytes of the A tile (8 waves: room for 256 rows whatever MT) ...
-  constexpr int TW = NW == 8 ? TILE_BYTES : BN_ * 128;   // ... and of the W tile
-  constexpr int BUF = TA + TW;              // one K-block buffer
+  constexpr int PA = (BM_ + 63) / 64;       // 64-row staging pieces per thread for A
+  constexpr int PW = (BN_ + 63) / 64;       // ... and for W
   constexpr int NP = PA + PW;               // LDS-DMA pieces per thread per K block
   constexpr int NF = NTW + MT;              // fragments per 32-deep K half
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
@@ -127,10 +119,6 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
   asm volatile("" : "+s"(wave));
   const int wm = wave / WNW, wn = wave % WNW;
 
-  if constexpr (NW == 4) {
-    if (p.delay > 0 && (int)(blockIdx.x >> 3) >= (int)(gridDim.x >> 4))
-      for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   // ---- persistent workgroups over an XCD-aware, grouped tile order: workgroup w lives on XCD w & 7 (round-robin
   // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
   // stride gridDim/8, so the tiles resident on an XCD at any time are neighbours in the list (shared A / W panels in
@@ -170,7 +158,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
     const int ts = (wave << 6) | fresh_lane();          // thread id, rebuilt (see fresh_lane)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = i * RP + (ts >> 3);
+      const int row = i * 64 + (ts >> 3);
       const int chunk = (ts & 7) ^ ((row >> 1) & 7);
       if (i < PA) a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);   // edge tiles re-read their last row
       if (i < PW) w_off[i] = (uint32_t)(((int64_t)min(row, p.N - 1 - n0) * p.ldw + chunk * 8) * 2);
@@ -197,14 +185,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
   // issued IN FRONT of the unit's K block 0 pieces (so every wait that covers K block 0 covers it), into one of two slots (unit
   // parity: the next unit's bias is on its way while this unit's epilogue reads its own).
   constexpr bool BIAS_LDS = STD && !TAIL;
-  constexpr int BIAS_OFF = 2 * BUF + NW * STG_WAVE;             // [2 slots][NW waves][64 floats]
+  constexpr int BIAS_OFF = 4 * TILE_BYTES + 8 * STG_WAVE;       // [2 slots][8 waves][64 floats]
   auto bias_dma = [&](int n0, int slot) {
     if constexpr (BIAS_LDS) {
       const float* pb = p.bias;          // laundered: the test is made here, on scalar registers, not kept as a 0 / 1 VGPR across the K loop
       asm volatile("" : "+s"(pb));       // (with ~100 SGPRs in use hipcc parks loop-invariant uniform values in VGPRs and then spills those)
       if (pb) {
         const uint32_t voff = (uint32_t)min(n0 + wn * (16 * NTW) + fresh_lane(), p.N - 1) * 4u;
-        const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + BIAS_OFF + (slot * NW + wave) * 256;
+        const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + BIAS_OFF + (slot * 8 + wave) * 256;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(pb), "s"(dst) : "memory");
       }
     }
@@ -213,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
     if (!p.bias) {                // no bias: both slots hold zeros for the whole launch (wave-local, ordered before any later read)
       float* z = (float*)(smem + BIAS_OFF + wave * 256);
       z[fresh_lane()] = 0.f;
-      z[NW * 64 + fresh_lane()] = 0.f;
+      z[8 * 64 + fresh_lane()] = 0.f;
     }
   }
   bool staged = false;          // K blocks 0 and 1 of the coming unit are already on their way into the two LDS buffers
@@ -255,7 +243,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
   auto dma = [&](int i, int64_t ka, int64_t kw, char* buf) {
     const char* sbase = i < PA ? a_tile + ka * 2 : w_tile + kw * 2;
     const uint32_t voff = i < PA ? a_off[i] : w_off[i - PA];
-    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * (NW * 1024) : TA + (i - PA) * (NW * 1024)) + wave * 1024;
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * 8192 : TILE_BYTES + (i - PA) * 8192) + wave * 1024;
     if (ABLATE(p, 4) || (ABLATE(p, 16) && i >= PA)) return;      // 16: no W-tile staging (half the LDS-DMA)
     // M0 (the LDS base of the DMA) is written and NOT restored: nothing else in this kernel uses it (gfx9+ LDS instructions do not;
     // tools/isa_loopwaits.py lists any other M0 reader of the listing), and the save / restore pair was 2 of the 6 scalar
@@ -269,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
   // fragment j (< NF = MT + NTW) of the set of K half hf: j < NTW -> W n-tile j, else A m-tile j - NTW, all 32 deep
   auto frag = [&](const char* buf, int hf, int j) -> bf16x8 {
     const int fo = frag_off[hf];
-    return j < NTW ? *(const bf16x8*)(buf + TA + wn * (16 * NTW * 128) + j * 2048 + fo)
+    return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
                    : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
   };
   // fragments 2g, 2g+1 of a set
@@ -300,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
     if (nkl > 1) {
       const int64_t k1 = kcol_a(kb0 + 1);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(kb0 + 1) * BK, smem + BUF);
+      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(kb0 + 1) * BK, smem + 2 * TILE_BYTES);
     }
   }
   int64_t kcol_next = kcol_a(kb0 + 2);    // A offset of the K block staged next, fetched one step ahead
@@ -326,8 +314,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
 
   auto block = [&](int kb, auto dma_c, auto rd_c, auto wait_c) {
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
-    char* cur = smem + (kb & 1) * BUF;
-    char* nxt = smem + ((kb + 1) & 1) * BUF;
+    char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
+    char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
     const int64_t kw = (int64_t)(kb0 + kb + 2) * BK;
 #pragma unroll
     for (int g = 0; g < MT; ++g) {                      // phase A
@@ -374,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
     if (nnkl > 1) {
       const int64_t k1 = kcol_a(nkb0 + 1);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(nkb0 + 1) * BK, smem + BUF);
+      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(nkb0 + 1) * BK, smem + 2 * TILE_BYTES);
     }
   }
 
@@ -404,7 +392,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
   const int ncol = n0 + wn * (16 * NTW) + (le / RT) * 4;
   f32x4 bias[NV];
   if constexpr (BIAS_LDS) {
-    const float* bl = (const float*)(smem + BIAS_OFF + ((it & 1) * NW + wave) * 256);     // landed with this unit's K block 0
+    const float* bl = (const float*)(smem + BIAS_OFF + ((it & 1) * 8 + wave) * 256);     // landed with this unit's K block 0
 #pragma unroll
     for (int v = 0; v < NV; ++v) bias[v] = *(const f32x4*)(bl + v * (4 * NG) + (le / RT) * 4);
   } else {
@@ -420,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_bf16_kernel(GemmParams p, con
   for (int v = 0; v < NV; ++v) asm volatile("" ::"v"(bias[v]));
   // LDS staging of one row tile (RT rows x 64 bf16 columns = RT x 128 bytes per wave, 16-byte chunks XOR-swizzled by row: the
   // 8-byte writes and the wider reads are conflict-free).  Unit v of a lane starts at byte 8*NG*v + 8*g of its row.
-  char* stg = smem + 2 * BUF + wave * STG_WAVE;
+  char* stg = smem + 4 * TILE_BYTES + wave * STG_WAVE;
   const int wr_row = le & (RT - 1), wr_g = le / RT;
   auto stg_write = [&](int v, bf16x4 o) {
     *(bf16x4*)(stg + wr_row * 128 + ((((NG / 2) * v + (wr_g >> 1)) ^ (wr_row & 7)) << 4) + (wr_g & 1) * 8) = o;
@@ -666,12 +654,11 @@ void plan_split(const GemmWorkspace& g_ws, int tiles, int nk, int& S, int& rem, 
   if (cost) *cost = best;
 }
 
-template <int EPI, typename OutT, int MT, int WMW = 2, int NTW = 4, int NW = 8>
+template <int EPI, typename OutT, int MT, int WMW = 2, int NTW = 4>
 int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
-  auto kern = gemm_bf16_kernel<EPI, OutT, MT, false, WMW, NTW, NW>;
+  auto kern = gemm_bf16_kernel<EPI, OutT, MT, false, WMW, NTW>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};          // per device: the attribute belongs to the device's copy of the code object
-  // two K-block buffers (8 waves: 128 KiB; 4 waves: 64 KiB) + one row tile of bf16 outputs per wave + two bias slots per wave
-  const int smem = (NW == 8 ? 4 * TILE_BYTES : 2 * (WMW * 16 * MT + (NW / WMW) * NTW * 16) * 128) + NW * 16 * 128 + 2 * NW * 256;
+  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 2 * 8 * 256;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots per wave
   const int dev = flexam_current_device();
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -679,10 +666,10 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
     attr_set[dev] = true;
   }
   p.tiles_m = (p.M + WMW * 16 * MT - 1) / (WMW * 16 * MT);
-  p.tiles_n = (p.N + (NW / WMW) * NTW * 16 - 1) / ((NW / WMW) * NTW * 16);
+  p.tiles_n = (p.N + (8 / WMW) * NTW * 16 - 1) / ((8 / WMW) * NTW * 16);
   const int tiles = p.tiles_m * p.tiles_n;
-  int split_s = 1, rem = 0;
-  if constexpr (NW == 8) plan_split(g_ws, tiles, p.K / BK, split_s, rem);
+  int split_s, rem;
+  plan_split(g_ws, tiles, p.K / BK, split_s, rem);
   p.split_s = split_s;
   p.split_full = split_s > 1 ? tiles - rem : tiles;
   p.units = p.split_full + (split_s > 1 ? rem * split_s : 0);
@@ -690,12 +677,11 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
   static const int persist = [] { const char* e = getenv("FLEXAM_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
   auto grid_for_units = [&](int nwg) {
     int grid = (nwg + 7) / 8 * 8;                        // a multiple of 8 so that blockIdx & 7 is the XCD
-    const int resident = num_cus() * (8 / NW);           // one persistent workgroup per CU (144 / 160 KiB of LDS each); 4 waves: two (74 KiB each)
-    if (persist && grid > resident) grid = resident;
+    if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (144 / 160 KiB of LDS each)
     return grid;
   };
-  if (p.split_full > 0) hipLaunchKernelGGL(kern, dim3(grid_for_units(p.split_full)), dim3(NW * 64), smem, s, p, a_koff);
-  if constexpr (NW == 8) if (split_s > 1) {
+  if (p.split_full > 0) hipLaunchKernelGGL(kern, dim3(grid_for_units(p.split_full)), dim3(512), smem, s, p, a_koff);
+  if (split_s > 1) {
     // the K slices of the tail tiles, then (stream-ordered) their sum in slice order + the epilogue
     auto tail = gemm_bf16_kernel<EPI_NONE, float, MT, true, WMW, NTW>;
     static bool tail_attr[FLEXAM_MAX_DEVICES] = {};
@@ -763,22 +749,6 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
   p.debug = dbg ? atoi(dbg) : 0;
 #endif
-  // short-K gate-residual launches (o-projection, cross-attention o: N = K = 3072): two 4-wave workgroups per CU on 128 x 128 tiles,
-  // one in its K loop while the other read-modify-writes X (FLEXAM_GEMM_2WG=0/1, read per call: tools/ab_step.py flips it in one process)
-#ifdef FLEXAM_GEMM_2WG_ALL
-  if constexpr (sizeof(OutT) == 2 && EPI != EPI_GELU) {
-#else
-  if constexpr (EPI == EPI_GATE_RESIDUAL) {
-#endif
-    const char* e = getenv("FLEXAM_GEMM_2WG");
-    const int two = e ? atoi(e) : GEMM_2WG_DEFAULT;
-    if (two && a_koff == nullptr && p.K <= 4096 && p.M >= 4096) {
-      if (!getenv("FLEXAM_GEMM_GM")) p.gm = 8;
-      const char* d = getenv("FLEXAM_GEMM_2WG_DELAY");
-      p.delay = d ? atoi(d) : 0;
-      return launch_shape<EPI, OutT, 4, 2, 4, 4>(p, g_ws, a_koff, s);
-    }
-  }
   // output widths that are multiples of 160 but not of 256 (VAE encoder: 160, 320 channels): the 256 x 160 shape wastes nothing,
   // a 256-wide tile 37.5 %; FLEXAM_GEMM_N160=0 keeps the 256-wide shape (A/B), =2 also takes N = 640 (83 % of 256-wide tiles)
   {
