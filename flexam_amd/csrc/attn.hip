@@ -59,6 +59,11 @@ struct AttnParams {
   // n_slots: slots the merge kernel adds up
   int partial, slot0, n_slots;
   float last_key_bias;  // added to the score of key Lk - 1 in exp2 units (log2 of its multiplicity), 0 = none: see flexam_attn_fwd_lastkey
+  // MXFP8 operands (attn_fp8.inc; q8 != nullptr selects that kernel): written by flexam_attn_fp8_pack
+  const unsigned char* q8;   // [B][H][lq_pad][128] e4m3
+  const unsigned* qs;        // [B][H][lq_pad] four E8M0 bytes per row
+  const unsigned char* kv8;  // [B][H][ceil(Lk / 64)] records of REC_BYTES
+  int lq_pad;
 };
 
 // byte offset of 16-byte chunk `ch` (0..15) of key row `row` in a [64][128] bf16 tile, image (b)
@@ -609,6 +614,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
 #ifdef FLEXAM_ATTN_BODY16
 #include "attn_body16.inc"
 #endif
+#include "attn_fp8.inc"
 
 // out[b][q][head][:] = sum_s w_s O_s / sum_s w_s l_s with w_s = exp2((m_s - max_s m_s) * scale_log2e) for the rows of the
 // launch's units; one wave per row, two columns per lane
@@ -643,8 +649,9 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
 
 int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
              int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk, int head_dim, float softmax_scale,
-             int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream, int partial_slot0 = -1, float last_key_bias = 0.f) {
-  FX_REQUIRE(q && k && v && (o || partial_slot0 >= 0), FLEXAM_E_ARG, "attn_fwd: null pointer");
+             int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream, int partial_slot0 = -1, float last_key_bias = 0.f,
+             const void* q8 = nullptr, const void* qs = nullptr, const void* kv8 = nullptr) {
+  FX_REQUIRE(((q && k && v) || (q8 && qs && kv8)) && (o || partial_slot0 >= 0), FLEXAM_E_ARG, "attn_fwd: null pointer");
   FX_REQUIRE(head_dim == HD, FLEXAM_E_SHAPE, "attn_fwd: head_dim %d unsupported (128 only)", head_dim);
   FX_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, FLEXAM_E_SHAPE, "attn_fwd: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
   FX_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 &&
@@ -666,12 +673,15 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.ws_o = ws_o; p.ws_ml = ws_ml;
   p.partial = 0; p.slot0 = 0; p.n_slots = p.kv_splits; p.whole_units = 0;
   p.last_key_bias = last_key_bias;
-  FX_REQUIRE((int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
+  p.q8 = (const unsigned char*)q8; p.qs = (const unsigned*)qs; p.kv8 = (const unsigned char*)kv8;
+  p.lq_pad = p.q_blocks * QBLK;
+  FX_REQUIRE(q8 || (int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
-  const int smem = NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB
+  const int smem = q8 ? NSLOT * REC_BYTES + 8 * 4096 : NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB (fp8: 4 records, 68 KiB)
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
   auto kern = cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
                     : (p.prescaled ? attn_fwd_kernel<0, true> : attn_fwd_kernel<0, false>);
+  if (q8) kern = attn8_fwd_kernel<0>;
   bool body16 = false;
 #ifdef FLEXAM_ATTN_BODY16                              // diagnostic builds only (attn_body16.inc): the 16x16x32 body, selected per call
   const char* be = getenv("FLEXAM_ATTN_BODY");
@@ -679,8 +689,8 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   if (body16) kern = cross ? (p.prescaled ? attn_fwd16_kernel<1, true> : attn_fwd16_kernel<1, false>)
                            : (p.prescaled ? attn_fwd16_kernel<0, true> : attn_fwd16_kernel<0, false>);
 #endif
-  static bool attr_set[FLEXAM_MAX_DEVICES][8] = {};      // per device and kernel instance
-  const int which = (cross ? 1 : 0) + (p.prescaled ? 2 : 0) + (body16 ? 4 : 0);
+  static bool attr_set[FLEXAM_MAX_DEVICES][9] = {};      // per device and kernel instance
+  const int which = q8 ? 8 : (cross ? 1 : 0) + (p.prescaled ? 2 : 0) + (body16 ? 4 : 0);
   const int dev = flexam_current_device();
   if (!attr_set[dev][which]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -753,6 +763,32 @@ extern "C" int flexam_attn_fwd_partial(const void* q, int64_t q_bs, int64_t q_rs
   FX_REQUIRE(slot0 >= 0, FLEXAM_E_ARG, "attn_fwd_partial: negative slot");
   return attn_run(q, q_bs, q_rs, k, k_bs, k_rs, v, v_bs, v_rs, nullptr, 0, 0, B, H, Lq, Lk, head_dim, softmax_scale, kv_splits, 0, ws_o,
                   ws_ml, stream, slot0);
+}
+
+extern "C" int flexam_attn_fp8_pack(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
+                                    int64_t v_bs, int64_t v_rs, void* q8, void* qs, void* kv8, int B, int H, int L, int head_dim,
+                                    void* stream) {
+  FX_REQUIRE(q && k && v && q8 && qs && kv8, FLEXAM_E_ARG, "attn_fp8_pack: null pointer");
+  FX_REQUIRE(head_dim == HD && B > 0 && H > 0 && L > 0, FLEXAM_E_SHAPE, "attn_fp8_pack: bad sizes (head_dim 128 only)");
+  FX_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0, FLEXAM_E_SHAPE,
+             "attn_fp8_pack: strides must keep 16-byte alignment of head rows");
+  FX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)q8 | (uintptr_t)qs | (uintptr_t)kv8) % 16 == 0, FLEXAM_E_ARG,
+             "attn_fp8_pack: misaligned pointer");
+  Attn8Pack a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.v = (const bf16*)v;
+  a.q_bs = q_bs; a.q_rs = q_rs; a.k_bs = k_bs; a.k_rs = k_rs; a.v_bs = v_bs; a.v_rs = v_rs;
+  a.q8 = (unsigned char*)q8; a.qs = (unsigned char*)qs; a.kv8 = (unsigned char*)kv8;
+  a.H = H; a.L = L; a.lq_pad = (L + QBLK - 1) / QBLK * QBLK; a.tiles = (L + KVBLK - 1) / KVBLK;
+  hipLaunchKernelGGL(attn8_pack_kernel, dim3(a.lq_pad / KVBLK, H, B), dim3(256), 0, (hipStream_t)stream, a);
+  return flexam_check_launch("flexam_attn_fp8_pack");
+}
+
+extern "C" int flexam_attn_fwd_fp8(const void* q8, const void* qs, const void* kv8, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int L,
+                                   int head_dim, int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream) {
+  FX_REQUIRE(q8 && qs && kv8, FLEXAM_E_ARG, "attn_fwd_fp8: null pointer");
+  FX_REQUIRE(((uintptr_t)q8 | (uintptr_t)qs | (uintptr_t)kv8) % 16 == 0, FLEXAM_E_ARG, "attn_fwd_fp8: misaligned pointer");
+  return attn_run(nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, o, o_bs, o_rs, B, H, L, L, head_dim, FLEXAM_ATTN_PRESCALED, kv_splits,
+                  split_from_unit, ws_o, ws_ml, stream, -1, 0.f, q8, qs, kv8);
 }
 
 #ifdef FLEXAM_ATTN_STAMPS

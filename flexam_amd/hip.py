@@ -34,6 +34,8 @@ _SIGNATURES = {
     "flexam_attn_fwd_splitkv": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_fwd_partial": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_merge": ([_P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
+    "flexam_attn_fp8_pack": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P], c_int),
+    "flexam_attn_fwd_fp8": ([_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
     "flexam_ln_modulate_fp8": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _F, _F, _P], c_int),
     "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
@@ -379,6 +381,61 @@ def attn_merge(out, ws, n_slots, softmax_scale=None, prescaled=False):
     scale = ATTN_PRESCALED if prescaled else (softmax_scale if softmax_scale is not None else D ** -0.5)
     _check(lib().flexam_attn_merge(_ptr(out, BF16), out.stride(0), out.stride(1), B, H, Lq, D, scale, n_slots, _ptr(ws[0], F32),
                                    _ptr(ws[1], F32), _stream()), "flexam_attn_merge")
+    return out
+
+
+ATTN8_REC_BYTES = 18432
+
+
+def attn_fp8_buffers(B, H, L, device):
+    """(q8, qs, kv8) for attn_fp8_pack / attn_fwd_fp8 at this shape (see flexam_hip.h)."""
+    lp, tiles = -(-L // 256) * 256, -(-L // 64)
+    return (torch.empty(B, H, lp, 128, device=device, dtype=torch.uint8), torch.empty(B, H, lp, device=device, dtype=torch.int32),
+            torch.empty(B, H, tiles, ATTN8_REC_BYTES, device=device, dtype=torch.uint8))
+
+
+def attn_fp8_pack(q, k, v, bufs=None):
+    """q, k, v [B, L, H, 128] bf16 (q prescaled by softmax_scale * log2 e) -> the MXFP8 operand buffers of attn_fwd_fp8."""
+    B, L, H, D = q.shape
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != D or t.shape != q.shape:
+            raise RuntimeError("attn_fp8_pack: q, k, v must be [B, L, H, 128] with packed heads")
+    if bufs is None:
+        bufs = attn_fp8_buffers(B, H, L, q.device)
+    q8, qs, kv8 = bufs
+    if q8.shape[:3] != (B, H, -(-L // 256) * 256) or kv8.shape[:3] != (B, H, -(-L // 64)):
+        raise RuntimeError("attn_fp8_pack: buffers of another shape")
+    _check(lib().flexam_attn_fp8_pack(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1), _ptr(v, BF16),
+                                      v.stride(0), v.stride(1), q8.data_ptr(), qs.data_ptr(), kv8.data_ptr(), B, H, L, D, _stream()),
+           "flexam_attn_fp8_pack")
+    return bufs
+
+
+def attn_fwd_fp8(bufs, L, out=None, kv_splits=None, split_from_unit=None):
+    """Self-attention from packed MXFP8 operands (attn_fp8_pack) -> out [B, L, H, 128] bf16."""
+    q8, qs, kv8 = bufs
+    B, H, D = q8.shape[0], q8.shape[1], 128
+    if out is None:
+        out = torch.empty(B, L, H, D, device=q8.device, dtype=BF16)
+    if out.stride(3) != 1 or out.stride(2) != D:
+        raise RuntimeError("attn_fwd_fp8: heads must be packed along the row")
+    units = B * H * ((L + 255) // 256)
+    if kv_splits is None:
+        S, from_unit = attn_split_plan(B * H, L, L, num_cus())
+    else:
+        S, from_unit = int(kv_splits), (0 if split_from_unit is None else int(split_from_unit))
+    ws_o = ws_ml = None
+    if S > 1:
+        n = units - from_unit
+        st = _stream()
+        slot, key = (q8.device.index if q8.device.index is not None else torch.cuda.current_device(), st), (S, n)
+        if _ATTN_WS.get(slot, (None,))[0] != key:
+            _ATTN_WS.pop(slot, None)
+            _ws_slot(_ATTN_WS, slot, lambda: (key, torch.empty(S, n, 256, D, device=q8.device, dtype=F32),
+                                              torch.empty(S, n, 256, 2, device=q8.device, dtype=F32)))
+        _, ws_o, ws_ml = _ws_slot(_ATTN_WS, slot, None)
+    _check(lib().flexam_attn_fwd_fp8(q8.data_ptr(), qs.data_ptr(), kv8.data_ptr(), _ptr(out, BF16), out.stride(0), out.stride(1), B, H, L, D,
+                                     max(S, 1), from_unit if S > 1 else 0, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()), "flexam_attn_fwd_fp8")
     return out
 
 

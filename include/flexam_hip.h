@@ -140,6 +140,20 @@ int flexam_attn_fwd_partial(const void* q, int64_t q_bs, int64_t q_rs, const voi
 int flexam_attn_merge(void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int head_dim, float softmax_scale, int n_slots,
                       const float* ws_o, const float* ws_ml, void* stream);
 
+/* Self-attention with MXFP8 operands (OCP e4m3 + one E8M0 scale per 32 elements; both products on
+ * v_mfma_scale_f32_32x32x64_f8f6f4 at twice the bf16 MFMA rate, fp32 softmax and accumulation) -- the quantised variant behind
+ * VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION, FlexAM/models/attention_utils.py:195-203 (the reference calls the third-party
+ * `sageattn`, which quantises Q, K and the P.V product; kept here: its contract, softmax attention within a stated tolerance).
+ * flexam_attn_fp8_pack: q, k, v bf16 [B, L, H, 128] as flexam_attn_fwd takes them (q carrying softmax_scale * log2 e, i.e. the
+ * FLEXAM_ATTN_PRESCALED form) -> q8 [B][H][Lp][128] e4m3, qs [B][H][Lp] four E8M0 bytes per row, kv8 [B][H][T] records of 18432
+ * bytes (K tile image, V^T tile image with the key order the P.V operand needs, their scales), Lp = ceil(L / 256) * 256,
+ * T = ceil(L / 64); rows past L are written as zeros.  flexam_attn_fwd_fp8: o [B, L, H, 128] bf16 from those buffers; kv_splits /
+ * split_from_unit / ws_o / ws_ml as flexam_attn_fwd_splitkv (kv_splits = 1: no workspace). */
+int flexam_attn_fp8_pack(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
+                         int64_t v_bs, int64_t v_rs, void* q8, void* qs, void* kv8, int B, int H, int L, int head_dim, void* stream);
+int flexam_attn_fwd_fp8(const void* q8, const void* qs, const void* kv8, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int L,
+                        int head_dim, int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream);
+
 /* out_bf16[m,:] = LN(x_f32[m,:]; eps) [* ln_w + ln_b] [* scale[row(m),:] + shift[row(m),:]]
  * row(m) = row_index[m] if row_index else m / rows_per_batch; scale rows already hold (1+scale),
  * shift rows already hold shift + density shift (flexam_mod_table).  Replaces WanLayerNorm +
