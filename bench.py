@@ -130,12 +130,21 @@ def self_attention_in_step(pipe, step_index, B):
         e.record()
         marks.append((q.shape[0], s, e))
         return out
-    hip.attn_fwd = timed_attn
+    real8 = hip.attn_fwd_fp8
+
+    def timed_attn8(bufs, L, *a, **kw):                 # --sage: the MXFP8 kernel in the same place (its pack launch is not part of this figure)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = real8(bufs, L, *a, **kw)
+        e.record()
+        marks.append((kw["out"].shape[0] if kw.get("out") is not None else bufs[0].shape[0], s, e))
+        return out
+    hip.attn_fwd, hip.attn_fwd_fp8 = timed_attn, timed_attn8
     try:
         pipe.denoise_step(step_index)
         torch.cuda.synchronize()
     finally:
-        hip.attn_fwd = real
+        hip.attn_fwd, hip.attn_fwd_fp8 = real, real8
     full = [s.elapsed_time(e) * 1e-3 for b, s, e in marks if b == B]
     every = [s.elapsed_time(e) * 1e-3 for b, s, e in marks]
     return {"sec": sum(full) / len(full), "calls": len(full), "calls_other_batch": len(marks) - len(full),
@@ -514,6 +523,8 @@ def main():
     ap.add_argument("--width", type=int, default=896)
     ap.add_argument("--layers", type=int, default=30, help="debug only: fewer layers makes the number INVALID")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: QKV / FFN GEMMs on fp8 MFMA; a SEPARATE line (dtype fp8), never the headline")
+    ap.add_argument("--sage", action="store_true", help="self-attention on MXFP8 operands (the reference's VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION switch); "
+                    "a SEPARATE line (dtype says so), never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-legs", action="store_true", help="skip the config-1 and VAE-chunk CPU baseline legs (keep the one-block leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -559,6 +570,8 @@ def main():
     model = build_model(cfg, device)
     if args.fp8:
         model.enable_fp8_gemm(True)
+    if args.sage:
+        os.environ["VIDEOX_ATTENTION_TYPE"] = "SAGE_ATTENTION"      # read by the engine at every forward, as the reference's attention() does
     if world > 1:
         cp = os.environ.get("FLEXAM_CFG_PARALLEL")
         model.enable_multi_gpus_inference(cfg_parallel=None if cp is None else cp == "1")
@@ -788,14 +801,14 @@ def main():
         result = {
             "metric": "denoise-steps/sec", "value": steps_per_sec, "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("fp8" if args.fp8 else "bf16") + (" + mxfp8 self-attention" if args.sage else ""), "data": "synthetic",
             "config": {"workload": f"Wan2.2-Fun-5B-FLEXAM DiT denoise step, {args.frames}x{args.height}x{args.width}, "
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
                                    f"random-init bf16 weights, synthetic conditioning "
                                    + (("(BASELINE configs[1])" if args.mask == "motion" else f"(BASELINE configs[3]: foreground_edit, mask '{args.mask}', "
                                        f"{rows_u} distinct per-token timesteps per sample)")
-                                      if (args.frames, args.height, args.width) == (97, 512, 896) and not args.fp8 else
-                                      "(BASELINE configs[4] shape family: " + ("fp8 e4m3 QKV/FFN GEMMs with per-row / per-channel scales, everything else bf16/fp32" if args.fp8 else "bf16")
+                                      if (args.frames, args.height, args.width) == (97, 512, 896) and not args.fp8 and not args.sage else
+                                      "(BASELINE configs[4] shape family: " + ("fp8 e4m3 QKV/FFN GEMMs with per-row / per-channel scales, everything else bf16/fp32" if args.fp8 else "bf16") + (", self-attention on MXFP8 operands (VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION)" if args.sage else "")
                                       + "; not the headline)"),
                        "parallelism": ((f"cfg{eng_cfg} x sp{eng_sp}: one CFG row per rank" + (", no per-block traffic" if eng_sp == 1 else
                                         f", token-chunk sequence parallel inside each half; exchange around self-attention (RCCL): {eng_mode}"))
@@ -864,6 +877,12 @@ def main():
                                   "launch_note": "one self-attention call = ONE attn_fwd_kernel<0, true> launch (the full rounds of work units and, on the same "
                                                  "XCDs behind them, the last partial round with its keys cut in 3) + attn_merge_kernel; launch_ms is the whole "
                                                  "call = its AverageNs in rocprofv3 + the merge"}
+            if args.sage and attn_in_step:               # the dominant kernel of THIS line is the MXFP8 one: priced against the fp8 pipe
+                r = result["roofline"]
+                r.update(kernel="attn8_fwd_kernel<0> (self-attention on MXFP8 operands, csrc/attn_fp8.inc)", peak=PEAK_FP8_TFLOPS,
+                         frac=r["achieved"] / PEAK_FP8_TFLOPS, traffic=None, isolated_launch_ms=None, isolated_frac=None,
+                         isolated_note="not timed alone in this run", launch_note="one call = ONE attn8_fwd_kernel launch + attn_merge_kernel; the "
+                         "attn8_pack_kernel launch in front of it (0.12 ms) is not part of launch_ms")
             result["kernels"] = {k: ({"ms": round(v["sec"] * 1e3, 4), "tflops": round(v["tflops"], 1), "bound": "mfma",
                                       "peak": PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS,
                                       "frac": round(v["tflops"] / (PEAK_FP8_TFLOPS if k.startswith("gemm_fp8") else PEAK_BF16_TFLOPS), 4)} if "flops" in v else

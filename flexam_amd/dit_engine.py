@@ -333,6 +333,13 @@ class DiTEngine:
                                      a8d=torch.empty(m, d, device=dev, dtype=torch.uint8), so=torch.empty(m, device=dev, dtype=F32))
         return self._ws[key]
 
+    def _attn8_buffers(self, nb, lc):
+        """MXFP8 operand buffers of the quantised self-attention (one set per shape, reused by every block)."""
+        key = ("attn8", nb, lc)
+        if getattr(self, "_attn8", (None,))[0] != key:
+            self._attn8 = (key, hip.attn_fp8_buffers(nb, self.nh, lc, self.device))
+        return self._attn8[1]
+
     # ------------------------------------------------------------------ per-step
     def embed_time(self, t_rows: torch.Tensor):
         """t_rows [R] fp32 distinct timesteps -> e [R, d], e0 [R, 6, d] (fp32, FX.py:928-944)."""
@@ -426,6 +433,8 @@ class DiTEngine:
         rpb = lc                                   # used only when row_index is None: row = m // lc = b
 
         nh, hdim = self.nh, self.hd
+        # the reference reads the switch at every attention call (attention_utils.py:195); quantised self-attention on one rank only
+        sage = sp == 1 and os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION"
         q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hdim))
         k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hdim))
         v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hdim))
@@ -472,7 +481,12 @@ class DiTEngine:
                 self._proj(hbuf[:mb], a8sa, i, p, "wqkv", "bqkv", slice(None), qkv[:mb])
                 hip.rmsnorm_rope(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
                                  tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
-                hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
+                if sage:                                   # VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION: MXFP8 operands (csrc/attn_fp8.inc)
+                    bufs = self._attn8_buffers(nb, lc)
+                    hip.attn_fp8_pack(q4[:nb], k4[:nb], v4[:nb], bufs)
+                    hip.attn_fwd_fp8(bufs, lc, out=ao4[:nb])
+                else:
+                    hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
                 hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
                 if nb < B:
                     xr[1].copy_(xr[0])

@@ -342,3 +342,23 @@ def test_5b_width_three_layers_one_forward_at_2912_tokens():
     with torch.no_grad():
         want = O.dit_forward(sd, cfg, **case)
     stats(out, want, "three-layer 5B-width model, L = 2912")
+
+
+def test_5b_width_three_layers_one_forward_with_quantised_self_attention():
+    """VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION (the reference's quantised-attention switch, attention_utils.py:195-203) on the same
+    3-layer 5B-width forward at L = 2912: self-attention on MXFP8 operands, everything else as before.  Tolerance: the variant's own
+    (e4m3 Q.K^T and P.V; measured 4.2e-3 / 66.9 dB here against 67.0 dB with the bf16 kernel: with random-init weights the softmax is near-uniform and the attention branch a small part of the residual stream -- the kernel-level tests carry the format's 5 % figure)."""
+    import os
+    cfg, sd, m = _three_layer_5b(seed=6)
+    case = C.dit_case(cfg, 16, frames=25, h=16, w=28, batch=2, text_lens=(77, 126))
+    dcase = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    base = m(**dcase).float().cpu()
+    os.environ["VIDEOX_ATTENTION_TYPE"] = "SAGE_ATTENTION"
+    try:
+        out = m(**dcase)
+    finally:
+        os.environ.pop("VIDEOX_ATTENTION_TYPE")
+    assert not torch.equal(out.float().cpu(), base)                    # the switch was taken
+    with torch.no_grad():
+        want = O.dit_forward(sd, cfg, **case)
+    stats(out, want, "three-layer 5B-width model, L = 2912, MXFP8 self-attention", rel_max=2.5e-2, psnr_min=38.0)
