@@ -186,7 +186,14 @@ constexpr float RESCALE_THR_LOG2 = 8.0f;
 // PRE: q was multiplied by softmax_scale * log2(e) by its producer, BEFORE its one rounding to bf16 (in the DiT: folded into the
 // RMSNorm weight of q).  The scores then leave the MFMA chain in exp2 units, and with the row reference of the online softmax as
 // the chain's initial accumulator p = exp2(S') needs no FMA per score (16 of ~85 vector operations per 16 MFMAs).
-template <int KIND, bool PRE>
+// FULL (Lk >= 64, no weighted key; the DiT's self-attention): the common path of a half-tile step is ONE basic block apart from the
+// rescale branch -- across block boundaries hipcc sinks MFMAs to the block of their first use, which serialises the pipeline
+// (-0.9 % of a denoise step, profiles/r4ab_*).  To that end: the last tile of a key range that is not a multiple of 64 is the window
+// [Lk - 64, Lk) instead of [64 (T - 1), 64 T) -- every tile is a whole in-bounds 64-row LDS-DMA with the same per-lane offsets, and
+// its keys that the tile before already held are masked instead of keys past the end; the mask exists only in the 1-4 tail tiles
+// of a work unit (branch-free there), the main loop has none; LDS-DMA past the end re-reads the last tile into a free slot; the
+// barrier of tile 0 is kept.
+template <int KIND, bool PRE, bool FULL = false>
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 K tiles][4 V tiles], each a ring
   ATTN_STAMP_DECL();
@@ -271,12 +278,14 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     v_go[i] = (unsigned)(row * p.v_rs * 2 + ch * 16);
   }
   const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
-  auto issue_tile = [&](int t, int parts = 3) {      // parts: 1 = K, 2 = V
-    const unsigned slot = lds0 + (unsigned)((t & (NSLOT - 1)) * KV_TILE_BYTES + wave * 1024);   // wave-uniform; K ring, V ring = + V_RING
+  auto issue_tile = [&](int t, int parts = 3, int tslot = -1) {      // parts: 1 = K, 2 = V; tslot: ring position (default t)
+    const unsigned slot = lds0 + (unsigned)(((tslot < 0 ? t : tslot) & (NSLOT - 1)) * KV_TILE_BYTES + wave * 1024);   // wave-uniform; K ring, V ring = + V_RING
     const int tg = t0 + t;
-    if ((tg + 1) * KVBLK <= p.Lk) {
-      const char* kt = kbase + (size_t)((unsigned)tg * k_step);     // wave-uniform tile bases
-      const char* vt = vbase + (size_t)((unsigned)tg * v_step);
+    if (FULL || (tg + 1) * KVBLK <= p.Lk) {
+      // FULL: the last tile is the window [Lk - 64, Lk) (scalar select, no branch)
+      const unsigned row0 = FULL && tg == tiles_all - 1 ? (unsigned)(p.Lk - KVBLK) : (unsigned)tg * KVBLK;
+      const char* kt = kbase + (size_t)(row0 * (unsigned)(p.k_rs * 2));     // wave-uniform tile bases
+      const char* vt = vbase + (size_t)(row0 * (unsigned)(p.v_rs * 2));
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (parts & 1) lds_dma16_sbase(kt, k_go[i], slot + i * 8192);
@@ -344,7 +353,15 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   bf16x8 kf_pre[4];      // the first four K fragments of the NEXT half tile, read one step ahead (block A starts on the matrix pipe)
   // weight of the LAST key as a score bias (multiplicity N of a key = + log2 N on its score): raw-score units in the non-PRE form
   const float last_bias = PRE ? p.last_key_bias : p.last_key_bias / p.scale_log2e;
+  // FULL: keys of the shifted last tile that the tile before it already held -> -inf.  Branch-free; called in the tail tiles only.
+  const int last_shift = tiles_all * KVBLK - p.Lk;      // 0..63: first valid in-tile position of the global last tile
+  auto mask_shift = [&](int g, f32x16& sacc) {
+    const int lim = (t0 + (g >> 1) == tiles_all - 1 ? last_shift : 0) - 32 * (g & 1) - 4 * h;      // element e is valid iff (e & 3) + 8 (e >> 2) >= lim
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = (e & 3) + 8 * (e >> 2) >= lim ? sacc[e] : -INFINITY;
+  };
   auto mask_half = [&](int g, f32x16& sacc) {      // g: local half index; keys are global
+    if constexpr (FULL) return;
     const int gg = 2 * t0 + g;
     // past the end of the keys, or of this split's range -- or the half tile that holds a weighted last key
     if ((gg + 1) * 32 > p.Lk || g >= 2 * ntiles || (p.last_key_bias != 0.f && (gg + 1) * 32 == p.Lk)) {
@@ -433,7 +450,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       l_run += ps;
     }
   };
-  auto stepA = [&](int g, f32x16& s_cur, f32x16& s_nxt) __attribute__((always_inline)) {
+  auto stepA = [&](int g, f32x16& s_cur, f32x16& s_nxt, auto mask_c) __attribute__((always_inline)) {
+    if constexpr (FULL && decltype(mask_c)::value) mask_shift(g, s_cur);
     mask_half(g, s_cur);             // keys past Lk -> -inf (uniform branch, only taken in the last tile)
     qk_mma(IC<0>{}, kf_pre, s_nxt);
     finish_pending();
@@ -521,10 +539,10 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   // Measured and not kept (profiles/r4e_attn_stagger_and_local_max.txt): waves 4-7 half a step behind their SIMD partners (their
   // barrier in front of part B instead of part A).  As two copies of the loop it does not fit the instruction cache (-10 %), as one
   // copy with two conditional barrier sites -1.4 % alone and +1.1 % on the step.
-  auto tile = [&](int t, auto t4_c) __attribute__((always_inline)) {       // t4 = t mod 4 as a compile-time constant
+  auto tile = [&](int t, auto t4_c, auto mask_c) __attribute__((always_inline)) {       // t4 = t mod 4 as a compile-time constant
     constexpr int t4 = decltype(t4_c)::value;
     auto top = [&](int tt) __attribute__((always_inline)) {
-      if (tt > 0) {
+      if (FULL || tt > 0) {
         // top of 64-key tile tt: tile tt+1 (issued one tile ago) has landed and becomes visible; the slot of tile
         // tt-2 (last read by the PV of its second half) is free again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -534,29 +552,35 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       }
       // K pieces of tile tt+2 now, its V pieces half a tile later: two short bursts of LDS-DMA issue per tile instead
       // of one of four per wave right after the barrier (-1.2...-1.6 % time; placements inside the steps' MFMA blocks were slower)
-      if (tt + 2 < ntiles) issue_tile(tt + 2, 1);
+      if constexpr (FULL) issue_tile(min(tt + 2, ntiles - 1), 1, tt + 2);
+      else if (tt + 2 < ntiles) issue_tile(tt + 2, 1);
     };
     // (every wave with its barrier between parts A and B of the odd step instead: +1.1 % alone, -0.7 % on the step, not additive
     //  with the deferred scores: profiles/r4g_*)
     top(t);
-    stepA(2 * t, s_a, s_b);
+    stepA(2 * t, s_a, s_b, mask_c);
     stepB(IC<2 * t4>{}, s_a, s_b);
-    if (t + 2 < ntiles) issue_tile(t + 2, 2);
-    stepA(2 * t + 1, s_b, s_a);
+    if constexpr (FULL) issue_tile(min(t + 2, ntiles - 1), 2, t + 2);
+    else if (t + 2 < ntiles) issue_tile(t + 2, 2);
+    stepA(2 * t + 1, s_b, s_a, mask_c);
     stepB(IC<2 * t4 + 1>{}, s_b, s_a);
   };
   ATTN_STAMP_BEGIN();
+  using MaskOn = std::integral_constant<bool, true>;
+  using MaskOff = std::integral_constant<bool, false>;
   int t = 0;
-  for (; t + 4 <= ntiles; t += 4) {
-    tile(t, IC<0>{});
-    tile(t + 1, IC<1>{});
-    tile(t + 2, IC<2>{});
-    tile(t + 3, IC<3>{});
+  // FULL: the main loop leaves 1..4 tail tiles (the only ones that may hold the shifted last tile); otherwise 0..3
+  for (; t + 4 <= ntiles - (FULL ? 1 : 0); t += 4) {
+    tile(t, IC<0>{}, MaskOff{});
+    tile(t + 1, IC<1>{}, MaskOff{});
+    tile(t + 2, IC<2>{}, MaskOff{});
+    tile(t + 3, IC<3>{}, MaskOff{});
   }
-  const int rem = ntiles - t;               // 0..3 tail tiles, same code with static slots
-  if (rem > 0) tile(t, IC<0>{});
-  if (rem > 1) tile(t + 1, IC<1>{});
-  if (rem > 2) tile(t + 2, IC<2>{});
+  const int rem = ntiles - t;               // tail tiles, same code with static slots
+  if (rem > 0) tile(t, IC<0>{}, MaskOn{});
+  if (rem > 1) tile(t + 1, IC<1>{}, MaskOn{});
+  if (rem > 2) tile(t + 2, IC<2>{}, MaskOn{});
+  if (rem > 3) tile(t + 3, IC<3>{}, MaskOn{});
   // pending PV of the last half (2*ntiles - 1): its slot is (ntiles - 1) & 3
   finish_pending();
   switch ((ntiles - 1) & 3) {
@@ -681,7 +705,6 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
   auto kern = cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
                     : (p.prescaled ? attn_fwd_kernel<0, true> : attn_fwd_kernel<0, false>);
-  if (q8) kern = attn8_fwd_kernel<0>;
   bool body16 = false;
 #ifdef FLEXAM_ATTN_BODY16                              // diagnostic builds only (attn_body16.inc): the 16x16x32 body, selected per call
   const char* be = getenv("FLEXAM_ATTN_BODY");
@@ -689,8 +712,12 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   if (body16) kern = cross ? (p.prescaled ? attn_fwd16_kernel<1, true> : attn_fwd16_kernel<1, false>)
                            : (p.prescaled ? attn_fwd16_kernel<0, true> : attn_fwd16_kernel<0, false>);
 #endif
-  static bool attr_set[FLEXAM_MAX_DEVICES][9] = {};      // per device and kernel instance
-  const int which = q8 ? 8 : (cross ? 1 : 0) + (p.prescaled ? 2 : 0) + (body16 ? 4 : 0);
+  const char* fe_ = getenv("FLEXAM_ATTN_FULL");        // read per call (A/B in one process); 0 = the general instance
+  const bool full = !q8 && !cross && p.prescaled && Lk >= KVBLK && last_key_bias == 0.f && !body16 && !(fe_ && atoi(fe_) == 0);
+  if (full) kern = attn_fwd_kernel<0, true, true>;
+  if (q8) kern = attn8_fwd_kernel<0>;
+  static bool attr_set[FLEXAM_MAX_DEVICES][10] = {};      // per device and kernel instance
+  const int which = q8 ? 8 : full ? 9 : (cross ? 1 : 0) + (p.prescaled ? 2 : 0) + (body16 ? 4 : 0);
   const int dev = flexam_current_device();
   if (!attr_set[dev][which]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)

@@ -656,3 +656,33 @@ def test_attention_weighted_last_key_equals_explicit_copies(H, lk, mult, prescal
     if not prescaled:
         want = O.attention(q.float(), k_full.float(), v_full.float())
         assert_bf16_close(got, want, ulps=4.0, atol=4e-3, msg="lastkey vs oracle")
+
+
+@pytest.mark.parametrize("b,h,l,splits", [(1, 2, 1088, None), (1, 2, 1111, None), (2, 1, 1025, None), (1, 1, 2055, (4, 0)), (1, 2, 1500, (3, 7)),
+                                          (1, 1, 1344, (21, 0))])
+def test_attention_one_block_step_instance_equals_the_general_instance(H, b, h, l, splits):
+    """The instance the DiT's self-attention runs (pre-scaled q, Lk > 1024, no weighted key): no key mask in the main loop, a key
+    count that is not a multiple of 64 handled by SHIFTING the last tile to the window [Lk - 64, Lk) and masking the keys the tile
+    before already held.  The arithmetic per key is the general instance's (FLEXAM_ATTN_FULL=0), so whole multiples of 64 agree bit
+    for bit; a ragged count changes the tile a key sits in, i.e. the summation order: compared with the oracle and, loosely, with
+    the general instance.  Split key ranges (the shifted tile in the last range only; one tile per range at 21 ranges) included."""
+    import os
+    g = torch.Generator().manual_seed(l + b)
+    c = 128 ** -0.5 * 1.4426950408889634
+    qf = torch.randn(b, l, h, 128, generator=g)
+    k = torch.randn(b, l, h, 128, generator=g)
+    v = torch.randn(b, l, h, 128, generator=g)
+    k[0, l - 3, 0] = qf[0, 5, 0] * 4.0                  # a spike inside the shifted tile: the reference moves there
+    qs, k, v = bf(qf * c), bf(k), bf(v)
+    kw = {} if splits is None else dict(kv_splits=splits[0], split_from_unit=splits[1])
+    out = H.attn_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), prescaled=True, **kw)
+    os.environ["FLEXAM_ATTN_FULL"] = "0"
+    try:
+        gen = H.attn_fwd(qs.to(dev()), k.to(dev()), v.to(dev()), prescaled=True, **kw)
+    finally:
+        os.environ.pop("FLEXAM_ATTN_FULL")
+    assert_bf16_close(out, _attn_ref(qs.float() / c, k, v), ulps=2.0, atol=6e-3, msg="attention, one-block-step instance")
+    if l % 64 == 0:
+        assert torch.equal(out, gen)
+    else:
+        torch.testing.assert_close(out.float(), gen.float(), rtol=2.0 ** -6, atol=6e-3)
