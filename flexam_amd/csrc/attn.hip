@@ -155,7 +155,7 @@ __device__ __forceinline__ float pair_sum(float x) {
 //  Q in the accumulator file and spills 150+ VGPRs; see DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
 #ifndef A32_DEFER
-#define A32_DEFER 4      // scores of a half tile whose exp2 / sum / pack wait for part A of the next step (see stepA); 0 = none
+#define A32_DEFER 0      // scores of a half tile whose exp2 / sum / pack wait for part A of the next step (see stepA); 0 = none
 #endif
 #ifdef FLEXAM_ATTN_STAMPS      // diagnostic builds only (MI355X_MICROARCH.md, DVFS give-back item 6): the in-kernel clock of the main loop
 __device__ unsigned long long g_attn_stamps[2 * 8192];      // per workgroup: shader cycles and 100 MHz ticks across the tile loop; read by nobody on the device
@@ -433,7 +433,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   // dependent chain of 9 maxima only -- instead of in part B beside 12 MFMAs, 16 exp2, 16 adds and 8 packs: P(g) is not needed
   // before PV(g) in part B of step g+1.  They wait in s_pend in the units of the reference of their own step; finish_pending runs
   // BEFORE the next step's rescale decision, so a rescale finds them where it expects them: in l_run and in the packed pf_prev.
-  // 4 of 16: +0.8 ... 1.0 % alone, -0.6 ... -0.9 % on the step; 6: about the same; 2 and 8: nothing (profiles/r4g_*).
+  // With a key-mask branch in every step (r4g) 4 of 16 paid (-0.6 ... -0.9 % of a step); since the step is one basic block (FULL) none
+  // is best: 0 / 1 / 2 / 4 / 6 / 8 deferred = -0.3 ... -0.8 / +0.3 / -0.4 / 0 / +0.7 / +0.5 % (profiles/r4ab_*).  Default 0.
   constexpr int DEF = PRE ? A32_DEFER : 0;
   float s_pend[DEF > 0 ? DEF : 1];
 #pragma unroll
@@ -532,7 +533,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < 12; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+#ifdef A32_VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, A32_VALU, 0);
+#else
       __builtin_amdgcn_sched_group_barrier(0x002, PRE ? (DEF >= 4 ? 3 : 4) : 5, 0);   // VALU (exp2 / fma / add / cvt)
+#endif
     }
   };
 
