@@ -97,3 +97,56 @@ def test_attention_seam_takes_the_reference_switch(H):
         assert torch.equal(attention(q, k, v, attention_type="SAGE_ATTENTION"), want)
     cross = attention(q, k[:, :77], v[:, :77], attention_type="SAGE_ATTENTION")      # Lq != Lk: the bf16 kernel
     assert torch.equal(cross, attention(q, k[:, :77], v[:, :77]))
+
+
+def _mx_quant(x32):
+    """OCP MX block quantisation as the pack kernel does it: x32 [..., 32] fp32 -> (e4m3 bytes [..., 32] uint8, E8M0 byte [...] uint8),
+    scale = the smallest power of two with amax / scale <= 448."""
+    amax = x32.abs().amax(dim=-1)
+    t = (amax / 448.0).float()
+    bits = t.view(torch.int32)
+    e = ((bits >> 23) & 255) + ((bits & 0x7FFFFF) != 0).int()
+    e = e.clamp(1, 253)
+    inv = ((254 - e) << 23).view(torch.float32)
+    q = (x32 * inv.unsqueeze(-1)).to(torch.float8_e4m3fn).view(torch.uint8)
+    return q, e.to(torch.uint8)
+
+
+def test_pack_kernel_bytes_scales_and_layouts_exactly(H):
+    """flexam_attn_fp8_pack against a torch restatement, byte for byte: e4m3 rounding and E8M0 scales of Q and K per 32 channels, of V
+    per channel and 32-key half tile; the Q rows, the swizzled K image, the transposed V image in the key order the P.V operand needs
+    (byte j of lane half h = key 32 (j / 16) + 8 ((j % 16) / 4) + 4 h + j % 4), zero rows past L."""
+    B, Hh, L = 1, 2, 150                       # 3 tiles, the last one ragged (22 keys)
+    q, k, v = _inputs(B, Hh, L, 5)
+    k[0, 7, 1, 40:48] *= 37.0                  # an outlier block
+    q8, qs, kv8 = H.attn_fp8_pack(q, k, v)
+    q8, qs, kv8 = q8.cpu(), qs.cpu(), kv8.cpu()
+    Lp, T = 256, 3
+    pad = lambda t: torch.cat([t.float().cpu(), torch.zeros(B, T * 64 - L, Hh, 128)], dim=1)      # [B, 192, H, 128]
+    qf, kf, vf = pad(q), pad(k), pad(v)
+    # Q: [B][H][Lp][128] bytes, scales as 4 bytes per row
+    wq, sq = _mx_quant(qf.permute(0, 2, 1, 3).reshape(B, Hh, T * 64, 4, 32))
+    assert torch.equal(q8[:, :, :T * 64].reshape(B, Hh, T * 64, 4, 32), wq)
+    assert torch.equal(qs.view(torch.uint8).reshape(B, Hh, Lp, 4)[:, :, :T * 64], sq)
+    assert int(q8[:, :, T * 64:].abs().max()) == 0
+    # K image: row `r` of a tile, 16-byte chunk c at position c ^ ((r >> 1) & 7); scales at 16384 + 4 r + block
+    wk, sk = _mx_quant(kf.permute(0, 2, 1, 3).reshape(B, Hh, T, 64, 4, 32))
+    wk = wk.reshape(B, Hh, T, 64, 8, 16)
+    rec = kv8.reshape(B, Hh, T, -1)
+    for r in range(64):
+        for c in range(8):
+            pos = c ^ ((r >> 1) & 7)
+            assert torch.equal(rec[..., r * 128 + 16 * pos: r * 128 + 16 * pos + 16], wk[:, :, :, r, c]), (r, c)
+    assert torch.equal(rec[..., 16384:16384 + 256].reshape(B, Hh, T, 64, 4), sk)
+    # V^T image: row d, chunk (2 b + h) at position (2 b + h) ^ ((d >> 2) & 3), byte e = key 32 b + (e & 3) + 8 (e >> 2) + 4 h
+    vt = vf.permute(0, 2, 1, 3).reshape(B, Hh, T, 64, 128)                   # [.., key, d]
+    keys = torch.tensor([[32 * b + (e & 3) + 8 * (e >> 2) + 4 * h for h in range(2) for e in range(16)] for b in range(2)])    # [b][16 h + e]
+    blocks = vt[:, :, :, keys, :].permute(0, 1, 2, 5, 3, 4)                  # [B, H, T, d, b, 32]
+    wv, sv = _mx_quant(blocks)
+    for d in range(128):
+        for b in range(2):
+            for h in range(2):
+                pos = (2 * b + h) ^ ((d >> 2) & 3)
+                got = rec[..., 8192 + d * 64 + 16 * pos: 8192 + d * 64 + 16 * pos + 16]
+                assert torch.equal(got, wv[:, :, :, d, b, 16 * h:16 * h + 16]), (d, b, h)
+    assert torch.equal(rec[..., 16640:16640 + 256].reshape(B, Hh, T, 128, 2), sv)
