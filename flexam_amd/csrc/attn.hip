@@ -417,6 +417,22 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   qk_part(IC<0>{}, IC<0>{}, s_a);
   qk_part(IC<0>{}, IC<4>{}, s_a);
   qk_read(IC<1>{}, IC<0>{}, kf_pre);
+  constexpr bool FIRST_IN_PROLOGUE = PRE && FULL;
+  if constexpr (FIRST_IN_PROLOGUE) {
+    // the first reference = the row maximum of half tile 0, set HERE: as a `g == 0` case of the step's rescale test it costs a scalar
+    // test and ~50 register copies (phi nodes of the loop-carried state) per loop iteration on the common path.  (FULL only: the
+    // general instance has no register to spare for it.)
+    float mx = s_a[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s_a[e]);
+    mx = pair_max(mx);
+    ref = mx;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s_a[e] -= mx;
+      negref[e] = -mx;
+    }
+  }
 #pragma unroll
   for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
@@ -464,10 +480,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     if constexpr (PRE) {
       // ---- deferred rescale (always taken for half 0, which sets the reference to the first row maximum): O, l, the pending
       // P(g-1), the scores of this half and the already started chain of the next half all move to the new reference
-      if (g == 0 || __any(mloc > RESCALE_THR_LOG2)) {            // relative to ref
+      const bool first = !FIRST_IN_PROLOGUE && g == 0;       // FULL: the first reference is set in the prologue
+      if (first || __any(mloc > RESCALE_THR_LOG2)) {            // relative to ref
         const float mx = pair_max(mloc);
-        const float delta = g == 0 ? mx : fmaxf(mx, 0.f);
-        const float alpha = g == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+        const float delta = first ? mx : fmaxf(mx, 0.f);
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
         ref += delta;
         l_run *= alpha;
 #pragma unroll

@@ -663,9 +663,7 @@ def test_attention_weighted_last_key_equals_explicit_copies(H, lk, mult, prescal
 def test_attention_one_block_step_instance_equals_the_general_instance(H, b, h, l, splits):
     """The instance the DiT's self-attention runs (pre-scaled q, Lk > 1024, no weighted key): no key mask in the main loop, a key
     count that is not a multiple of 64 handled by SHIFTING the last tile to the window [Lk - 64, Lk) and masking the keys the tile
-    before already held.  The arithmetic per key is the general instance's (FLEXAM_ATTN_FULL=0), so whole multiples of 64 agree bit
-    for bit; a ragged count changes the tile a key sits in, i.e. the summation order: compared with the oracle and, loosely, with
-    the general instance.  Split key ranges (the shifted tile in the last range only; one tile per range at 21 ranges) included."""
+    before already held.  Compared with the oracle and, at bf16 precision, with the general instance (FLEXAM_ATTN_FULL=0).  Split key ranges (the shifted tile in the last range only; one tile per range at 21 ranges) included."""
     import os
     g = torch.Generator().manual_seed(l + b)
     c = 128 ** -0.5 * 1.4426950408889634
@@ -682,7 +680,6 @@ def test_attention_one_block_step_instance_equals_the_general_instance(H, b, h, 
     finally:
         os.environ.pop("FLEXAM_ATTN_FULL")
     assert_bf16_close(out, _attn_ref(qs.float() / c, k, v), ulps=2.0, atol=6e-3, msg="attention, one-block-step instance")
-    if l % 64 == 0:
-        assert torch.equal(out, gen)
-    else:
-        torch.testing.assert_close(out.float(), gen.float(), rtol=2.0 ** -6, atol=6e-3)
+    # not bit for bit: the instance sets its first reference in the prologue (the second half tile's chain then starts from -ref
+    # instead of being shifted afterwards), and a ragged count changes the tile a key sits in; bf16-level agreement
+    torch.testing.assert_close(out.float(), gen.float(), rtol=2.0 ** -6, atol=6e-3)

@@ -40,12 +40,17 @@ def main():
     lat = torch.randn(48, 25, 32, 56, device=dev)
     known, mask = torch.randn_like(lat), (torch.arange(25, device=dev) > 0).float().view(25, 1, 1).expand(25, 32, 56).contiguous()
     tok = torch.randn(2, L, 192, device=dev)
+    bufs8 = H.attn_fp8_buffers(B, nh, L, dev)
     KERNELS = {
         "ln_modulate": lambda: H.ln_modulate(x, out=hb, shift=tab[:, 0], scale=tab[:, 1], row_index=rows),
         "ln_affine": lambda: H.ln_modulate(x, out=hb, ln_w=nw, ln_b=nw),
         "gemm_qkv": lambda: H.gemm(hb, wqkv, bq, out=qkv),
         "rmsnorm_rope_qk": lambda: H.rmsnorm_rope(qkv[:, 0:d], nw, qkv[:, d:2 * d], nw, rope_cos=cos, rope_sin=sin, tokens_per_batch=L, head_dim=128),
         "attn_self": lambda: H.attn_fwd(q4, k4, v4, out=ao.view(B, L, nh, 128), prescaled=True),
+        "attn_self_general": lambda: (os.environ.__setitem__("FLEXAM_ATTN_FULL", "0"), H.attn_fwd(q4, k4, v4, out=ao.view(B, L, nh, 128), prescaled=True),
+                                      os.environ.pop("FLEXAM_ATTN_FULL")),
+        "attn_mxfp8_pack": lambda: H.attn_fp8_pack(q4, k4, v4, bufs8),
+        "attn_mxfp8": lambda: H.attn_fwd_fp8(bufs8, L, out=ao.view(B, L, nh, 128)),
         "gemm_oproj_residual": lambda: H.gemm_gate_residual(ao, wo, bo, x, gate=tab[:, 2], gate_row=rows),
         "gemm_crossq": lambda: H.gemm(hb, wo, bo, out=qkv[:, 0:d]),
         "rmsnorm_q": lambda: H.rmsnorm_rope(qkv[:, 0:d], nw),
