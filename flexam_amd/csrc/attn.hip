@@ -723,7 +723,7 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.lq_pad = p.q_blocks * QBLK;
   FX_REQUIRE(q8 || (int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
-  const int smem = q8 ? NSLOT * REC_BYTES + 8 * 4096 : NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB (fp8: 4 records, 68 KiB)
+  const int smem = q8 ? NSLOT * REC_BYTES : NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB (fp8: 4 records, 68 KiB)
   const bool cross = Lk <= 1024;        // separate symbol for the short-context (text) launches
   auto kern = cross ? (p.prescaled ? attn_fwd_kernel<1, true> : attn_fwd_kernel<1, false>)
                     : (p.prescaled ? attn_fwd_kernel<0, true> : attn_fwd_kernel<0, false>);
