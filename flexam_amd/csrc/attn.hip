@@ -817,7 +817,7 @@ extern "C" int flexam_attn_fwd_partial(const void* q, int64_t q_bs, int64_t q_rs
 extern "C" int flexam_attn_fp8_pack(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                                     int64_t v_bs, int64_t v_rs, void* q8, void* qs, void* kv8, int B, int H, int L, int head_dim,
                                     void* stream) {
-  FX_REQUIRE(q && k && v && q8 && qs && kv8, FLEXAM_E_ARG, "attn_fp8_pack: null pointer");
+  FX_REQUIRE(v && q8 && qs && kv8 && ((q == nullptr) == (k == nullptr)), FLEXAM_E_ARG, "attn_fp8_pack: null pointer (q and k: both or neither)");
   FX_REQUIRE(head_dim == HD && B > 0 && H > 0 && L > 0, FLEXAM_E_SHAPE, "attn_fp8_pack: bad sizes (head_dim 128 only)");
   FX_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0, FLEXAM_E_SHAPE,
              "attn_fp8_pack: strides must keep 16-byte alignment of head rows");
@@ -830,6 +830,22 @@ extern "C" int flexam_attn_fp8_pack(const void* q, int64_t q_bs, int64_t q_rs, c
   a.H = H; a.L = L; a.lq_pad = (L + QBLK - 1) / QBLK * QBLK; a.tiles = (L + KVBLK - 1) / KVBLK;
   hipLaunchKernelGGL(attn8_pack_kernel, dim3(a.lq_pad / KVBLK, H, B), dim3(256), 0, (hipStream_t)stream, a);
   return flexam_check_launch("flexam_attn_fp8_pack");
+}
+
+extern "C" int flexam_rmsnorm_rope_mx(const void* q, int64_t ldq, const float* wq, const void* k, int64_t ldk, const float* wk, void* q8,
+                                      void* qs, void* kv8, int64_t M, int C, float eps, const float* rope_cos, const float* rope_sin,
+                                      int64_t tokens_per_batch, int64_t token_offset, int H, int head_dim, void* stream) {
+  FX_REQUIRE(q && k && wq && wk && q8 && qs && kv8 && rope_cos && rope_sin, FLEXAM_E_ARG, "rmsnorm_rope_mx: null pointer");
+  FX_REQUIRE(head_dim == HD && H == 24 && C == H * HD, FLEXAM_E_SHAPE, "rmsnorm_rope_mx: 24 heads of 128 channels only (C = %d, H = %d)", C, H);
+  FX_REQUIRE(M > 0 && tokens_per_batch > 0 && M % tokens_per_batch == 0 && ldq % 8 == 0 && ldk % 8 == 0, FLEXAM_E_SHAPE, "rmsnorm_rope_mx: bad sizes");
+  FX_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)q8 | (uintptr_t)qs | (uintptr_t)kv8) % 16 == 0, FLEXAM_E_ARG, "rmsnorm_rope_mx: misaligned pointer");
+  RmsRopeMx a;
+  a.q = (const bf16*)q; a.k = (const bf16*)k; a.ldq = ldq; a.ldk = ldk; a.wq = wq; a.wk = wk; a.cs = rope_cos; a.sn = rope_sin;
+  a.q8 = (unsigned char*)q8; a.qs = (unsigned char*)qs; a.kv8 = (unsigned char*)kv8;
+  a.tokens_per_batch = tokens_per_batch; a.token_offset = token_offset; a.H = H; a.L = (int)tokens_per_batch;
+  a.lq_pad = (a.L + QBLK - 1) / QBLK * QBLK; a.tiles = (a.L + KVBLK - 1) / KVBLK; a.eps = eps;
+  hipLaunchKernelGGL(rmsnorm_rope_mx_kernel, dim3((unsigned)M, 2), dim3(128), 0, (hipStream_t)stream, a);
+  return flexam_check_launch("flexam_rmsnorm_rope_mx");
 }
 
 extern "C" int flexam_attn_fwd_fp8(const void* q8, const void* qs, const void* kv8, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int L,

@@ -479,14 +479,20 @@ class DiTEngine:
             else:
                 a8sa = fp8_here and (a8[:mb], sa[:mb])
                 self._proj(hbuf[:mb], a8sa, i, p, "wqkv", "bqkv", slice(None), qkv[:mb])
-                hip.rmsnorm_rope(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
-                                 tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
-                if sage:                                   # VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION: MXFP8 operands (csrc/attn_fp8.inc)
-                    bufs = self._attn8_buffers(nb, lc)
-                    hip.attn_fp8_pack(q4[:nb], k4[:nb], v4[:nb], bufs)
+                if sage and nh == 24 and hdim == 128 and os.environ.get("FLEXAM_SAGE_FUSED", "1") != "0":   # SAGE_ATTENTION: MXFP8 operands (csrc/attn_fp8.inc);
+                    bufs = self._attn8_buffers(nb, lc)     # RMSNorm + RoPE write Q and K as operands directly, V is packed on its own
+                    hip.rmsnorm_rope_mx(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], bufs, cd["cos"], cd["sin"], lc, tok0, eps=self.eps)
+                    hip.attn_fp8_pack(None, None, v4[:nb], bufs)
                     hip.attn_fwd_fp8(bufs, lc, out=ao4[:nb])
                 else:
-                    hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
+                    hip.rmsnorm_rope(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                                     tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
+                    if sage:
+                        bufs = self._attn8_buffers(nb, lc)
+                        hip.attn_fp8_pack(q4[:nb], k4[:nb], v4[:nb], bufs)
+                        hip.attn_fwd_fp8(bufs, lc, out=ao4[:nb])
+                    else:
+                        hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
                 hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
                 if nb < B:
                     xr[1].copy_(xr[0])

@@ -35,6 +35,7 @@ _SIGNATURES = {
     "flexam_attn_fwd_partial": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _P], c_int),
     "flexam_attn_merge": ([_P, _L, _L, _I, _I, _I, _I, _F, _I, _P, _P, _P], c_int),
     "flexam_attn_fp8_pack": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P], c_int),
+    "flexam_rmsnorm_rope_mx": ([_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P, _P, _L, _L, _I, _I, _P], c_int),
     "flexam_attn_fwd_fp8": ([_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
     "flexam_ln_modulate_fp8": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _F, _F, _P], c_int),
@@ -390,24 +391,38 @@ ATTN8_REC_BYTES = 18432
 def attn_fp8_buffers(B, H, L, device):
     """(q8, qs, kv8) for attn_fp8_pack / attn_fwd_fp8 at this shape (see flexam_hip.h)."""
     lp, tiles = -(-L // 256) * 256, -(-L // 64)
-    return (torch.empty(B, H, lp, 128, device=device, dtype=torch.uint8), torch.empty(B, H, lp, device=device, dtype=torch.int32),
-            torch.empty(B, H, tiles, ATTN8_REC_BYTES, device=device, dtype=torch.uint8))
+    return (torch.zeros(B, H, lp, 128, device=device, dtype=torch.uint8), torch.zeros(B, H, lp, device=device, dtype=torch.int32),
+            torch.zeros(B, H, tiles, ATTN8_REC_BYTES, device=device, dtype=torch.uint8))      # zeros: rmsnorm_rope_mx never writes the padding rows
 
 
 def attn_fp8_pack(q, k, v, bufs=None):
     """q, k, v [B, L, H, 128] bf16 (q prescaled by softmax_scale * log2 e) -> the MXFP8 operand buffers of attn_fwd_fp8."""
-    B, L, H, D = q.shape
+    B, L, H, D = v.shape
     for t in (q, k, v):
-        if t.stride(3) != 1 or t.stride(2) != D or t.shape != q.shape:
+        if t is not None and (t.stride(3) != 1 or t.stride(2) != D or t.shape != v.shape):
             raise RuntimeError("attn_fp8_pack: q, k, v must be [B, L, H, 128] with packed heads")
+    if (q is None) != (k is None):
+        raise RuntimeError("attn_fp8_pack: q and k go together (both None: V only, after rmsnorm_rope_mx)")
     if bufs is None:
-        bufs = attn_fp8_buffers(B, H, L, q.device)
+        bufs = attn_fp8_buffers(B, H, L, v.device)
     q8, qs, kv8 = bufs
     if q8.shape[:3] != (B, H, -(-L // 256) * 256) or kv8.shape[:3] != (B, H, -(-L // 64)):
         raise RuntimeError("attn_fp8_pack: buffers of another shape")
-    _check(lib().flexam_attn_fp8_pack(_ptr(q, BF16), q.stride(0), q.stride(1), _ptr(k, BF16), k.stride(0), k.stride(1), _ptr(v, BF16),
+    qk = (lambda t: (t.stride(0), t.stride(1))) if q is not None else (lambda t: (0, 0))
+    _check(lib().flexam_attn_fp8_pack(_ptr(q, BF16), *qk(q), _ptr(k, BF16), *qk(k), _ptr(v, BF16),
                                       v.stride(0), v.stride(1), q8.data_ptr(), qs.data_ptr(), kv8.data_ptr(), B, H, L, D, _stream()),
            "flexam_attn_fp8_pack")
+    return bufs
+
+
+def rmsnorm_rope_mx(q, wq, k, wk, bufs, rope_cos, rope_sin, tokens_per_batch, token_offset=0, eps=1e-6, heads=24):
+    """RMSNorm + RoPE of q and k ([M, 3072] bf16 views) written as the MXFP8 operands of attn_fwd_fp8 (Q rows, K image and scales);
+    the V half of `bufs` comes from attn_fp8_pack(None, None, v, bufs)."""
+    M, C, ldq = _rows(q)
+    q8, qs, kv8 = bufs
+    _check(lib().flexam_rmsnorm_rope_mx(_ptr(q, BF16), ldq, _ptr(wq, F32), _ptr(k, BF16), k.stride(0), _ptr(wk, F32), q8.data_ptr(),
+                                        qs.data_ptr(), kv8.data_ptr(), M, C, eps, _ptr(rope_cos, F32), _ptr(rope_sin, F32),
+                                        tokens_per_batch, token_offset, heads, 128, _stream()), "flexam_rmsnorm_rope_mx")
     return bufs
 
 

@@ -147,10 +147,17 @@ int flexam_attn_merge(void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq,
  * flexam_attn_fp8_pack: q, k, v bf16 [B, L, H, 128] as flexam_attn_fwd takes them (q carrying softmax_scale * log2 e, i.e. the
  * FLEXAM_ATTN_PRESCALED form) -> q8 [B][H][Lp][128] e4m3, qs [B][H][Lp] four E8M0 bytes per row, kv8 [B][H][T] records of 18432
  * bytes (K tile image, V^T tile image with the key order the P.V operand needs, their scales), Lp = ceil(L / 256) * 256,
- * T = ceil(L / 64); rows past L are written as zeros.  flexam_attn_fwd_fp8: o [B, L, H, 128] bf16 from those buffers; kv_splits /
+ * T = ceil(L / 64); rows past L are written as zeros; q = k = NULL: only the V half of the records is written.  flexam_attn_fwd_fp8: o [B, L, H, 128] bf16 from those buffers; kv_splits /
  * split_from_unit / ws_o / ws_ml as flexam_attn_fwd_splitkv (kv_splits = 1: no workspace). */
 int flexam_attn_fp8_pack(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v,
                          int64_t v_bs, int64_t v_rs, void* q8, void* qs, void* kv8, int B, int H, int L, int head_dim, void* stream);
+/* The producer of those operands inside the DiT: RMSNorm over the full width + RoPE of q and k (flexam_rmsnorm_rope's arithmetic,
+ * q's weight carrying softmax_scale * log2 e) written as q8 / qs and the K image + K scales of the kv8 records directly, quantised
+ * from fp32; 24 heads of 128 channels; M = B * tokens_per_batch rows.  The buffers' padding rows (past L) must have been zeroed once
+ * (they are never written here); the V half of the records then comes from flexam_attn_fp8_pack with q = k = NULL. */
+int flexam_rmsnorm_rope_mx(const void* q, int64_t ldq, const float* wq, const void* k, int64_t ldk, const float* wk, void* q8, void* qs,
+                           void* kv8, int64_t M, int C, float eps, const float* rope_cos, const float* rope_sin,
+                           int64_t tokens_per_batch, int64_t token_offset, int H, int head_dim, void* stream);
 int flexam_attn_fwd_fp8(const void* q8, const void* qs, const void* kv8, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int L,
                         int head_dim, int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream);
 

@@ -150,3 +150,44 @@ def test_pack_kernel_bytes_scales_and_layouts_exactly(H):
                 got = rec[..., 8192 + d * 64 + 16 * pos: 8192 + d * 64 + 16 * pos + 16]
                 assert torch.equal(got, wv[:, :, :, d, b, 16 * h:16 * h + 16]), (d, b, h)
     assert torch.equal(rec[..., 16640:16640 + 256].reshape(B, Hh, T, 128, 2), sv)
+
+
+def test_fused_rmsnorm_rope_writes_the_same_operands_as_the_two_step_path(H):
+    """flexam_rmsnorm_rope_mx (RMSNorm + RoPE written as MXFP8 Q rows / K image directly, quantised from fp32) against
+    flexam_rmsnorm_rope + flexam_attn_fp8_pack (quantised from the bf16 intermediate): same scale bytes except where bf16's rounding
+    moves a block maximum across a power of two, values within one e4m3 step -- and the attention that reads them agrees with the
+    two-step path at the format's noise level.  Ragged token count (padding rows stay zero), token offset, two samples."""
+    B, L, nh = 2, 200, 24
+    g = torch.Generator().manual_seed(21)
+    qkv = (torch.randn(B * L, 3 * nh * 128, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    wq = (torch.rand(nh * 128, generator=g) * 0.2 + 0.05).cuda()
+    wk = (torch.rand(nh * 128, generator=g) + 0.5).cuda()
+    ang = torch.rand(L + 5, 64, generator=g) * 6.28
+    cos, sin = ang.cos().cuda(), ang.sin().cuda()
+    d = nh * 128
+    q2, k2 = qkv[:, 0:d].clone(), qkv[:, d:2 * d].clone()
+    H.rmsnorm_rope(q2, wq, k2, wk, rope_cos=cos, rope_sin=sin, tokens_per_batch=L, token_offset=5, head_dim=128)
+    v4 = qkv.view(B, L, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, 128))
+    two = H.attn_fp8_pack(q2.view(B, L, nh, 128), k2.view(B, L, nh, 128), v4)
+    one = H.attn_fp8_buffers(B, nh, L, qkv.device)
+    H.rmsnorm_rope_mx(qkv[:, 0:d], wq, qkv[:, d:2 * d], wk, one, cos, sin, L, 5)
+    H.attn_fp8_pack(None, None, v4, one)
+    # scale bytes of the valid rows: equal or one apart (padding rows: the pack kernel writes scale byte 1 for its zero rows, the
+    # fused kernel leaves the zero the buffers are created with); the V half identical
+    qa, qb = one[1].view(torch.uint8).reshape(B, nh, 256, 4)[:, :, :L], two[1].view(torch.uint8).reshape(B, nh, 256, 4)[:, :, :L]
+    diff = (qa.int() - qb.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff != 0).float().mean()) < 0.02
+    ra, rb = one[2].reshape(B, nh, 4, -1), two[2].reshape(B, nh, 4, -1)
+    assert torch.equal(ra[..., 8192:16384], rb[..., 8192:16384]) and torch.equal(ra[..., 16640:16896], rb[..., 16640:16896])      # V image, V scales
+    ka, kb = ra[..., 16384:16640].reshape(B, nh, 256, 4)[:, :, :L], rb[..., 16384:16640].reshape(B, nh, 256, 4)[:, :, :L]
+    kd = (ka.int() - kb.int()).abs()
+    assert int(kd.max()) <= 1 and float((kd != 0).float().mean()) < 0.02
+    same = (ra[:, :, :3, :8192] == rb[:, :, :3, :8192]).float().mean()
+    assert float(same) > 0.9                       # K bytes: identical except where the bf16 intermediate rounded differently
+    assert int(one[0][:, :, L:].abs().max()) == 0 and int(ra[:, :, 3, 8 * 128:64 * 128].abs().max()) == 0      # padding rows untouched (zero)
+    o1 = H.attn_fwd_fp8(one, L).float()
+    o2 = H.attn_fwd_fp8(two, L).float()
+    ref = H.attn_fwd(q2.view(B, L, nh, 128), k2.view(B, L, nh, 128), v4, prescaled=True).float()
+    r1, r2 = float((o1 - ref).norm() / ref.norm()), float((o2 - ref).norm() / ref.norm())
+    print("fused", r1, "two-step", r2)
+    assert r1 <= 1.15 * r2 + 5e-3
