@@ -860,7 +860,7 @@ def main():
             if world == 1 and (args.frames, args.height, args.width) == (97, 512, 896) and os.path.exists(tpath):
                 traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             sec_live = attn_in_step["sec"] if attn_in_step else a["sec"]
-            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0, true> (self-attention, head_dim 128, q pre-scaled by its RMSNorm weight)",
+            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<0, true, true> (self-attention, head_dim 128, q pre-scaled by its RMSNorm weight; the one-basic-block-step instance)",
                                   "achieved": a["flops"] / sec_live / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": a["flops"] / sec_live / 1e12 / PEAK_BF16_TFLOPS,
                                   "traffic": traffic,
                                   "traffic_note": "bytes/launch, rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over the launches of one call (" + os.path.basename(tpath) + ")",
@@ -874,7 +874,7 @@ def main():
                                                               "compare with the kernel's AverageNs in rocprofv3 --kernel-trace --stats of `bench.py --no-kernel-timing`",
                                   "isolated_launch_ms": a["sec"] * 1e3, "isolated_frac": a["tflops"] / PEAK_BF16_TFLOPS,
                                   "isolated_note": "8 back-to-back launches on the step's own buffers: runs at the clock the kernel holds alone, not the step's",
-                                  "launch_note": "one self-attention call = ONE attn_fwd_kernel<0, true> launch (the full rounds of work units and, on the same "
+                                  "launch_note": "one self-attention call = ONE attn_fwd_kernel<0, true, true> launch (the full rounds of work units and, on the same "
                                                  "XCDs behind them, the last partial round with its keys cut in 3) + attn_merge_kernel; launch_ms is the whole "
                                                  "call = its AverageNs in rocprofv3 + the merge"}
             if args.sage and attn_in_step:               # the dominant kernel of THIS line is the MXFP8 one: priced against the fp8 pipe
@@ -889,7 +889,7 @@ def main():
                                      {"ms": round(v["sec"] * 1e3, 4), "gbs": round(v["bytes"] / v["sec"] / 1e9, 1), "bound": "hbm",
                                       "frac": round(v["bytes"] / v["sec"] / 1e9 / PEAK_HBM_GBS, 4)}) for k, v in kern.items()}
             result["kernels_note"] = ("live per-launch timing at this run's shapes; mfma rows: algorithmic FLOPs / 2.5 PFLOP/s, hbm rows: "
-                                      "algorithmic bytes (SURVEY 8d) / 8 TB/s; counter-side traffic and MFMA-busy: profiles/r4*_block_kernels_pmc.txt")
+                                      "algorithmic bytes (SURVEY 8d) / 8 TB/s; counter-side traffic and MFMA-busy: profiles/r4ae_block_kernels_pmc.txt")
         if base is not None:
             result["cpu_baseline"] = base
         print(json.dumps(result))
