@@ -525,6 +525,8 @@ def main():
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: QKV / FFN GEMMs on fp8 MFMA; a SEPARATE line (dtype fp8), never the headline")
     ap.add_argument("--sage", action="store_true", help="self-attention on MXFP8 operands (the reference's VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION switch); "
                     "a SEPARATE line (dtype says so), never the headline")
+    ap.add_argument("--fp8-oproj", action="store_true", help="with --fp8: the two output projections of a block on the fp8 pipe as well (FLEXAM_FP8_OPROJ=1; "
+                    "beyond configs[4]'s 'QKV/FFN', its own line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cpu-legs", action="store_true", help="skip the config-1 and VAE-chunk CPU baseline legs (keep the one-block leg)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -568,6 +570,10 @@ def main():
     from flexam_amd.configs import WAN22_FUN_5B_FLEXAM
     cfg = dict(WAN22_FUN_5B_FLEXAM, num_layers=args.layers)
     model = build_model(cfg, device)
+    if args.fp8_oproj:
+        if not args.fp8:
+            raise SystemExit("--fp8-oproj needs --fp8")
+        os.environ["FLEXAM_FP8_OPROJ"] = "1"                        # read by the engine at every forward
     if args.fp8:
         model.enable_fp8_gemm(True)
     if args.sage:
@@ -801,14 +807,14 @@ def main():
         result = {
             "metric": "denoise-steps/sec", "value": steps_per_sec, "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": ("fp8" if args.fp8 else "bf16") + (" + mxfp8 self-attention" if args.sage else ""), "data": "synthetic",
+            "vs_baseline": None, "dtype": ("fp8" if args.fp8 else "bf16") + (" + mxfp8 self-attention" if args.sage else "") + (" + fp8 output projections" if args.fp8_oproj else ""), "data": "synthetic",
             "config": {"workload": f"Wan2.2-Fun-5B-FLEXAM DiT denoise step, {args.frames}x{args.height}x{args.width}, "
                                    f"L={L} tokens, CFG pair B=2, {cfg['num_layers']} layers, flow-match Euler (50-step schedule), "
                                    f"random-init bf16 weights, synthetic conditioning "
                                    + (("(BASELINE configs[1])" if args.mask == "motion" else f"(BASELINE configs[3]: foreground_edit, mask '{args.mask}', "
                                        f"{rows_u} distinct per-token timesteps per sample)")
                                       if (args.frames, args.height, args.width) == (97, 512, 896) and not args.fp8 and not args.sage else
-                                      "(BASELINE configs[4] shape family: " + ("fp8 e4m3 QKV/FFN GEMMs with per-row / per-channel scales, everything else bf16/fp32" if args.fp8 else "bf16") + (", self-attention on MXFP8 operands (VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION)" if args.sage else "")
+                                      "(BASELINE configs[4] shape family: " + ("fp8 e4m3 QKV/FFN GEMMs with per-row / per-channel scales, everything else bf16/fp32" if args.fp8 else "bf16") + (", self-attention on MXFP8 operands (VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION)" if args.sage else "") + (", o-projections on fp8 too (FLEXAM_FP8_OPROJ=1)" if args.fp8_oproj else "")
                                       + "; not the headline)"),
                        "parallelism": ((f"cfg{eng_cfg} x sp{eng_sp}: one CFG row per rank" + (", no per-block traffic" if eng_sp == 1 else
                                         f", token-chunk sequence parallel inside each half; exchange around self-attention (RCCL): {eng_mode}"))

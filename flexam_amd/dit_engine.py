@@ -184,11 +184,14 @@ class DiTEngine:
         variant"); the reference's own fp8 mode only stores weights in fp8 (FlexAM/utils/fp8_optimization.py:1-57)."""
         if on and not self.fused:
             raise NotImplementedError("fp8 GEMMs run in the engine's fused block path (no replaced / re-bound blocks)")
+        # wo / cwo are quantised too: FLEXAM_FP8_OPROJ=1 (read per forward; an experiment, not part of configs[4]'s "QKV/FFN") runs the
+        # self-attention and cross-attention output projections on the fp8 pipe as well -- the attention output is row-quantised by one
+        # more pass (flexam_quantize_rows_fp8)
         if on and self._fp8_w is None:
             self._fp8_w = []
             for p in self.blocks:
                 q = {}
-                for name in ("wqkv", "cwq", "w1", "w2"):
+                for name in ("wqkv", "cwq", "w1", "w2", "wo", "cwo"):
                     q[name], q["s_" + name] = hip.quantize_rows_fp8(p[name])
                 # bounds for the a-priori scale of FFN1's e4m3 output (flexam_ln_modulate_fp8, next_scale): the largest L2 norm of a
                 # DEQUANTISED w1 row (what the MFMA multiplies) and the largest |bias|; two floats per layer, read back once
@@ -435,6 +438,7 @@ class DiTEngine:
         nh, hdim = self.nh, self.hd
         # the reference reads the switch at every attention call (attention_utils.py:195); quantised self-attention on one rank only
         sage = sp == 1 and os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION"
+        fp8_oproj = self.fp8 and os.environ.get("FLEXAM_FP8_OPROJ", "0") == "1"
         q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hdim))
         k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hdim))
         v4 = qkv.view(B, lc, 3 * d)[:, :, 2 * d:].unflatten(2, (nh, hdim))
@@ -493,7 +497,12 @@ class DiTEngine:
                         hip.attn_fwd_fp8(bufs, lc, out=ao4[:nb])
                     else:
                         hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
-                hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
+                if fp8_here and fp8_oproj:
+                    a8o, sao = hip.quantize_rows_fp8(ao[:mb], ws["a8d"][:mb], ws["sa"][:mb])
+                    hip.gemm_fp8_gate_residual(a8o, sao, self._fp8_w[i]["wo"], self._fp8_w[i]["s_wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri,
+                                               rows_per_batch=rpb)
+                else:
+                    hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
                 if nb < B:
                     xr[1].copy_(xr[0])
             # cross-attention on the text context (K/V precomputed per clip)
@@ -512,7 +521,11 @@ class DiTEngine:
                                      out=ao4, prescaled=True)
             else:
                 hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
-            hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
+            if self.fp8 and fp8_oproj:
+                a8o, sao = hip.quantize_rows_fp8(ao, ws["a8d"], ws["sa"])
+                hip.gemm_fp8_gate_residual(a8o, sao, self._fp8_w[i]["cwo"], self._fp8_w[i]["s_cwo"], p["cbo"], xres)
+            else:
+                hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
             # FFN
             if self.fp8:
                 w8 = self._fp8_w[i]

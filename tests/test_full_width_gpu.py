@@ -290,8 +290,8 @@ def _three_layer_5b(seed=5):
     return cfg, sd, m.to("cuda:0")
 
 
-@pytest.mark.parametrize("fp8", [False, True], ids=["bf16", "fp8"])
-def test_5b_width_three_layers_four_steps_sampler_vs_oracle_loop(fp8):
+@pytest.mark.parametrize("fp8", [False, True, "oproj"], ids=["bf16", "fp8", "fp8_with_o_projections"])
+def test_5b_width_three_layers_four_steps_sampler_vs_oracle_loop(fp8, monkeypatch):
     """The loop the reference runs (PIPE.py:840-949 over FX.py:1053-1089) at the 5B WIDTH with DEPTH and STEPS together: BASELINE
     config 1's latent [1,48,3,16,16] (9x256x256), d = 3072 / 24 heads / ffn 14336, 3 of the 30 layers, 4 Euler steps, CFG pair
     (two prompts on one latent), HIP sampler vs oracle.sampler.denoise_loop over oracle.dit.dit_forward (fp32), every step's
@@ -302,6 +302,8 @@ def test_5b_width_three_layers_four_steps_sampler_vs_oracle_loop(fp8):
     from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
     from oracle import sampler as S
     cfg, sd, m = _three_layer_5b()
+    if fp8 == "oproj":                               # FLEXAM_FP8_OPROJ=1: the two output projections of a block on the fp8 pipe as well (opt-in)
+        monkeypatch.setenv("FLEXAM_FP8_OPROJ", "1")
     if fp8:
         m.enable_fp8_gemm(True)
     pipe = Wan2_2FunControlPipeline_FlexAM(transformer=m)
