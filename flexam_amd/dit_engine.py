@@ -337,11 +337,13 @@ class DiTEngine:
         return self._ws[key]
 
     def _attn8_buffers(self, nb, lc):
-        """MXFP8 operand buffers of the quantised self-attention (one set per shape, reused by every block)."""
-        key = ("attn8", nb, lc)
-        if getattr(self, "_attn8", (None,))[0] != key:
-            self._attn8 = (key, hip.attn_fp8_buffers(nb, self.nh, lc, self.device))
-        return self._attn8[1]
+        """MXFP8 operand buffers of the quantised self-attention (one set per (samples, tokens) shape, reused by every block)."""
+        cache = self.__dict__.setdefault("_attn8", {})
+        if (nb, lc) not in cache:
+            if any(k[1] != lc for k in cache):          # another token count: drop the old sets (as _workspace does)
+                cache.clear()
+            cache[(nb, lc)] = hip.attn_fp8_buffers(nb, self.nh, lc, self.device)      # (block 0 may run one sample: its own set, not a re-allocation per step)
+        return cache[(nb, lc)]
 
     # ------------------------------------------------------------------ per-step
     def embed_time(self, t_rows: torch.Tensor):

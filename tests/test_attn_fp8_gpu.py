@@ -33,7 +33,7 @@ def _inputs(B, Hh, L, seed, sharp=1.0):
     return [t.to(torch.bfloat16).cuda() for t in (q, k, v)]
 
 
-@pytest.mark.parametrize("B,Hh,L,splits", [(1, 1, 64, None), (1, 2, 256, None), (1, 1, 300, None), (2, 3, 1111, None), (1, 2, 1024, (2, 0)),
+@pytest.mark.parametrize("B,Hh,L,splits", [(1, 1, 40, None), (1, 1, 64, None), (1, 2, 256, None), (1, 1, 300, None), (2, 3, 1111, None), (1, 2, 1024, (2, 0)),
                                            (1, 2, 1024, (4, 5)), (1, 1, 2912, None)])
 def test_mxfp8_attention_against_fp32_attention(H, B, Hh, L, splits):
     """Whole and ragged tiles, a main-loop pass plus tail tiles, split key ranges with the merge launch."""
