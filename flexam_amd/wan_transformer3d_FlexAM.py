@@ -193,8 +193,11 @@ class _SelfAttn(_Attn):
         hip.rmsnorm_rope(qkv[:, 0:c], pk["nq"], qkv[:, c:2 * c], pk["nk"], eps=self.eps, rope_cos=cos, rope_sin=sin,
                          tokens_per_batch=l, token_offset=0, head_dim=hd)
         q3 = qkv.view(b, l, 3 * c)
-        ao = hip.attn_fwd(q3[:, :, 0:c].unflatten(2, (nh, hd)), q3[:, :, c:2 * c].unflatten(2, (nh, hd)),
-                          q3[:, :, 2 * c:].unflatten(2, (nh, hd)), prescaled=True)
+        q4, k4, v4 = (q3[:, :, i * c:(i + 1) * c].unflatten(2, (nh, hd)) for i in range(3))
+        if os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION" and not torch.is_grad_enabled() and hd == 128:
+            ao = hip.attn_fwd_fp8(hip.attn_fp8_pack(q4, k4, v4), l)      # the reference's attention() reads the switch per call (ATT.py:195-203)
+        else:
+            ao = hip.attn_fwd(q4, k4, v4, prescaled=True)
         return hip.gemm(ao.view(b * l, c), pk["wo"], pk["bo"]).view(b, l, c)
 
 

@@ -256,3 +256,27 @@ def test_conditioning_rewritten_behind_pytorchs_back_is_seen_unless_identity_is_
     check(out, O.dit_forward(sd, cfg, **case2), "after invalidate_conditioning")
     m.trust_conditioning_identity(False)
     assert m._cond_ident is None
+
+
+def test_block_seam_takes_the_quantised_attention_switch(monkeypatch):
+    """The module-level self-attention seam reads VIDEOX_ATTENTION_TYPE per call like the reference's attention() (ATT.py:195-203):
+    SAGE_ATTENTION -> the MXFP8 kernel (head_dim 128), anything else -> the bf16 kernel.  Block output within the variant's
+    tolerance of the bf16 path (the attention branch is one of three residual contributions)."""
+    from flexam_amd.wan_transformer3d_FlexAM import _Block
+    from flexam_amd.rope import rope_angle_table
+    bc = C.block_case()
+    blk = _Block(bc["dim"], bc["ffn"], bc["heads"], 1e-6)
+    blk.load_state_dict(C.block_weights(bc["dim"], bc["ffn"]), strict=True)
+    blk = blk.cuda()
+    b, l = bc["x"].shape[:2]
+    kw = dict(seq_lens=torch.tensor([l] * b), grid_sizes=torch.tensor([list(bc["grid"])] * b), freqs=rope_angle_table(1024, 128),
+              context=bc["context"].cuda(), context_lens=None)
+    base = blk(bc["x"].cuda(), e=bc["e0"].cuda(), density_emb=bc["dens0"].cuda(), **kw)
+    monkeypatch.setenv("VIDEOX_ATTENTION_TYPE", "SAGE_ATTENTION")
+    got = blk(bc["x"].cuda(), e=bc["e0"].cuda(), density_emb=bc["dens0"].cuda(), **kw)      # (the modules run under no_grad themselves: inference only)
+    assert not torch.equal(got, base)
+    monkeypatch.setenv("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION")
+    assert torch.equal(blk(bc["x"].cuda(), e=bc["e0"].cuda(), density_emb=bc["dens0"].cuda(), **kw), base)
+    rel = float((got - base).norm() / base.norm())
+    print("block output, SAGE vs bf16 attention: rel", rel)
+    assert rel <= 2e-2
