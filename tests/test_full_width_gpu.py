@@ -290,7 +290,7 @@ def _three_layer_5b(seed=5):
     return cfg, sd, m.to("cuda:0")
 
 
-@pytest.mark.parametrize("fp8", [False, True, "oproj"], ids=["bf16", "fp8", "fp8_with_o_projections"])
+@pytest.mark.parametrize("fp8", [False, True, "oproj", "sage"], ids=["bf16", "fp8", "fp8_with_o_projections", "fp8_with_quantised_self_attention"])
 def test_5b_width_three_layers_four_steps_sampler_vs_oracle_loop(fp8, monkeypatch):
     """The loop the reference runs (PIPE.py:840-949 over FX.py:1053-1089) at the 5B WIDTH with DEPTH and STEPS together: BASELINE
     config 1's latent [1,48,3,16,16] (9x256x256), d = 3072 / 24 heads / ffn 14336, 3 of the 30 layers, 4 Euler steps, CFG pair
@@ -304,6 +304,8 @@ def test_5b_width_three_layers_four_steps_sampler_vs_oracle_loop(fp8, monkeypatc
     cfg, sd, m = _three_layer_5b()
     if fp8 == "oproj":                               # FLEXAM_FP8_OPROJ=1: the two output projections of a block on the fp8 pipe as well (opt-in)
         monkeypatch.setenv("FLEXAM_FP8_OPROJ", "1")
+    if fp8 == "sage":                                # + the reference's quantised-attention switch: MXFP8 self-attention (bench.py --fp8 --sage)
+        monkeypatch.setenv("VIDEOX_ATTENTION_TYPE", "SAGE_ATTENTION")
     if fp8:
         m.enable_fp8_gemm(True)
     pipe = Wan2_2FunControlPipeline_FlexAM(transformer=m)
