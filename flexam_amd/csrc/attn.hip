@@ -193,7 +193,11 @@ constexpr float RESCALE_THR_LOG2 = 8.0f;
 // its keys that the tile before already held are masked instead of keys past the end; the mask exists only in the 1-4 tail tiles
 // of a work unit (branch-free there), the main loop has none; LDS-DMA past the end re-reads the last tile into a free slot; the
 // barrier of tile 0 is kept.
-template <int KIND, bool PRE, bool FULL = false>
+// SHORT (at most 4 key tiles, i.e. the text cross-attention): one persistent workgroup per CU walks a contiguous range of work units
+// (q blocks of one (batch, head), then of the next); the K/V tiles of a head stay in the ring while its q blocks last -- one LDS-DMA
+// prologue and barrier per head change instead of per q block, none inside (the tiles are read-only), so the waves run through
+// their rows of the blocks on their own.
+template <int KIND, bool PRE, bool FULL = false, bool SHORT = false>
 __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 K tiles][4 V tiles], each a ring
   ATTN_STAMP_DECL();
@@ -213,7 +217,13 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + local;
   };
   int split = 0, ul, unit, tps = p.tiles_per_split, partial = p.partial;
-  {
+  int unit_end;                              // SHORT: this workgroup walks units [unit, unit_end)
+  if constexpr (SHORT) {
+    const int64_t all = (int64_t)p.B * p.H * p.q_blocks;
+    ul = unit = (int)(all * blockIdx.x / gridDim.x);
+    unit_end = (int)(all * (blockIdx.x + 1) / gridDim.x);
+    if (unit >= unit_end) return;
+  } else {
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int wmax = (p.whole_units + 7) >> 3;
     if (local < wmax) {                              // (whole_units = 0: wmax = 0)
@@ -231,20 +241,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       unit = p.unit0 + ul;
     }
   }
-  const int qb = unit % p.q_blocks;
-  const int bh = unit / p.q_blocks;
-  const int head = bh % p.H, b = bh / p.H;
-
-  const bf16* qbase = p.q + (int64_t)b * p.q_bs + head * HD;
-  const char* kbase = (const char*)(p.k + (int64_t)b * p.k_bs + head * HD);
-  const char* vbase = (const char*)(p.v + (int64_t)b * p.v_bs + head * HD);
-
-  // ---- Q fragment (B operand of S^T = K.Q^T): lane (r, h) holds Q[q0 + r][16*ds + 8h .. +7]
-  const int q0 = qb * QBLK + wave * 32;
-  const int qrow = min(q0 + r, p.Lq - 1);
-  bf16x8 qf[8];
-#pragma unroll
-  for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qbase + (int64_t)qrow * p.q_rs + ds * 16 + h * 8);
+  if constexpr (!SHORT) unit_end = unit + 1;
+  // (batch, head) of the unit being worked on: set at the top of every unit of the walk below
+  int head = 0, b = 0, bh_loaded = -1;
+  const bf16* qbase = nullptr;
+  const char *kbase = nullptr, *vbase = nullptr;
 
   // ---- LDS read offsets (dual-use swizzled image, see kv_off)
   int koff[8];
@@ -313,6 +314,20 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   for (int half = 0; half < 2; ++half)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vaddr[half][dt] = smem + V_RING + voff[half][dt];
+  // ---- the work units of this workgroup (one, unless SHORT)
+  for (int u = unit; u < unit_end; ++u) {
+  const int qbi = u % p.q_blocks, bh = u / p.q_blocks;
+  head = bh % p.H; b = bh / p.H;
+  qbase = p.q + (int64_t)b * p.q_bs + head * HD;
+  kbase = (const char*)(p.k + (int64_t)b * p.k_bs + head * HD);
+  vbase = (const char*)(p.v + (int64_t)b * p.v_bs + head * HD);
+  // ---- Q fragment (B operand of S^T = K.Q^T): lane (r, h) holds Q[q0 + r][16*ds + 8h .. +7]
+  const int q0 = qbi * QBLK + wave * 32;
+  const int qrow = min(q0 + r, p.Lq - 1);
+  bf16x8 qf[8];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) qf[ds] = *(const bf16x8*)(qbase + (int64_t)qrow * p.q_rs + ds * 16 + h * 8);
+
   // PRE: row reference of the online softmax in exp2 units (a lane holds 32 scores of ONE query row, so it is one value per lane,
   // kept 16 times as the C operand that starts every S^T chain).  It is NOT the running maximum: it is only raised when a score
   // exceeds it by more than 2^THR (deferred rescale).
@@ -407,11 +422,22 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   const float c = p.scale_log2e;
 
   // ---- prologue: tiles 0 and 1 on their way, S(half 0) computed; zero the V half that PV(-1) multiplies by P = 0
-  *(u32x4*)(smem + V_RING + (NSLOT - 1) * KV_TILE_BYTES + 8192 + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
-  issue_tile(0);
-  if (ntiles > 1) issue_tile(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if constexpr (SHORT) {
+    if (bh != bh_loaded) {                 // first unit of a (batch, head): every tile of it into its slot, once
+      if (bh_loaded >= 0) __builtin_amdgcn_s_barrier();      // every wave is done with the tiles of the head before
+      bh_loaded = bh;
+      if (ntiles < NSLOT) *(u32x4*)(smem + V_RING + (NSLOT - 1) * KV_TILE_BYTES + 8192 + tid * 16) = (u32x4){0u, 0u, 0u, 0u};   // (4 tiles: slot 3 holds finite data)
+      for (int tt = 0; tt < ntiles; ++tt) issue_tile(tt);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    *(u32x4*)(smem + V_RING + (NSLOT - 1) * KV_TILE_BYTES + 8192 + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+    issue_tile(0);
+    if (ntiles > 1) issue_tile(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   __builtin_amdgcn_sched_barrier(0);
   f32x16 s_a, s_b;         // scores of the current / next half, ping-ponged statically (no register copies)
   qk_part(IC<0>{}, IC<0>{}, s_a);
@@ -564,6 +590,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
   auto tile = [&](int t, auto t4_c, auto mask_c) __attribute__((always_inline)) {       // t4 = t mod 4 as a compile-time constant
     constexpr int t4 = decltype(t4_c)::value;
     auto top = [&](int tt) __attribute__((always_inline)) {
+      if constexpr (SHORT) return;         // every tile is resident
       if (FULL || tt > 0) {
         // top of 64-key tile tt: tile tt+1 (issued one tile ago) has landed and becomes visible; the slot of tile
         // tt-2 (last read by the PV of its second half) is free again
@@ -582,7 +609,8 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     top(t);
     stepA(2 * t, s_a, s_b, mask_c);
     stepB(IC<2 * t4>{}, s_a, s_b);
-    if constexpr (FULL) issue_tile(min(t + 2, ntiles - 1), 2, t + 2);
+    if constexpr (SHORT) {
+    } else if constexpr (FULL) issue_tile(min(t + 2, ntiles - 1), 2, t + 2);
     else if (t + 2 < ntiles) issue_tile(t + 2, 2);
     stepA(2 * t + 1, s_b, s_a, mask_c);
     stepB(IC<2 * t4 + 1>{}, s_b, s_a);
@@ -655,6 +683,7 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
       half_swap_u32(a1, c1);
       if (qi < p.Lq) *(u32x4*)(orow + 32 * dt + 8 * i) = (u32x4){a0, a1, c0, c1};
     }
+  }   // q blocks of this workgroup
 }
 
 #ifdef FLEXAM_ATTN_BODY16
@@ -734,12 +763,16 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   if (body16) kern = cross ? (p.prescaled ? attn_fwd16_kernel<1, true> : attn_fwd16_kernel<1, false>)
                            : (p.prescaled ? attn_fwd16_kernel<0, true> : attn_fwd16_kernel<0, false>);
 #endif
+  // the text cross-attention (at most 4 key tiles, pre-scaled q, one launch without key splits): K/V resident, several q blocks per workgroup
+  const char* se_ = getenv("FLEXAM_ATTN_SHORT");       // read per call (A/B in one process); 0 = one workgroup per q block
+  const bool short_ctx = !q8 && cross && p.prescaled && tiles_all <= NSLOT && kv_splits == 1 && partial_slot0 < 0 && !body16 && !(se_ && atoi(se_) == 0);
+  if (short_ctx) kern = attn_fwd_kernel<1, true, false, true>;
   const char* fe_ = getenv("FLEXAM_ATTN_FULL");        // read per call (A/B in one process); 0 = the general instance
   const bool full = !q8 && !cross && p.prescaled && Lk >= KVBLK && last_key_bias == 0.f && !body16 && !(fe_ && atoi(fe_) == 0);
   if (full) kern = attn_fwd_kernel<0, true, true>;
   if (q8) kern = attn8_fwd_kernel<0>;
-  static bool attr_set[FLEXAM_MAX_DEVICES][10] = {};      // per device and kernel instance
-  const int which = q8 ? 8 : full ? 9 : (cross ? 1 : 0) + (p.prescaled ? 2 : 0) + (body16 ? 4 : 0);
+  static bool attr_set[FLEXAM_MAX_DEVICES][11] = {};      // per device and kernel instance
+  const int which = q8 ? 8 : full ? 9 : short_ctx ? 10 : (cross ? 1 : 0) + (p.prescaled ? 2 : 0) + (body16 ? 4 : 0);
   const int dev = flexam_current_device();
   if (!attr_set[dev][which]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -757,6 +790,12 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
     return flexam_check_launch("flexam_attn_fwd_partial");
   }
   if (S == 1) split_from_unit = units;
+  if (short_ctx) {                         // one persistent workgroup per CU, each with a contiguous share of the units
+    p.unit0 = 0; p.n_units = units; p.kv_splits = 1; p.tiles_per_split = tiles_all;
+    const int cus = flexam_num_cus();
+    hipLaunchKernelGGL(kern, dim3(units < cus ? units : cus), dim3(NT), smem, (hipStream_t)stream, p);
+    return flexam_check_launch("flexam_attn_fwd");
+  }
   const char* fe = getenv("FLEXAM_ATTN_FUSED_TAIL");     // read per call (A/B in one process); 0 = the two-launch form
   if (split_from_unit > 0 && split_from_unit < units && (!fe || atoi(fe) != 0)) {
     // one launch: whole units and the split tail side by side on every XCD (see AttnParams::whole_units), then the merge

@@ -683,3 +683,33 @@ def test_attention_one_block_step_instance_equals_the_general_instance(H, b, h, 
     # not bit for bit: the instance sets its first reference in the prologue (the second half tile's chain then starts from -ref
     # instead of being shifted afterwards), and a ragged count changes the tile a key sits in; bf16-level agreement
     torch.testing.assert_close(out.float(), gen.float(), rtol=2.0 ** -6, atol=6e-3)
+
+
+@pytest.mark.parametrize("h,lq,lk,mult", [(3, 25600, 127, 386.0), (5, 20000, 200, 1.0), (2, 40000, 64, 1.0)])
+def test_short_context_instance_walks_units_and_heads(H, h, lq, lk, mult):
+    """The text cross-attention's instance (at most 4 key tiles, pre-scaled q): one persistent workgroup per CU walks a contiguous
+    range of (q block, head) units with the head's K/V tiles resident, reloading them where its range crosses into the next head.
+    More units than CUs here, so workgroups walk several units and some cross a head boundary; ragged last q block; 2, 4 and 1 key
+    tiles; a weighted last key.  Bit-equal to the one-workgroup-per-q-block path (FLEXAM_ATTN_SHORT=0), and sampled rows vs the oracle."""
+    import os
+    g = torch.Generator().manual_seed(lq + lk)
+    c = 128 ** -0.5 * 1.4426950408889634
+    q = bf(torch.randn(1, lq, h, 128, generator=g) * c).to(dev())
+    k = bf(torch.randn(1, lk, h, 128, generator=g)).to(dev())
+    v = bf(torch.randn(1, lk, h, 128, generator=g)).to(dev())
+    run = (lambda: H.attn_fwd_lastkey(q, k, v, mult, prescaled=True)) if mult != 1.0 else (lambda: H.attn_fwd(q, k, v, prescaled=True))
+    out = run()
+    os.environ["FLEXAM_ATTN_SHORT"] = "0"
+    try:
+        gen = run()
+    finally:
+        os.environ.pop("FLEXAM_ATTN_SHORT")
+    assert torch.equal(out, gen)
+    rows = torch.arange(0, lq, lq // 50)[:50]
+    kk, vv = k.cpu(), v.cpu()
+    if mult != 1.0:                                  # the weighted last key as explicit copies
+        n = int(mult) - 1
+        kk = torch.cat([kk, kk[:, -1:].expand(1, n, h, 128)], dim=1)
+        vv = torch.cat([vv, vv[:, -1:].expand(1, n, h, 128)], dim=1)
+    ref = _attn_ref(q[:, rows].float().cpu() / c, kk, vv)
+    assert_bf16_close(out[:, rows], ref, ulps=2.0, atol=4e-3, msg="short-context instance")
