@@ -454,7 +454,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
           for (int i = 0; i < 8; ++i) {
             if (i >= nit) continue;
             const int m = mw + t0 * RT + 4 * i + rr;
-            xv[i] = *(const f32x4*)(xtile + (int64_t)(t0 * RT + 4 * i) * p.ldx * 4 + xlane);
+            // X is 286 MB of fp32 at the DiT shapes -- larger than the Infinity Cache -- and every element is touched once per launch:
+            // non-temporal loads and stores keep it from evicting the operands that ARE re-read (-0.8 ... -0.9 % of a step, profiles/r4as_*)
+            xv[i] = __builtin_nontemporal_load((const f32x4*)(xtile + (int64_t)(t0 * RT + 4 * i) * p.ldx * 4 + xlane));
             if constexpr (GATE == 1) gr[i] = p.gate_row[m];
             if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
           }
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
               f32x4 x = xv[idx];
 #pragma unroll
               for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[idx][j] : bf2f(y[j]);
-              *(f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane) = x;
+              __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane));
             }
           }
           __builtin_amdgcn_sched_barrier(0);           // one batch of loads in flight at a time: all of them at once would not fit the registers
@@ -518,7 +520,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
         for (int i = 0; i < RT / 8; ++i) {
           const int row = 8 * i + rd_row;
           const bf16x8 o8 = *(const bf16x8*)(stg + row * 128 + ((rd_c ^ (row & 7)) << 4));
-          *(bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc) = o8;
+          // the GELU output (FFN1: 668 MB, read once by FFN2 from its start, when the Infinity Cache holds only its end) leaves non-temporally
+          // as well (a further -0.2 ... -0.4 %); the plain outputs (QKV, cross-q) are re-read at once by the next launch and stay cached
+          if constexpr (EPI == EPI_GELU) __builtin_nontemporal_store(o8, (bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc));
+          else *(bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc) = o8;
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));   // see the gate-residual path

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
           for (int i = 0; i < 8; ++i) {
             if (i >= nit) continue;
             const int m = mw + t0 * 16 + 4 * i + rr;
-            xv[i] = *(const f32x4*)(xtile + (int64_t)(t0 * 16 + 4 * i) * p.ldx * 4 + xlane);
+            // non-temporal, like the bf16 GEMM's epilogues (gemm.hip): X and the e4m3 GELU output are touched once per launch
+            xv[i] = __builtin_nontemporal_load((const f32x4*)(xtile + (int64_t)(t0 * 16 + 4 * i) * p.ldx * 4 + xlane));
             if constexpr (GATE == 1) gr[i] = p.gate_row[m];
             if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
           }
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
               f32x4 x = xv[idx];
 #pragma unroll
               for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[idx][j] : bf2f(y[j]);
-              *(f32x4*)(xtile + (int64_t)(t0 * 16 + 4 * idx) * p.ldx * 4 + xlane) = x;
+              __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * 16 + 4 * idx) * p.ldx * 4 + xlane));
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(Gemm8Params p) {
           *(int*)(stg + wr_row * 64 + ((v ^ ((wr_row >> 1) & 3)) << 4) + wr_g * 4) = w;
         }
         const u32x4 o = *(const u32x4*)(stg + rd_row * 64 + ((rd_c ^ ((rd_row >> 1) & 3)) << 4));
-        *(u32x4*)(crow + (int64_t)(t * 16) * p.ldc) = o;
+        __builtin_nontemporal_store(o, (u32x4*)(crow + (int64_t)(t * 16) * p.ldc));
       }
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));
       pend = true;
