@@ -1,0 +1,68 @@
+"""`cpu_baseline` legs of the JSON line: the fp32 oracle (oracle/: test infrastructure, pinned to the reference by golden vectors) timed on the
+host cores AFTER the timed region.  The only bench module that imports `oracle`."""
+import time
+
+import torch
+
+
+def cpu_baseline(L, cfg):
+    """fp32 oracle (oracle/dit.py: the restatement pinned to the reference by golden vectors) on the
+    host cores: ONE WanAttentionBlock forward on ONE sample at the full token count = 1/60 of a step."""
+    from oracle import cases as C
+    from oracle import dit as O
+    d, f, nh, T = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"], cfg["text_len"]
+    one = dict(cfg, num_layers=1)
+    shapes = {k: v for k, v in O.dit_param_shapes(one).items() if k.startswith("blocks.0.")}
+    sd = O.seeded_state_dict(shapes, 3)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, L, d, generator=g)
+    e0 = torch.randn(1, 6, d, generator=g) * 0.1
+    dens0 = torch.randn(1, 2, d, generator=g) * 0.1
+    ctx = torch.randn(1, T, d, generator=g)
+    grid = (26, 16, 28) if L == 11648 else (1, 1, L)
+    ang = O.rope_angles(1024, d // nh)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.block_forward(sd, "blocks.0", x, e0, dens0, grid, ang, ctx, nh)
+    sec = time.perf_counter() - t0
+    steps_per_sec = 1.0 / (sec * 60.0)
+    return dict(value=steps_per_sec, unit="denoise-steps/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"1 of the 60 block-forwards of one step (oracle/dit.py block_forward, fp32, L={L}, d={d}) "
+                       f"took {sec:.1f} s; value = 1/(60 x that), extrapolated", block_seconds=sec)
+
+
+def cpu_baseline_legs(cfg, layers=3):
+    """The other two legs of SURVEY 8(d)'s CPU baseline, each a bounded sample on the host cores (fp32 oracle):
+    (i)  BASELINE config 1 end to end -- 9x256x256 (latent [1,48,3,16,16], L = 256), 4 Euler steps, CFG pair -- with `layers` of
+         the 30 layers of the 5B-width model (the weights of 30 would be 20 GB of fp32), block time extrapolated to 30;
+    (ii) the Wan2.2 VAE decoder at its true widths on a 1/16-area latent [1,48,2,8,14] (first chunk + one cached 4-frame chunk),
+         extrapolated x16 in area and to the 25 latent frames of a 97-frame clip."""
+    from oracle import cases as C
+    from oracle import dit as O
+    from oracle import sampler as S
+    from oracle import vae as OV
+    c1 = dict(cfg, num_layers=layers)
+    sd = C.dit_weights(c1, 5)
+    sc = C.sampler_case(c1)
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        S.denoise_loop(lambda **k: O.dit_forward(sd, c1, **k), S.FlowMatchEulerSchedule(1000, 5.0), 4, sc["latents"], sc["context_uncond"],
+                       sc["context_cond"], sc["control_latents"], sc["additional_control"], ml, sc["masked_video_latents"],
+                       sc["ref_latents"], mask, pinned, 0.1, 6.0)
+    sec1 = time.perf_counter() - t0
+    del sd
+    v = dict(z_dim=48, dec_dim=256, dim_mult=(1, 2, 4, 4), temporal_up=(True, True, False))
+    vsd = C.vae_weights(v, seed=61, prefix="model.")
+    z = C.vae_case(seed=62, frames=2, h=8, w=14)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        OV.vae_decode(vsd, z, v["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
+    sec2 = time.perf_counter() - t0
+    return {
+        "config1_4_steps": dict(seconds=sec1, layers_run=layers, sample=f"9x256x256, 4 Euler steps, CFG pair, {layers} of 30 layers at d=3072 (oracle loop + dit_forward)",
+                                extrapolated_seconds_30_layers=sec1 * 30.0 / layers),
+        "vae_decode_chunk": dict(seconds=sec2, sample="true-width decoder, latent [1,48,2,8,14] (1/16 area): first chunk + one 4-frame chunk",
+                                 extrapolated_seconds_97x512x896=sec2 / 5.0 * 97.0 * 16.0),
+    }
+

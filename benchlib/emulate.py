@@ -1,0 +1,80 @@
+"""`bench.py --emulate-rank N`: ONE process runs one rank's share of an N-GPU denoise step at full size on one GPU.
+
+The rank's engine is the real one (DiTEngine.set_parallel: token chunk L/sp, one CFG row or the batched pair, head-group pieces, local-
+chunk-first partial attention + merge, send / receive layouts); its process groups are flexam_amd.dist.LoopbackGroup objects, so every
+collective becomes device copies of the same sizes on a side stream (where RCCL's stream sits in a real run).  What this measures per
+layout: the rank's GPU time per step with every launch, piece and merge the multi-GPU path adds, and the host's enqueue time for them --
+everything except the xGMI transfers themselves.  `predicted_scaling_no_comm` = single-GPU step / emulated rank step: the ceiling the
+links can only lower (tools/rank_shapes.py summed isolated kernels; this runs the step).  Results of the emulated step are not
+meaningful (the "remote" chunks are copies of the local one): such a line is never a measurement of N GPUs and says so."""
+import os
+import time
+
+import torch
+
+
+def layouts(world: int, num_heads: int):
+    """(name, FLEXAM_SP_MODE, cfg_parallel, pieces): the layouts the N-rank run chooses between (benchlib/probe.candidates), without
+    the overlap variants that only differ in what travels under what."""
+    out = []
+    if world % 2 == 0:
+        out.append((f"cfg2 x sp{world // 2}, K|V all-gather (default)", "allgather", True, None))
+    if world >= 4 and num_heads % world == 0:
+        out.append((f"cfg1 x sp{world}, all-to-all over heads", "ulysses", False, None))
+    if world % 2 or world == 2:
+        out.append((f"cfg1 x sp{world}, K|V all-gather", "allgather", False, None))
+    return out
+
+
+def set_emulated_layout(model, world: int, cfg_parallel: bool, rank: int):
+    from flexam_amd.dist import LoopbackGroup
+    if cfg_parallel:
+        sp = world // 2
+        par = dict(sp_group=LoopbackGroup(sp, rank % sp) if sp > 1 else None, sp_rank=rank % sp, sp_size=sp, world_group=LoopbackGroup(world, rank),
+                   world_size=world, cfg_size=2, cfg_row=rank // sp)
+    else:
+        g = LoopbackGroup(world, rank)
+        par = dict(sp_group=g, sp_rank=rank, sp_size=world, world_group=g, world_size=world)
+    model._parallel = par
+    model._engine = None                                   # rebuilt for the layout on its next use (reads the FLEXAM_SP_* switches)
+
+
+def emulate(model, make_pipe, inp, cond, world: int, steps: int, warmup: int, total_steps: int, rank=None):
+    """Times one emulated rank per layout.  `rank`: which rank's share (default: the middle chunk of the first CFG half -- remote
+    chunks on both sides of its own, the most partial-attention calls).  Leaves the model without a parallel layout."""
+    saved = {k: os.environ.get(k) for k in ("FLEXAM_SP_MODE", "FLEXAM_SP_PIECES", "FLEXAM_SP_OVERLAP")}
+    rows = []
+    try:
+        for name, mode, cfgp, pieces in layouts(world, model.num_heads):
+            sp = world // 2 if cfgp else world
+            r = rank if rank is not None else (sp // 2 if sp > 2 else 0)
+            os.environ["FLEXAM_SP_MODE"] = mode
+            os.environ.pop("FLEXAM_SP_PIECES", None)
+            if pieces is not None:
+                os.environ["FLEXAM_SP_PIECES"] = str(pieces)
+            set_emulated_layout(model, world, cfgp, r)
+            pipe = make_pipe()
+            pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+            eng = model.engine()
+            for i in range(warmup):
+                pipe.denoise_step(i % total_steps)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                pipe.denoise_step((warmup + i) % total_steps)
+            t_enq = time.perf_counter() - t0                 # the host is done enqueueing here (no sync inside a step)
+            torch.cuda.synchronize()
+            sec = (time.perf_counter() - t0) / steps
+            rows.append({"layout": name, "emulated_rank": r, "sp_size": eng.sp_size, "cfg_size": eng.cfg_size, "tokens_per_rank": eng.cond["L"] // eng.sp_size,
+                         "samples_per_rank": 1 if eng.cfg_size == 2 else 2, "pieces": getattr(eng, "sp_pieces", 1), "ms_per_step": sec * 1e3,
+                         "host_enqueue_ms_per_step": t_enq / steps * 1e3, "host_share_of_step": t_enq / steps / sec})
+            del pipe
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        model._parallel = None
+        model._engine = None
+    return rows

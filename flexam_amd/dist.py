@@ -24,24 +24,139 @@ import torch
 import torch.distributed as dist
 
 
-_SUBGROUPS = {}      # member tuple -> process group: a communicator is made once per member set and process
+_SUBGROUPS = {}      # (generation of the default process group, member tuple) -> process group
+_GENERATION = [None, 0]   # [the default process group the cache was filled under, counter]
+
+
+def _generation() -> int:
+    """Bumps when the default process group is not the one the cache was filled under (destroy_process_group + a new
+    init_process_group in a long-lived process): handles of a destroyed communicator must not be handed out again."""
+    world = dist.group.WORLD if dist.is_initialized() else None
+    if world is not _GENERATION[0]:
+        _GENERATION[0] = world
+        _GENERATION[1] += 1
+        _SUBGROUPS.clear()
+    return _GENERATION[1]
 
 
 def subgroup(members) -> "dist.ProcessGroup":
     """The process group of `members` (global ranks), created on first use and cached: torch.distributed.new_group builds a new
     communicator on every call (collective over ALL ranks, never freed), so a caller that re-selects a layout -- bench.py's layout
     probe, repeated enable_multi_gpus_inference calls -- must not create them again.  Every rank must ask for the same member sets in
-    the same order the first time (new_group's own rule)."""
-    key = tuple(int(r) for r in members)
+    the same order the first time (new_group's own rule).  The cache belongs to ONE default process group: after
+    destroy_process_group() and a re-init it starts empty (clear_subgroups() does the same by hand)."""
+    key = (_generation(), tuple(int(r) for r in members))
     g = _SUBGROUPS.get(key)
     if g is None:
-        g = _SUBGROUPS[key] = dist.new_group(list(key))
+        g = _SUBGROUPS[key] = dist.new_group(list(key[1]))
     return g
 
 
+def clear_subgroups() -> None:
+    """Forgets the cached sub-communicators (they are not destroyed here: destroy_process_group() does that)."""
+    _SUBGROUPS.clear()
+
+
 def live_subgroups() -> int:
-    """Number of sub-communicators this process has created through subgroup() (the world group is not counted)."""
+    """Number of sub-communicators this process has created through subgroup() under the current default process group
+    (the world group is not counted)."""
+    _generation()
     return len(_SUBGROUPS)
+
+
+class LoopbackGroup:
+    """ONE process standing in for rank `rank` of a `size`-rank group (bench.py --emulate-rank, tests): every collective issued on
+    it is replaced by device copies of the SAME sizes on a side stream -- the place RCCL's own stream has in a real run -- and returns
+    a Work-like object, so a rank's launch sequence, buffer shapes, partial / merge calls and stream dependencies are the real ones
+    while nothing leaves the GPU.  The "received" chunks are copies of the local one: timing and plumbing only, never results."""
+
+    def __init__(self, size: int, rank: int = 0):
+        if not 0 <= rank < size:
+            raise ValueError(f"LoopbackGroup: rank {rank} outside 0..{size - 1}")
+        self.size, self.rank = int(size), int(rank)
+        self._stream = None
+
+    def side_stream(self, device):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=device)
+        return self._stream
+
+    def run(self, fn, ref: torch.Tensor, async_op: bool):
+        """`fn()` (the copies) after everything enqueued so far on the caller's stream; returns a Work (async) or None (joined)."""
+        if ref.device.type != "cuda":                      # CPU tensors (unit tests of the plumbing): synchronous
+            fn()
+            return _LoopbackWork(None) if async_op else None
+        cur = torch.cuda.current_stream(ref.device)
+        side = self.side_stream(ref.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            fn()
+            done = torch.cuda.Event()
+            done.record(side)
+        work = _LoopbackWork(done)
+        if async_op:
+            return work
+        work.wait()
+        return None
+
+
+class _LoopbackWork:
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+        return True
+
+
+def group_size(group=None) -> int:
+    return group.size if isinstance(group, LoopbackGroup) else dist.get_world_size(group)
+
+
+def group_rank(group=None) -> int:
+    return group.rank if isinstance(group, LoopbackGroup) else dist.get_rank(group)
+
+
+def group_backend(group=None) -> str:
+    """"nccl" (RCCL), "gloo", ... or "loopback"."""
+    return "loopback" if isinstance(group, LoopbackGroup) else dist.get_backend(group)
+
+
+def all_gather_into_tensor(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
+    """dist.all_gather_into_tensor (rank-major concatenation on dim 0) on a real group; on a LoopbackGroup every rank's slot of `out`
+    receives a copy of `inp` (one launch, the bytes a real gather writes)."""
+    if isinstance(group, LoopbackGroup):
+        src = inp.contiguous()
+        return group.run(lambda: out.view(group.size, *src.shape).copy_(src.unsqueeze(0).expand(group.size, *src.shape)), out, async_op)
+    return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
+
+
+_SP_CONTEXT = [None]
+
+
+class sequence_parallel_context:
+    """Set by the engine around the block-module calls of a sequence-parallel forward (the reference re-binds every
+    `block.self_attn.forward` to a USP forward at this point, wan_transformer3d_FlexAM.py:807-815): blocks receive THIS RANK'S token
+    chunk [B, L/N, C] with the global `seq_lens` / `grid_sizes` (wan_transformer3d_FlexAM.py:970-975), and a self-attention forward --
+    the native one, or a caller's re-bound one -- finds here what it needs for the exchange: group, rank, size, the global token
+    offset of the chunk and the RoPE tables of the WHOLE sequence.  `current_sp_context()` is None outside such a forward."""
+
+    def __init__(self, group, rank: int, size: int, token_offset: int, seq_len: int, rope_cos=None, rope_sin=None):
+        self.info = dict(group=group, rank=rank, size=size, token_offset=token_offset, seq_len=seq_len, rope_cos=rope_cos, rope_sin=rope_sin)
+
+    def __enter__(self):
+        self._prev = _SP_CONTEXT[0]
+        _SP_CONTEXT[0] = self.info
+        return self.info
+
+    def __exit__(self, *exc):
+        _SP_CONTEXT[0] = self._prev
+        return False
+
+
+def current_sp_context():
+    return _SP_CONTEXT[0]
 
 
 def chunk_bounds(seq_len: int, rank: int, world: int) -> Tuple[int, int]:
@@ -54,11 +169,11 @@ def chunk_bounds(seq_len: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_gather_seq(local: torch.Tensor, group=None, out: torch.Tensor = None, scratch: torch.Tensor = None) -> torch.Tensor:
     """local [B, Lc, X] on every rank -> [B, N*Lc, X] with rank r's rows at [r*Lc, (r+1)*Lc)."""
-    world = dist.get_world_size(group)
+    world = group_size(group)
     b, lc, x = local.shape
     if scratch is None:
         scratch = torch.empty(world * b, lc, x, device=local.device, dtype=local.dtype)
-    dist.all_gather_into_tensor(scratch.view(world * b, lc, x), local.contiguous(), group=group)   # rank-major concat on dim 0
+    all_gather_into_tensor(scratch.view(world * b, lc, x), local.contiguous(), group=group)   # rank-major concat on dim 0
     if out is None:
         out = torch.empty(b, world * lc, x, device=local.device, dtype=local.dtype)
     out.view(b, world, lc, x).copy_(scratch.view(world, b, lc, x).transpose(0, 1))
@@ -71,7 +186,7 @@ class SeqGather:
     rank-major concatenation already IS the token order, so no re-layout pass is needed."""
 
     def __init__(self, local: torch.Tensor, group=None, out: torch.Tensor = None, scratch: torch.Tensor = None):
-        self.world = dist.get_world_size(group)
+        self.world = group_size(group)
         self.shape = tuple(local.shape)
         b, lc, x = self.shape
         self.out = out
@@ -79,7 +194,7 @@ class SeqGather:
             self.scratch = out.view(self.world * b, lc, x) if out is not None else torch.empty(self.world, lc, x, device=local.device, dtype=local.dtype)
         else:
             self.scratch = scratch if scratch is not None else torch.empty(self.world * b, lc, x, device=local.device, dtype=local.dtype)
-        self.work = dist.all_gather_into_tensor(self.scratch.view(self.world * b, lc, x), local.contiguous(), group=group, async_op=True)
+        self.work = all_gather_into_tensor(self.scratch.view(self.world * b, lc, x), local.contiguous(), group=group, async_op=True)
 
     def finish(self) -> torch.Tensor:
         self.work.wait()
@@ -95,6 +210,8 @@ def all_to_all_chunks(out: torch.Tensor, inp: torch.Tensor, group=None, async_op
     """inp [N, ...] (chunk j goes to rank j) -> out [N, ...] (chunk i came from rank i), both contiguous.  RCCL: one
     all_to_all_single (pairwise sends over the xGMI mesh).  Other backends (the gloo test runs) may lack all-to-all on device
     tensors: the same result is assembled from an all-gather of every rank's send buffer."""
+    if isinstance(group, LoopbackGroup):
+        return group.run(lambda: out.copy_(inp), out, async_op)
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "nccl":
         return dist.all_to_all_single(out, inp, group=group, async_op=async_op)
@@ -111,6 +228,11 @@ def all_to_all_blocks(outs, ins, group=None, async_op: bool = False):
     async_op = True returns its Work (wait() makes the caller's stream wait for the exchange), so the next sample's exchange
     travels under this sample's attention.  Other backends (the gloo runs of the tests): the same result from an all-gather of
     every rank's stacked blocks, finished before returning (None: nothing to wait for)."""
+    if isinstance(group, LoopbackGroup):                                  # block i "arrives" as a copy of the block sent to rank i
+        def copies():
+            for o, t in zip(outs, ins):
+                o.copy_(t)
+        return group.run(copies, outs[0], async_op)
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "nccl":
         return dist.all_to_all(list(outs), list(ins), group=group, async_op=async_op)
@@ -157,8 +279,16 @@ def shard_streams(jobs, encode, group=None):
 
 
 def get_sequence_parallel_world_size(group=None) -> int:
-    return dist.get_world_size(group) if dist.is_initialized() else 1
+    """The reference's `get_sequence_parallel_world_size()` (missing FlexAM/dist; call site wan_transformer3d_FlexAM.py:802): inside a
+    sequence-parallel forward the size of the group the engine runs on (a CFG half under the 2 x N/2 layout)."""
+    ctx = current_sp_context()
+    if ctx is not None and group is None:
+        return ctx["size"]
+    return group_size(group) if (isinstance(group, LoopbackGroup) or dist.is_initialized()) else 1
 
 
 def get_sequence_parallel_rank(group=None) -> int:
-    return dist.get_rank(group) if dist.is_initialized() else 0
+    ctx = current_sp_context()
+    if ctx is not None and group is None:
+        return ctx["rank"]
+    return group_rank(group) if (isinstance(group, LoopbackGroup) or dist.is_initialized()) else 0

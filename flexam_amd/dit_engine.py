@@ -20,6 +20,7 @@ All arithmetic runs in libflexam_hip.so (flexam_amd/hip.py); torch only allocate
 """
 import math
 import os
+from contextlib import nullcontext
 from typing import List, Optional
 
 import torch
@@ -73,6 +74,8 @@ class _Image:
 
 
 class DiTEngine:
+    _sage_warned = False
+
     def __init__(self, model):
         self.model = model
         c = model.config
@@ -439,7 +442,15 @@ class DiTEngine:
 
         nh, hdim = self.nh, self.hd
         # the reference reads the switch at every attention call (attention_utils.py:195); quantised self-attention on one rank only
-        sage = sp == 1 and os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION"
+        sage_asked = os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION"
+        sage = sp == 1 and sage_asked
+        self.sage_taken = bool(sage)                       # what this forward DID (bench.py labels its line from it, like share0_taken)
+        if sage_asked and not sage and not DiTEngine._sage_warned:
+            DiTEngine._sage_warned = True
+            import warnings
+            warnings.warn("flexam_amd: VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION is ignored " +
+                          "under sequence parallelism (the K|V exchange carries bf16 rows): self-attention runs the bf16 kernel",
+                          RuntimeWarning, stacklevel=2)
         fp8_oproj = self.fp8 and os.environ.get("FLEXAM_FP8_OPROJ", "0") == "1"
         q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hdim))
         k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hdim))
@@ -564,8 +575,6 @@ class DiTEngine:
         with the reference's block signature (wan_transformer3d_FlexAM.py:1053-1089) on [B, L, C] fp32 tensors.  The AdaLN
         input is materialised per token like the reference's e0 ([B, L, 6, C]); native blocks find its compact form in the
         `_flexam_rows` attribute."""
-        if self.sp_size > 1:
-            raise NotImplementedError("replaced / re-bound blocks are called as whole-sequence modules: not with sequence parallelism")
         cd, d = self.cond, self.dim
         if row_index is not None:
             e_full = e0[row_index.long()].view(B, lc, 6, d)
@@ -573,13 +582,20 @@ class DiTEngine:
             e_full = e0.view(B, 6, d)
         e_full._flexam_rows = (e0, row_index, rows_per_batch)
         grid_sizes = torch.tensor([list(cd["grid"])] * B, dtype=torch.long)
-        seq_lens = torch.tensor([lc] * B, dtype=torch.long)
+        # Under sequence parallelism the blocks get this rank's token chunk and the GLOBAL lengths / grid, as the reference hands them
+        # over (wan_transformer3d_FlexAM.py:970-975, 1075-1086); the exchange around self-attention belongs to `self_attn.forward`
+        # (the reference re-binds it to a USP forward, :807-815): the native _SelfAttn.forward reads the context below and gathers K|V
+        # itself, a caller's re-bound forward finds group / rank / token offset / RoPE tables in flexam_amd.dist.current_sp_context()
+        from .dist import sequence_parallel_context
+        sp = self.sp_size
+        seq_lens = torch.tensor([lc * sp] * B, dtype=torch.long)
         x3 = xres.view(B, lc, d)
         ctx = cd["ctx"][rsel]
-        for blk in self.block_modules:
-            out = blk(x3, e=e_full, density_emb=dens0, seq_lens=seq_lens, grid_sizes=grid_sizes, freqs=self.model.freqs, context=ctx,
-                      context_lens=None, dtype=BF16, t=t_rows)
-            x3.copy_(out.view(B, lc, d))
+        with sequence_parallel_context(self.sp_group, self.sp_rank, sp, self.sp_rank * lc, lc * sp, cd["cos"], cd["sin"]) if sp > 1 else nullcontext():
+            for blk in self.block_modules:
+                out = blk(x3, e=e_full, density_emb=dens0, seq_lens=seq_lens, grid_sizes=grid_sizes, freqs=self.model.freqs, context=ctx,
+                          context_lens=None, dtype=BF16, t=t_rows)
+                x3.copy_(out.view(B, lc, d))
 
     # ------------------------------------------------------------------ TeaCache
     @staticmethod
@@ -711,7 +727,7 @@ class DiTEngine:
         g - 1 computed.  A peer chunk cannot arrive faster than its one xGMI link delivers it, and the chunks of one gather all
         land together; cutting along the heads gives pieces that are complete work for part of the kernel, so all links stay
         busy in every phase (reference call sites of the missing exchange: wan_transformer3d_FlexAM.py:801-815, 970-975)."""
-        import torch.distributed as dist
+        from .dist import all_gather_into_tensor, group_backend
         sp, nh, hd, d, dev = self.sp_size, self.nh, self.hd, self.dim, self.device
         ws = self._ws[(B, lc)]
         L = sp * lc
@@ -733,8 +749,8 @@ class DiTEngine:
         # RCCL runs the pieces one after the other on its own stream, in the order they are issued here.  The host-staged backends of the
         # test runs (gloo) execute several in-flight collectives of one group on concurrent worker threads, which is not what is being
         # modelled (and delivered wrong chunks intermittently with 8 ranks on one device): there each gather completes before the next.
-        overlapped = dist.get_backend(self.sp_group) == "nccl"
-        works = [[dist.all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=overlapped) for b in range(B)] for g in range(G)]
+        overlapped = group_backend(self.sp_group) in ("nccl", "loopback")
+        works = [[all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=overlapped) for b in range(B)] for g in range(G)]
         self._proj(hbuf, a8sa, layer, p, "wqkv", "bqkv", slice(0, d), qkv[:, 0:d])
         hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0,
                          head_dim=hd)
@@ -768,10 +784,10 @@ class DiTEngine:
         if self.cfg_size == 1:
             return all_gather_seq(head_local, self.sp_group)
         # world rank = cfg_row * sp + sp_rank, one local row each: the rank-major gather IS [2, sp, Lc, n]
-        import torch.distributed as dist
+        from .dist import all_gather_into_tensor
         bl, lc, n = head_local.shape
         if bl != 1:
             raise RuntimeError("cfg-parallel ranks carry exactly one CFG row")
         out = torch.empty(self.world_size * lc, n, device=head_local.device, dtype=head_local.dtype)   # rank-major concat
-        dist.all_gather_into_tensor(out, head_local.reshape(lc, n).contiguous(), group=self.world_group)
+        all_gather_into_tensor(out, head_local.reshape(lc, n).contiguous(), group=self.world_group)
         return out.view(self.cfg_size, self.sp_size * lc, n)

@@ -182,8 +182,12 @@ class _SelfAttn(_Attn):
         """x [B, L, C] -> [B, L, C] bf16; seq_lens [B] (all equal to L on this path), grid_sizes [B, 3], freqs [1024, C/heads/2]
         (angle table, or the reference's complex exp(i angle) table)."""
         from . import hip
+        from .dist import current_sp_context
         b, l, c = x.shape
         nh, hd = self.num_heads, self.head_dim
+        sp = current_sp_context()
+        if sp is not None and sp["size"] > 1:
+            return self._forward_chunk(x, seq_lens, sp)
         if seq_lens is not None and any(int(v) != l for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens)):
             raise NotImplementedError("flexam_amd: padded sequences (seq_lens < L) do not occur on the FlexAM path (H, W multiples of 32)")
         pk = self.packed()
@@ -199,6 +203,31 @@ class _SelfAttn(_Attn):
         else:
             ao = hip.attn_fwd(q4, k4, v4, prescaled=True)
         return hip.gemm(ao.view(b * l, c), pk["wo"], pk["bo"]).view(b, l, c)
+
+
+    def _forward_chunk(self, x, seq_lens, sp):
+        """Sequence-parallel form of forward() for blocks that are called as modules (the reference's `usp_attn_forward`, re-bound at
+        wan_transformer3d_FlexAM.py:807-815): x is this rank's token chunk [B, L/N, C]; q|k|v of the chunk, RMSNorm + RoPE at the
+        chunk's GLOBAL token offset, ONE all-gather of the normed / rotated K|V over the sequence-parallel group (RCCL over xGMI; the
+        rank-major concatenation is the token order), attention of the local queries to all keys, output projection.  The engine's
+        fused path does the same exchange in head-group pieces overlapped with compute (DiTEngine._allgather_attention); this seam
+        form favours being one plain forward a wrapper can trace."""
+        from . import hip
+        from .dist import all_gather_seq
+        b, lc, c = x.shape
+        nh, hd = self.num_heads, self.head_dim
+        L = sp["seq_len"]
+        if lc * sp["size"] != L or (seq_lens is not None and any(int(v) != L for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens))):
+            raise NotImplementedError(f"flexam_amd: a sequence-parallel chunk of {lc} tokens x {sp['size']} ranks does not tile seq_lens / L = {L}")
+        pk = self.packed()
+        qkv = hip.gemm(x.reshape(b * lc, c).to(BF16).contiguous(), pk["wqkv"], pk["bqkv"])
+        hip.rmsnorm_rope(qkv[:, 0:c], pk["nq"], qkv[:, c:2 * c], pk["nk"], eps=self.eps, rope_cos=sp["rope_cos"], rope_sin=sp["rope_sin"],
+                         tokens_per_batch=lc, token_offset=sp["token_offset"], head_dim=hd)
+        q3 = qkv.view(b, lc, 3 * c)
+        kv = all_gather_seq(q3[:, :, c:].contiguous(), sp["group"])                  # [B, L, 2C]
+        ao = hip.attn_fwd(q3[:, :, 0:c].unflatten(2, (nh, hd)), kv[:, :, 0:c].unflatten(2, (nh, hd)), kv[:, :, c:].unflatten(2, (nh, hd)),
+                          prescaled=True)
+        return hip.gemm(ao.view(b * lc, c), pk["wo"], pk["bo"]).view(b, lc, c)
 
 
 class _CrossAttn(_Attn):

@@ -56,6 +56,58 @@ def dit_weights(cfg: dict, seed: int) -> Dict[str, Tensor]:
     return O.seeded_state_dict(O.dit_param_shapes(cfg), seed)
 
 
+def dit_weights_threaded(cfg: dict, seed: int) -> Dict[str, Tensor]:
+    """Full-depth 5B-width state dicts (5 B parameters): one generator per tensor on a thread pool (oracle.dit.seeded_state_dict_threaded)."""
+    import os
+    return O.seeded_state_dict_threaded(O.dit_param_shapes(cfg), seed, threads=min(32, os.cpu_count() or 8))
+
+
+def scale_self_attention_logits(sd: Dict[str, Tensor], logit_std: float) -> list:
+    """Peaked softmax rows: multiplies every `blocks.*.self_attn.norm_q.weight` / `norm_k.weight` by sqrt(logit_std) IN PLACE.  q and k
+    leave WanRMSNorm (FX.py:173-189, over the full width) with unit RMS per element, so q.k / sqrt(128) of two different tokens is
+    ~N(0, 1) with the seeded weights; after the scaling it is ~N(0, logit_std^2): rows whose maximum sits tens of exp2 units above
+    their mean, a few keys carrying the row, and -- in a kernel that keeps a running reference -- many reference moves.
+    Returns the names it touched."""
+    names = [k for k in sd if ".self_attn.norm_q.weight" in k or ".self_attn.norm_k.weight" in k]
+    for k in names:
+        sd[k].mul_(math.sqrt(logit_std))
+    return names
+
+
+def self_attention_row_stats(sd: Dict[str, Tensor], cfg: dict, case: dict, head: int = 0, tile: int = 64) -> dict:
+    """What block 0's self-attention rows look like for a DiT call (FX.py:230-262 on the block-0 input): per-row statistics of the
+    scores s = q.k / sqrt(D) * log2(e) (exp2 units) of ONE head of sample 0 -- std over keys, max - mean, the effective number of
+    keys 1 / sum(p^2), and how far the row maximum lies above the maximum of the first `tile` keys (a flash kernel that keeps the
+    first tile's maximum as its reference has to move it when this exceeds its threshold)."""
+    one = dict(cfg, num_layers=1)
+    taps = {}
+    with torch.no_grad():
+        O.dit_forward({k: v for k, v in sd.items() if not k.startswith("blocks.") or k.startswith("blocks.0.")}, one, taps=taps, **case)
+        x, e0, dens0 = taps["x_embed"][:1], taps["e0"][:1], taps["dens0"][:1]
+        p = "blocks.0"
+        if e0.dim() > 3:
+            e = [u.squeeze(2) for u in (sd[p + ".modulation"].unsqueeze(0) + e0).chunk(6, dim=2)]
+        else:
+            e = (sd[p + ".modulation"] + e0).chunk(6, dim=1)
+        dm = (sd[p + ".modulation_density"] + dens0).chunk(2, dim=1)
+        eps = cfg.get("eps", 1e-6)
+        h = O.layer_norm(x, eps) * (1 + e[1]) + e[0] + dm[0]
+        nh = cfg["num_heads"]
+        hd = cfg["dim"] // nh
+        l = h.shape[1]
+        q = O.rms_norm(O.linear(sd, p + ".self_attn.q", h), sd[p + ".self_attn.norm_q.weight"], eps).view(1, l, nh, hd)
+        k = O.rms_norm(O.linear(sd, p + ".self_attn.k", h), sd[p + ".self_attn.norm_k.weight"], eps).view(1, l, nh, hd)
+        f = case["x"].shape[2] + (1 if case.get("full_ref") is not None else 0)
+        grid = (f, case["x"].shape[3] // 2, case["x"].shape[4] // 2)
+        ang = O.rope_angles(1024, hd)
+        q, k = O.rope_apply(q, grid, ang)[0, :, head], O.rope_apply(k, grid, ang)[0, :, head]
+        s = (q @ k.t()) / math.sqrt(hd) * math.log2(math.e)
+        pr = torch.softmax(s * math.log(2.0), dim=-1)
+        return dict(std=s.std(dim=1).mean().item(), max_minus_mean=(s.max(dim=1).values - s.mean(dim=1)).mean().item(),
+                    n_eff=(1.0 / pr.pow(2).sum(dim=1)).mean().item(), keys=l,
+                    over_first_tile=(s.max(dim=1).values - s[:, :tile].max(dim=1).values))
+
+
 def block_case(dim: int = 256, ffn: int = 512, heads: int = 2, grid=(4, 8, 8), text: int = 16, seed: int = 11) -> dict:
     """One WanAttentionBlock (G3): L = prod(grid), per-token e0 with two distinct rows."""
     g = torch.Generator().manual_seed(seed)

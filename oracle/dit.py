@@ -329,30 +329,49 @@ def dit_param_shapes(cfg: dict) -> Dict[str, tuple]:
     return s
 
 
+def _seeded_tensor(name: str, shape: tuple, r: Tensor) -> Tensor:
+    """Scale rule of the seeded state dicts: activations stay O(1); nothing is left at the reference's zero-init
+    (FX.py:1172-1188, VAE.py:258) so every path contributes to the output."""
+    if name.endswith("gamma"):
+        return 1.0 + 0.1 * r
+    if name.endswith(".bias"):
+        return 0.05 * r
+    if "modulation" in name:
+        return r / math.sqrt(shape[-1])
+    if len(shape) == 1:                            # norm weights
+        return 1.0 + 0.1 * r
+    fan_in = 1                                     # linear / conv weights: ~1/sqrt(fan_in)
+    for v in shape[1:]:
+        fan_in *= v
+    return r / math.sqrt(fan_in)
+
+
 def seeded_state_dict(shapes: Dict[str, tuple], seed: int, dtype=torch.float32) -> Dict[str, Tensor]:
-    """Deterministic random weights (CPU generator; same torch build here and on the GPU box).
-    Scales keep activations O(1); nothing is left at the reference's zero-init (FX.py:1172-1188,
-    VAE.py:258) so every path contributes to the output."""
+    """Deterministic random weights (CPU generator; same torch build here and on the GPU box): ONE generator walked over the
+    sorted names (the goldens' checksums depend on exactly this order)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
     for name in sorted(shapes):
         shape = shapes[name]
         r = torch.randn(shape, generator=g, dtype=torch.float32)
-        if name.endswith("gamma"):
-            w = 1.0 + 0.1 * r
-        elif name.endswith(".bias"):
-            w = 0.05 * r
-        elif "modulation" in name:
-            w = r / math.sqrt(shape[-1])
-        elif len(shape) == 1:                      # norm weights
-            w = 1.0 + 0.1 * r
-        else:                                      # linear / conv weights: ~1/sqrt(fan_in)
-            fan_in = 1
-            for v in shape[1:]:
-                fan_in *= v
-            w = r / math.sqrt(fan_in)
-        sd[name] = w.to(dtype)
+        sd[name] = _seeded_tensor(name, shape, r).to(dtype)
     return sd
+
+
+def seeded_state_dict_threaded(shapes: Dict[str, tuple], seed: int, threads: int = 16) -> Dict[str, Tensor]:
+    """The same scale rule with ONE generator PER TENSOR (seeded by (seed, position in the sorted names)) so the tensors can be drawn
+    on a thread pool: the 5 B parameters of the full-depth model in seconds instead of half a minute.  Not bit-equal to
+    seeded_state_dict() -- a different, equally deterministic draw; no golden depends on it."""
+    from concurrent.futures import ThreadPoolExecutor
+    names = sorted(shapes)
+
+    def draw(i):
+        g = torch.Generator().manual_seed(seed * 1000003 + i)
+        r = torch.randn(shapes[names[i]], generator=g, dtype=torch.float32)
+        return _seeded_tensor(names[i], shapes[names[i]], r)
+    with ThreadPoolExecutor(threads) as ex:
+        vals = list(ex.map(draw, range(len(names))))
+    return dict(zip(names, vals))
 
 
 DIT_5B = dict(model_type="ti2v", patch_size=(1, 2, 2), text_len=512, in_dim=148, dim=3072, ffn_dim=14336,

@@ -347,3 +347,104 @@ def test_cfg_half_groups_are_created_once_per_member_set():
     for seen in res:
         assert max(n for _, _, n in seen) == 2 and seen[-1][2] == 2
         assert [c for c, _, _ in seen[:6]] == [2, 2, 1, 1, 2, 2]          # None -> the default for 4 ranks with the all-gather: 2 x 2
+
+
+# ----------------------------------------------------------------------------- r5: re-bound self-attention under sequence parallelism
+def _rebound_usp_forward(rank, world):
+    """The seam the engine offers blocks that are called as modules under sequence parallelism (DiTEngine._run_block_modules): the
+    block gets this rank's token chunk, global seq_lens / grid, and its `self_attn.forward` -- here a caller's own USP forward,
+    re-bound the way the reference does it (wan_transformer3d_FlexAM.py:807-815) -- reads group / rank / token offset from
+    flexam_amd.dist.current_sp_context() and exchanges K|V with all_gather_seq.  Compute = the fp32 oracle; two stacked blocks'
+    self-attention halves; equal to the whole-sequence result."""
+    from flexam_amd.dist import (all_gather_seq, chunk_bounds, current_sp_context, get_sequence_parallel_rank,
+                                 get_sequence_parallel_world_size, sequence_parallel_context)
+    g = torch.Generator().manual_seed(3)
+    b, heads, d = 2, 2, 256
+    grid = (3, 2, 4)
+    l = 24
+    x = torch.randn(b, l, d, generator=g)
+    layers = [dict(wq=torch.randn(d, d, generator=g) / 16, wk=torch.randn(d, d, generator=g) / 16, wv=torch.randn(d, d, generator=g) / 16,
+                   nq=1 + 0.1 * torch.randn(d, generator=g), nk=1 + 0.1 * torch.randn(d, generator=g)) for _ in range(2)]
+    ang = O.rope_angles(1024, 128)
+
+    def whole(xx, p):
+        q = O.rope_apply(O.rms_norm(xx @ p["wq"].t(), p["nq"], 1e-6).view(b, l, heads, 128), grid, ang)
+        k = O.rope_apply(O.rms_norm(xx @ p["wk"].t(), p["nk"], 1e-6).view(b, l, heads, 128), grid, ang)
+        return xx + O.attention(q, k, (xx @ p["wv"].t()).view(b, l, heads, 128)).flatten(2)
+    want = whole(whole(x, layers[0]), layers[1])
+    assert current_sp_context() is None and get_sequence_parallel_world_size() == world      # outside a forward: the world group
+
+    def usp_forward(xc, seq_lens, p):                      # a caller's re-bound forward: everything it needs is in the context
+        ctx = current_sp_context()
+        assert ctx["size"] == get_sequence_parallel_world_size() == world and ctx["rank"] == get_sequence_parallel_rank() == rank
+        lc, t0 = xc.shape[1], ctx["token_offset"]
+        assert lc * ctx["size"] == ctx["seq_len"] == int(seq_lens[0])
+        full_q = torch.zeros(b, l, heads, 128)
+        full_k = torch.zeros(b, l, heads, 128)
+        full_q[:, t0:t0 + lc] = O.rms_norm(xc @ p["wq"].t(), p["nq"], 1e-6).view(b, lc, heads, 128)
+        full_k[:, t0:t0 + lc] = O.rms_norm(xc @ p["wk"].t(), p["nk"], 1e-6).view(b, lc, heads, 128)
+        ql = O.rope_apply(full_q, grid, ang)[:, t0:t0 + lc]             # RoPE at the chunk's GLOBAL positions
+        kl = O.rope_apply(full_k, grid, ang)[:, t0:t0 + lc]
+        vl = (xc @ p["wv"].t()).view(b, lc, heads, 128)
+        kv = all_gather_seq(torch.cat([kl.flatten(2), vl.flatten(2)], dim=2), ctx["group"])
+        return xc + O.attention(ql, kv[:, :, :d].unflatten(2, (heads, 128)), kv[:, :, d:].unflatten(2, (heads, 128))).flatten(2)
+    s, e = chunk_bounds(l, rank, world)
+    xc = x[:, s:e].clone()
+    with sequence_parallel_context(None, rank, world, s, l):
+        for p in layers:
+            xc = usp_forward(xc, torch.tensor([l] * b), p)
+    assert current_sp_context() is None
+    out = all_gather_seq(xc)
+    return float((out - want).abs().max())
+
+
+def test_rebound_self_attention_forward_under_sequence_parallel_context():
+    errs = run_world(_rebound_usp_forward)
+    assert max(errs) < 5e-5, errs
+
+
+def _subgroups_after_reinit(rank, world):
+    """Round-4 advice: the sub-communicator cache must not hand out groups of a destroyed default process group."""
+    from flexam_amd.dist import clear_subgroups, live_subgroups, subgroup
+    g1 = subgroup([0, 1])
+    assert subgroup([0, 1]) is g1 and live_subgroups() == 1
+    port = int(os.environ["MASTER_PORT"])
+    dist.destroy_process_group()
+    os.environ["MASTER_PORT"] = str(port + 1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert live_subgroups() == 0                            # a new default group: the cache starts empty
+    g2 = subgroup([0, 1])
+    assert g2 is not g1
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t, group=g2)                           # and the new handle works
+    clear_subgroups()
+    assert live_subgroups() == 0
+    return float(t)
+
+
+def test_subgroup_cache_belongs_to_one_default_process_group():
+    assert run_world(_subgroups_after_reinit) == [3.0, 3.0]
+
+
+def test_loopback_group_collectives_keep_shapes_and_order():
+    """flexam_amd.dist.LoopbackGroup (bench.py --emulate-rank): one process as rank r of N, collectives = copies of the same sizes.
+    On CPU tensors the copies are synchronous; shapes, slot order and the Work protocol are what is under test."""
+    from flexam_amd.dist import (LoopbackGroup, SeqGather, all_gather_into_tensor, all_gather_seq, all_to_all_blocks, group_backend,
+                                 group_rank, group_size)
+    g = LoopbackGroup(4, rank=2)
+    assert (group_size(g), group_rank(g), group_backend(g)) == (4, 2, "loopback")
+    loc = torch.arange(2 * 3 * 5, dtype=torch.float32).view(2, 3, 5)
+    out = all_gather_seq(loc, g)
+    assert out.shape == (2, 12, 5)
+    for r in range(4):
+        assert torch.equal(out[:, r * 3:(r + 1) * 3], loc)
+    flat = torch.empty(4 * 6, 5)
+    w = all_gather_into_tensor(flat, loc.view(6, 5), group=g, async_op=True)
+    assert w.wait() and torch.equal(flat.view(4, 6, 5)[3], loc.view(6, 5))
+    sg = SeqGather(loc[:1], g)
+    assert torch.equal(sg.finish()[:, 9:12], loc[:1])
+    ins = [torch.full((2, 2), float(i)) for i in range(4)]
+    outs = [torch.empty(2, 2) for _ in range(4)]
+    assert all_to_all_blocks(outs, ins, g) is None and all(float(o[0, 0]) == i for i, o in enumerate(outs))
+    with pytest.raises(ValueError):
+        LoopbackGroup(2, rank=2)

@@ -1,0 +1,199 @@
+"""Parity at FULL DEPTH x FULL WIDTH, and with softmax rows that have PEAKS (round-4 verdict, item 1).
+
+(a) BASELINE configs[0] on the REAL model shape: latent [1,48,3,16,16] (9 x 256 x 256), d = 3072 / 24 heads / ffn 14336 / text
+    512 x 4096, all 30 layers (5.03 B parameters), 4 Euler steps, CFG pair -- the HIP sampler vs oracle.sampler.denoise_loop over
+    oracle.dit.dit_forward (= PIPE.py:840-949 over FX.py:1053-1089), every step's latents compared.
+(b) The same models with `self_attn.norm_q / norm_k` scaled so q.k / sqrt(128) has std 6 instead of 1 (oracle.cases.
+    scale_self_attention_logits): rows whose maximum lies 25-40 exp2 units above their mean, 2-3 effective keys per row, the
+    attention branch a visible part of the residual stream, and the kernel's deferred-rescale branch (attn.hip: `any(lane max >
+    2^8)`) taken in most rows -- on N(0, 1) logits it never is.  3 layers (4-step sampler + one forward at L = 2912) and 30 layers.
+
+Stated tolerance: bf16 operands, fp32 accumulation / softmax / residual stream -> PSNR >= 40 dB and rel-RMS <= 2.5e-2 on every
+step's latents (north_star's figure); the quantised variants (fp8 QKV / FFN GEMMs, MXFP8 self-attention) are MEASURED and held to
+their own stated bounds below.  The 5 B-parameter state dict is drawn once per module (thread pool, one generator per tensor)."""
+import gc
+import math
+import os
+
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import dit as O
+from oracle import sampler as S
+
+pytestmark = pytest.mark.gpu
+CFG_5B = dict(O.DIT_5B)
+LOGIT_STD = 6.0
+LAYERS_FULL = int(os.environ.get("FLEXAM_TEST_FULL_DEPTH_LAYERS", "30"))      # dry runs of this file's host side on a small box
+
+
+def stats(got, want, what, rel_max, psnr_min):
+    got, want = got.float().cpu(), want.float().cpu()
+    rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    p = C.psnr(got, want)
+    print(f"{what}: rel-rms {rel:.3e}, psnr {p:.1f} dB")
+    assert rel <= rel_max and p >= psnr_min, f"{what}: rel-rms {rel:.3e}, psnr {p:.1f} dB"
+    return rel, p
+
+
+def _model(cfg, sd):
+    """The drop-in class with `sd` loaded straight onto the GPU (fp32 parameters as drawn; the engine packs its bf16 operands
+    from them -- no second host copy of the 20 GB)."""
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+    kw = dict(cfg)
+    kw.pop("eps")
+    with torch.device("cuda:0"):
+        m = Wan2_2Transformer3DModel_FlexAM(**kw)
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def _set_logit_std(sd, m, base, std):
+    """norm_q / norm_k of every self-attention = base * sqrt(std), in the oracle's state dict and in the model's parameters
+    (in-place copies bump the version counters -> the engine re-packs)."""
+    with torch.no_grad():
+        params = dict(m.named_parameters())
+        for k, v in base.items():
+            sd[k].copy_(v * math.sqrt(std))
+            params[k].copy_(sd[k])
+
+
+def _norm_names(sd):
+    return [k for k in sd if ".self_attn.norm_q.weight" in k or ".self_attn.norm_k.weight" in k]
+
+
+def _sampler_traces(m, sd, cfg, steps, variants=("bf16",)):
+    """HIP sampler per variant and ONE oracle loop on BASELINE config 1's clip: lists of per-step latents."""
+    from flexam_amd import Wan2_2FunControlPipeline_FlexAM
+    from flexam_amd.pipeline_wan2_2_fun_control_FlexAM import LatentConditioning
+    sc = C.sampler_case(cfg)
+    cond = LatentConditioning(sc["control_latents"], sc["additional_control"], sc["masked_video_latents"], sc["ref_latents"], sc["mask_pixels"])
+    got = {}
+    for v in variants:
+        m.enable_fp8_gemm(v in ("fp8", "fp8+sage"))
+        if "sage" in v:
+            os.environ["VIDEOX_ATTENTION_TYPE"] = "SAGE_ATTENTION"
+        try:
+            pipe = Wan2_2FunControlPipeline_FlexAM(transformer=m)
+            trace = []
+            pipe(prompt_embeds=sc["context_cond"], negative_prompt_embeds=sc["context_uncond"], height=256, width=256, num_frames=9,
+                 num_inference_steps=steps, guidance_scale=6.0, density=0.1, latents=sc["latents"], conditioning=cond, output_type="latent",
+                 callback_on_step_end=lambda p, i, t, k: trace.append(k["latents"].float().cpu().clone()))
+            if v in ("fp8", "fp8+sage"):
+                assert m.engine().fp8
+        finally:
+            os.environ.pop("VIDEOX_ATTENTION_TYPE", None)
+            m.enable_fp8_gemm(False)
+        got[v] = trace
+    ml, mask, pinned = S.prepare_masks(sc["mask_pixels"], sc["latents"])
+    ref_trace = []
+    with torch.no_grad():
+        S.denoise_loop(lambda **k: O.dit_forward(sd, cfg, **k), S.FlowMatchEulerSchedule(1000, 5.0), steps, sc["latents"],
+                       sc["context_uncond"], sc["context_cond"], sc["control_latents"], sc["additional_control"], ml,
+                       sc["masked_video_latents"], sc["ref_latents"], mask, pinned, 0.1, 6.0, trace=ref_trace)
+    return got, ref_trace
+
+
+def _row_stats(sd, cfg, case, what):
+    st = C.self_attention_row_stats(sd, cfg, case)
+    over = st.pop("over_first_tile")
+    frac = (over > 8.0).float().mean().item()
+    print(f"{what}: block-0 self-attention rows (exp2 units): std {st['std']:.2f}, max - mean {st['max_minus_mean']:.1f}, "
+          f"effective keys {st['n_eff']:.1f} of {st['keys']}, rows whose maximum is > 8 above their first 64 keys' maximum: {frac:.2f}")
+    return st, frac
+
+
+# ----------------------------------------------------------------------------- 30 layers x d = 3072
+@pytest.fixture(scope="module")
+def full_model():
+    cfg = dict(CFG_5B, num_layers=LAYERS_FULL)
+    sd = C.dit_weights_threaded(cfg, 101)
+    m = _model(cfg, sd)
+    base = {k: sd[k].clone() for k in _norm_names(sd)}
+    yield cfg, sd, m, base
+    del m, sd
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_config0_full_depth_full_width_sampler_vs_oracle_loop(full_model):
+    """(a): BASELINE configs[0] at the real depth and width, every Euler step compared."""
+    cfg, sd, m, base = full_model
+    _set_logit_std(sd, m, base, 1.0)
+    assert sum(p.numel() for p in m.parameters()) > (5.0e9 if LAYERS_FULL == 30 else 0)
+    got, ref = _sampler_traces(m, sd, cfg, steps=4)
+    ps = [C.psnr(a, b) for a, b in zip(got["bf16"], ref)]
+    print(f"{LAYERS_FULL} layers x d=3072 x 4 steps: psnr after steps 1..4:", [round(x, 1) for x in ps])
+    assert len(ps) == 4
+    stats(got["bf16"][-1], ref[-1], f"configs[0], {LAYERS_FULL} layers, final latents", rel_max=2.5e-2, psnr_min=40.0)
+    assert min(ps) >= 40.0
+
+
+def test_full_depth_peaked_softmax_two_steps(full_model):
+    """(b) at 30 layers: logit std 6, 2 Euler steps (4 CFG-pair forwards of the oracle), bf16 held to 40 dB; the quantised variants
+    are reported and held to their stated bounds (fp8 GEMMs: >= 30 dB; + MXFP8 self-attention: >= 25 dB -- e4m3 scores of std 8 carry
+    2^-4 relative steps into the exponent)."""
+    cfg, sd, m, base = full_model
+    _set_logit_std(sd, m, base, LOGIT_STD)
+    try:
+        sc = C.sampler_case(cfg)
+        case = C.dit_case(cfg, 16, frames=3, h=16, w=16, batch=1, text_lens=(9,))
+        st, frac = _row_stats(sd, cfg, case, "30-layer model, L = 256")
+        assert st["std"] >= 6.0 and st["max_minus_mean"] >= 18.0 and st["n_eff"] <= 8.0 and frac >= 0.05
+        got, ref = _sampler_traces(m, sd, cfg, steps=2, variants=("bf16", "fp8", "fp8+sage"))
+        for v, (rel_max, psnr_min) in dict(bf16=(2.5e-2, 40.0), fp8=(1.0e-1, 30.0)).items():
+            ps = [C.psnr(a, b) for a, b in zip(got[v], ref)]
+            print(f"peaked rows, {LAYERS_FULL} layers, {v}: psnr after steps 1, 2:", [round(x, 1) for x in ps])
+            stats(got[v][-1], ref[-1], f"peaked rows, {LAYERS_FULL} layers x 2 steps, {v}", rel_max=rel_max, psnr_min=psnr_min)
+        ps = [C.psnr(a, b) for a, b in zip(got["fp8+sage"], ref)]
+        print(f"peaked rows, {LAYERS_FULL} layers, fp8 GEMMs + MXFP8 self-attention: psnr after steps 1, 2:", [round(x, 1) for x in ps])
+        assert min(ps) >= 25.0
+    finally:
+        _set_logit_std(sd, m, base, 1.0)
+
+
+# ----------------------------------------------------------------------------- 3 layers x d = 3072, peaked rows
+@pytest.fixture(scope="module")
+def three_layer_peaked():
+    cfg = dict(CFG_5B, num_layers=3)
+    sd = C.dit_weights(cfg, 5)                         # the weights of test_full_width_gpu.py's three-layer cases ...
+    C.scale_self_attention_logits(sd, LOGIT_STD)       # ... with peaked self-attention rows
+    m = _model(cfg, sd)
+    yield cfg, sd, m
+    del m, sd
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def test_three_layers_peaked_softmax_sampler(three_layer_peaked):
+    """(b) at 3 layers: configs[0]'s clip, 4 Euler steps, every variant against one oracle loop."""
+    cfg, sd, m = three_layer_peaked
+    got, ref = _sampler_traces(m, sd, cfg, steps=4, variants=("bf16", "sage", "fp8", "fp8+sage"))
+    bounds = {"bf16": 40.0, "sage": 30.0, "fp8": 35.0, "fp8+sage": 28.0}
+    for v, trace in got.items():
+        ps = [C.psnr(a, b) for a, b in zip(trace, ref)]
+        print(f"peaked rows, 3 layers x 4 steps, {v}: psnr after steps 1..4:", [round(x, 1) for x in ps])
+        assert min(ps) >= bounds[v], (v, ps)
+    stats(got["bf16"][-1], ref[-1], "peaked rows, 3 layers x 4 steps, bf16 final latents", rel_max=2.5e-2, psnr_min=40.0)
+
+
+def test_three_layers_peaked_softmax_forward_at_2912_tokens(three_layer_peaked):
+    """(b): one forward on a [2,48,25,16,28] latent (L = 2912: 46 key tiles per row, the per-rank token count at 8 GPUs): the reference of
+    nearly every row moves several times."""
+    cfg, sd, m = three_layer_peaked
+    case = C.dit_case(cfg, 16, frames=25, h=16, w=28, batch=2, text_lens=(77, 126))
+    st, frac = _row_stats(sd, cfg, case, "3-layer model, L = 2912")
+    assert st["std"] >= 6.0 and st["max_minus_mean"] >= 25.0 and st["n_eff"] <= 8.0 and frac >= 0.25
+    dcase = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    out = m(**dcase).float().cpu()
+    os.environ["VIDEOX_ATTENTION_TYPE"] = "SAGE_ATTENTION"
+    try:
+        out8 = m(**dcase).float().cpu()
+    finally:
+        os.environ.pop("VIDEOX_ATTENTION_TYPE")
+    with torch.no_grad():
+        want = O.dit_forward(sd, cfg, **case)
+    stats(out, want, "peaked rows, three-layer 5B-width model, L = 2912, bf16", rel_max=2.5e-2, psnr_min=40.0)
+    assert not torch.equal(out8, out)
+    stats(out8, want, "peaked rows, three-layer 5B-width model, L = 2912, MXFP8 self-attention", rel_max=2.0e-1, psnr_min=28.0)

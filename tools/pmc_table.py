@@ -4,7 +4,9 @@ the kernel trace, and the derived figures the roofline lines quote:
   GB/s        = hbm_bytes / average duration
   mfma_busy   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
   clock_ghz   = GRBM_GUI_ACTIVE / 8 / duration
-usage: pmc_table.py <dir> [--json out.json]"""
+usage: pmc_table.py <dir> [--json out.json] [--attn-traffic out.json [record-name]]
+  --attn-traffic: the self-attention call's HBM bytes per launch (attn_fwd_kernel + attn_merge_kernel) with the sha of the attention
+  sources they were measured on -> profiles/head_attn_traffic.json, the only file bench.py's roofline.traffic reads"""
 import collections, csv, glob, json, subprocess, sys
 root = sys.argv[1]
 
@@ -59,3 +61,23 @@ for k, row in table.items():
     print("   ", row["counters"])
 if "--json" in sys.argv:
     json.dump(table, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+
+if "--attn-traffic" in sys.argv:
+    import os
+    i = sys.argv.index("--attn-traffic")
+    dst = sys.argv[i + 1]
+    record = sys.argv[i + 2] if len(sys.argv) > i + 2 and not sys.argv[i + 2].startswith("--") else os.path.basename(root.rstrip("/"))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    from benchlib.kernels import attn_source_sha
+    main = [k for k in table if "attn_fwd_kernel<0, true, true>" in k.replace("(anonymous namespace)::", "") or "attn_fwd_kernel<0,true,true>" in k.replace(" ", "")]
+    merge = [k for k in table if "attn_merge_kernel" in k]
+    if not main or "hbm_bytes" not in table[main[0]]:
+        sys.exit("pmc_table --attn-traffic: no attn_fwd_kernel<0, true, true> row with FETCH_SIZE / WRITE_SIZE in " + root)
+    b = table[main[0]]["hbm_bytes"] + (table[merge[0]].get("hbm_bytes", 0) if merge else 0)
+    json.dump({"kernel": "one self-attention call = ONE attn_fwd_kernel<0, true, true> launch + attn_merge_kernel", "hbm_bytes_per_launch": b,
+               "parts": {main[0]: table[main[0]]["hbm_bytes"], **({merge[0]: table[merge[0]].get("hbm_bytes", 0)} if merge else {})},
+               "gfx950_fetch_correction": 2.0, "algorithmic_bytes_per_launch": 2 * 11648 * 24 * 128 * 2 * 4, "shape": [2, 11648, 24, 128],
+               "source_sha16": attn_source_sha(repo), "record": record,
+               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/pmc_pass.sh over tools/kernel_driver.py), mean per dispatch"},
+              open(dst, "w"), indent=1)
