@@ -191,6 +191,66 @@ __global__ __launch_bounds__(256) void dupup_add_kernel(float* __restrict__ xm, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// rows [T, 2C] -> padded image of 2T frames at the SAME resolution: frame 2t + s takes channels [s*C, (s+1)*C) of src frame t
+// (the temporal half of Resample upsample3d, wan_vae3_8.py:153-156, without the spatial upsample: the phase-decomposed
+// convolution below reads the low-resolution frames directly)
+// ------------------------------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void deinterleave_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
+                                                           bf16* __restrict__ dst, int Cp) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int cvec = C >> 2;
+  const int64_t total = (int64_t)2 * T * H * W * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cvec) * 4;
+    int64_t r = i / cvec;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int to = (int)(r / H);
+    const int64_t pos = (((int64_t)(to >> 1) * Hp + h + 1) * Wp + w + 1);
+    const TI* s = src + pos * lds_ + (to & 1) * C + c;
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f2bf(ld(s + j));
+    *(bf16x4*)(dst + (((int64_t)to * Hp + h + 1) * Wp + w + 1) * Cp + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// x_main[(t', h', w'), co] = phase[(h' & 1) * 2 + (w' & 1)][(t', h' >> 1, w' >> 1), co] + DupUp3D(x_in)   (see dupup_add_kernel)
+// The four phase matrices are the outputs of the phase-decomposed "nearest 2x upsample + 3x3 convolution": output pixels of
+// parity (a, b) are a 2x2 convolution of the LOW-resolution image with pre-summed taps, so the upsampled image is never built
+// and the convolution costs 16 instead of 36 tap products per low-resolution pixel.  x_main is written, not accumulated.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void phase_dupup_kernel(const float* __restrict__ ph, int64_t ldp, int64_t phase_stride,
+                                                          float* __restrict__ xm, int64_t ldm, int Co, int To, int Ho, int Wo,
+                                                          const float* __restrict__ xin, int64_t ldi, int Ci, int ft, int drop) {
+  const int H = Ho / 2, W = Wo / 2;
+  const int Hp = H + 2, Wp = W + 2, Hop = Ho + 2, Wop = Wo + 2;
+  const int repeats = Co * ft * 4 / Ci;
+  const int cvec = Co >> 2;
+  const int64_t total = (int64_t)To * Ho * Wo * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % cvec) * 4;
+    int64_t r = i / cvec;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int to = (int)(r / Ho);
+    const int tt = to + drop;
+    const int t = tt / ft, st = tt - t * ft;
+    const float* xi = xin + (((int64_t)t * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldi;
+    const int sub = st * 4 + (ho & 1) * 2 + (wo & 1);
+    const float* pp = ph + (int64_t)((ho & 1) * 2 + (wo & 1)) * phase_stride + (((int64_t)to * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldp + co;
+    f32x4 x = __builtin_nontemporal_load((const f32x4*)pp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] += xi[((co + j) * ft * 4 + sub) / repeats];
+    *(f32x4*)(xm + (((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + co) = x;
+  }
+}
+
 // row softmax(scale * s) fp32 -> bf16 (zero padded to ldo columns); one 256-thread block per row
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds_, int N, float scale,
                                                            bf16* __restrict__ out, int64_t ldo, int Npad) {
@@ -391,6 +451,30 @@ extern "C" int flexam_dupup_add_cl(float* x_main, int64_t ld_main, int Co, int T
   hipLaunchKernelGGL(dupup_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
                      Co, To, Ho, Wo, x_in, ld_in, Ci, ft, drop);
   return flexam_check_launch("flexam_dupup_add_cl");
+}
+
+extern "C" int flexam_deinterleave_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, void* dst, int Cp,
+                                      void* stream) {
+  FX_REQUIRE(src && dst, FLEXAM_E_ARG, "deinterleave_cl: null pointer");
+  FX_REQUIRE(C % 4 == 0 && C <= Cp && Cp % 4 == 0 && 2 * C <= ld_src && T > 0 && H > 0 && W > 0, FLEXAM_E_SHAPE,
+             "deinterleave_cl: C=%d must be a multiple of 4 and 2C <= ld_src=%ld", C, (long)ld_src);
+  const int64_t total = (int64_t)2 * T * H * W * (C / 4);
+  if (src_is_bf16)
+    hipLaunchKernelGGL(deinterleave_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cp);
+  else
+    hipLaunchKernelGGL(deinterleave_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, (bf16*)dst, Cp);
+  return flexam_check_launch("flexam_deinterleave_cl");
+}
+
+extern "C" int flexam_phase_dupup_cl(const float* phases, int64_t ld_ph, int64_t phase_stride, float* x_main, int64_t ld_main, int Co, int To,
+                                     int Ho, int Wo, const float* x_in, int64_t ld_in, int Ci, int ft, int drop, void* stream) {
+  FX_REQUIRE(phases && x_main && x_in, FLEXAM_E_ARG, "phase_dupup_cl: null pointer");
+  FX_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0 && (ft == 1 || ft == 2) && (Co * ft * 4) % Ci == 0, FLEXAM_E_SHAPE, "phase_dupup_cl: bad shape");
+  FX_REQUIRE(Co % 4 == 0 && ld_main % 4 == 0 && ld_ph % 4 == 0 && phase_stride % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)phases % 16 == 0,
+             FLEXAM_E_SHAPE, "phase_dupup_cl: Co, ld_main, ld_ph and phase_stride must be multiples of 4");
+  hipLaunchKernelGGL(phase_dupup_kernel, dim3(grid_for((int64_t)To * Ho * Wo * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, phases, ld_ph,
+                     phase_stride, x_main, ld_main, Co, To, Ho, Wo, x_in, ld_in, Ci, ft, drop);
+  return flexam_check_launch("flexam_phase_dupup_cl");
 }
 
 extern "C" int flexam_softmax_rows(const float* s, int64_t ld_s, int64_t M, int N, float scale, void* out, int64_t ld_out, int Npad,

@@ -2,9 +2,11 @@
 `get_sampling_sigmas`, `retrieve_timesteps`.
 
 Reference: FlexAM/utils/fm_solvers.py:22-66 (helpers), :69-856 (scheduler: set_timesteps :226-290, first / second /
-third order updates :415-677, step :706-798).  Supported configuration (what the reference's configs select):
-algorithm_type "dpmsolver++" (deterministic), solver_type midpoint | heun, orders 1-3, flow_prediction, final sigma
-zero, no thresholding / dynamic shifting; the SDE variants and "dpmsolver" raise NotImplementedError.
+third order updates :415-677, step :706-798).  Supported configuration = everything the reference class itself can run:
+algorithm_type "dpmsolver++" (orders 1-3) and "sde-dpmsolver++" (orders 1-2; its noise is drawn from the caller's generator the way
+the reference draws it), solver_type midpoint | heun, flow_prediction, final sigma zero, with or without dynamic thresholding.
+"dpmsolver" / "sde-dpmsolver" raise NotImplementedError here; in the reference they die in set_timesteps (their mandatory
+final_sigmas_type "sigma_min" reads an `alphas_cumprod` the flow scheduler never defines, fm_solvers.py:148-175, 249-275).
 
 As for UniPC (fm_solvers_unipc.py) every update is a linear combination of the sample and the stored x0
 predictions: coefficients on the host in float64, ONE `flexam_lincomb_f32` launch per conversion and per update.

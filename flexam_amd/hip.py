@@ -59,6 +59,8 @@ _SIGNATURES = {
     "flexam_vae_prep_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _P], c_int),
     "flexam_upsample2x_cl": ([_P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P], c_int),
     "flexam_dupup_add_cl": ([_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _P], c_int),
+    "flexam_deinterleave_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _P], c_int),
+    "flexam_phase_dupup_cl": ([_P, _L, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _P], c_int),
     "flexam_softmax_rows": ([_P, _L, _L, _I, _F, _P, _L, _I, _P], c_int),
     "flexam_scatter_add_cl": ([_P, _L, _P, _L, _I, _I, _I, _I, _P], c_int),
     "flexam_vae_unpatchify_clamp": ([_P, _L, _I, _I, _I, _P, _I, _I, _F, _F, _P], c_int),
@@ -395,6 +397,22 @@ def attn_fp8_buffers(B, H, L, device):
             torch.zeros(B, H, tiles, ATTN8_REC_BYTES, device=device, dtype=torch.uint8))      # zeros: rmsnorm_rope_mx never writes the padding rows
 
 
+def _check_fp8_bufs(bufs, B, H, L, device, who):
+    """The MXFP8 operand buffers are raw byte images the C side cannot size-check: refuse anything that is not what attn_fp8_buffers(B,
+    H, L) makes (shape, dtype, device, contiguity) -- a buffer set of another (B, L) would be out-of-bounds device traffic, not an
+    error.  The kernels also rely on the padding rows past L staying zero, which attn_fp8_buffers' torch.zeros guarantees and nothing
+    here ever writes."""
+    if not isinstance(bufs, (tuple, list)) or len(bufs) != 3:
+        raise RuntimeError(f"{who}: bufs must be the (q8, qs, kv8) triple of attn_fp8_buffers")
+    q8, qs, kv8 = bufs
+    lp, tiles = -(-L // 256) * 256, -(-L // 64)
+    want = ((q8, (B, H, lp, 128), torch.uint8), (qs, (B, H, lp), torch.int32), (kv8, (B, H, tiles, ATTN8_REC_BYTES), torch.uint8))
+    for t, shape, dt in want:
+        if tuple(t.shape) != shape or t.dtype != dt or not t.is_contiguous() or t.device != torch.device(device):
+            raise RuntimeError(f"{who}: operand buffers are not attn_fp8_buffers(B={B}, H={H}, L={L}) on {device}: got {tuple(t.shape)} {t.dtype} "
+                               f"on {t.device}, want {shape} {dt}")
+
+
 def attn_fp8_pack(q, k, v, bufs=None):
     """q, k, v [B, L, H, 128] bf16 (q prescaled by softmax_scale * log2 e) -> the MXFP8 operand buffers of attn_fwd_fp8."""
     B, L, H, D = v.shape
@@ -405,9 +423,8 @@ def attn_fp8_pack(q, k, v, bufs=None):
         raise RuntimeError("attn_fp8_pack: q and k go together (both None: V only, after rmsnorm_rope_mx)")
     if bufs is None:
         bufs = attn_fp8_buffers(B, H, L, v.device)
+    _check_fp8_bufs(bufs, B, H, L, v.device, "attn_fp8_pack")
     q8, qs, kv8 = bufs
-    if q8.shape[:3] != (B, H, -(-L // 256) * 256) or kv8.shape[:3] != (B, H, -(-L // 64)):
-        raise RuntimeError("attn_fp8_pack: buffers of another shape")
     qk = (lambda t: (t.stride(0), t.stride(1))) if q is not None else (lambda t: (0, 0))
     _check(lib().flexam_attn_fp8_pack(_ptr(q, BF16), *qk(q), _ptr(k, BF16), *qk(k), _ptr(v, BF16),
                                       v.stride(0), v.stride(1), q8.data_ptr(), qs.data_ptr(), kv8.data_ptr(), B, H, L, D, _stream()),
@@ -419,6 +436,9 @@ def rmsnorm_rope_mx(q, wq, k, wk, bufs, rope_cos, rope_sin, tokens_per_batch, to
     """RMSNorm + RoPE of q and k ([M, 3072] bf16 views) written as the MXFP8 operands of attn_fwd_fp8 (Q rows, K image and scales);
     the V half of `bufs` comes from attn_fp8_pack(None, None, v, bufs)."""
     M, C, ldq = _rows(q)
+    if tokens_per_batch <= 0 or M % tokens_per_batch or C != heads * 128:
+        raise RuntimeError(f"rmsnorm_rope_mx: {M} rows of {C} columns do not tile batches of {tokens_per_batch} tokens x {heads} heads x 128")
+    _check_fp8_bufs(bufs, M // tokens_per_batch, heads, tokens_per_batch, q.device, "rmsnorm_rope_mx")
     q8, qs, kv8 = bufs
     _check(lib().flexam_rmsnorm_rope_mx(_ptr(q, BF16), ldq, _ptr(wq, F32), _ptr(k, BF16), k.stride(0), _ptr(wk, F32), q8.data_ptr(),
                                         qs.data_ptr(), kv8.data_ptr(), M, C, eps, _ptr(rope_cos, F32), _ptr(rope_sin, F32),
@@ -430,10 +450,11 @@ def attn_fwd_fp8(bufs, L, out=None, kv_splits=None, split_from_unit=None):
     """Self-attention from packed MXFP8 operands (attn_fp8_pack) -> out [B, L, H, 128] bf16."""
     q8, qs, kv8 = bufs
     B, H, D = q8.shape[0], q8.shape[1], 128
+    _check_fp8_bufs(bufs, B, H, L, q8.device, "attn_fwd_fp8")
     if out is None:
         out = torch.empty(B, L, H, D, device=q8.device, dtype=BF16)
-    if out.stride(3) != 1 or out.stride(2) != D:
-        raise RuntimeError("attn_fwd_fp8: heads must be packed along the row")
+    if out.stride(3) != 1 or out.stride(2) != D or tuple(out.shape) != (B, L, H, D):
+        raise RuntimeError(f"attn_fwd_fp8: out must be [B={B}, L={L}, H={H}, 128] with heads packed along the row, got {tuple(out.shape)}")
     units = B * H * ((L + 255) // 256)
     if kv_splits is None:
         S, from_unit = attn_split_plan(B * H, L, L, num_cus())
@@ -684,6 +705,22 @@ def upsample2x_cl(src, C, T, H, W, dst, interleave=False):
 def dupup_add_cl(x_main, Co, To, Ho, Wo, x_in, Ci, ft, drop):
     _check(lib().flexam_dupup_add_cl(_ptr(x_main, F32), x_main.stride(0), Co, To, Ho, Wo, _ptr(x_in, F32), x_in.stride(0), Ci, ft, drop,
                                      _stream()), "flexam_dupup_add_cl")
+    return x_main
+
+
+def deinterleave_cl(src, C, T, H, W, dst):
+    """src rows [T*(H+2)*(W+2), 2C] -> dst padded image [2T, H+2, W+2, Cp]: frame 2t + s = channels [sC, (s+1)C) of frame t."""
+    _check(lib().flexam_deinterleave_cl(_ptr(src), 1 if src.dtype == BF16 else 0, src.stride(0), C, T, H, W, _ptr(dst, BF16), dst.shape[-1],
+                                        _stream()), "flexam_deinterleave_cl")
+    return dst
+
+
+def phase_dupup_cl(phases, x_main, Co, To, Ho, Wo, x_in, Ci, ft, drop):
+    """phases [4, rows of the padded (Ho/2, Wo/2) image, Co] fp32 -> x_main rows of the padded (Ho, Wo) image, + the DupUp3D shortcut of x_in."""
+    if phases.dim() != 3 or phases.shape[0] != 4 or phases.stride(2) != 1 or phases.shape[2] != Co:
+        raise RuntimeError("phase_dupup_cl: phases must be [4, rows, Co] fp32")
+    _check(lib().flexam_phase_dupup_cl(_ptr(phases, F32), phases.stride(1), phases.stride(0), _ptr(x_main, F32), x_main.stride(0), Co, To, Ho, Wo,
+                                       _ptr(x_in, F32), x_in.stride(0), Ci, ft, drop, _stream()), "flexam_phase_dupup_cl")
     return x_main
 
 

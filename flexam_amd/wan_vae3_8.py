@@ -220,7 +220,8 @@ class _Conv:
     def image(self, h, w):
         if self.shape != (h, w):
             hp, wp = h + 2, w + 2
-            frames = self.hist + self.t_cap * (self.RING if self.hist else 1)
+            ring = max(1, min(self.RING, 16 // max(self.t_cap, 1))) if self.hist else 1      # long chunks: fewer of them, and a short ring (memory)
+            frames = self.hist + self.t_cap * ring
             guard = _round_up((wp + 1) * self.cp + 64, 8)       # + the overrun of a packed run's last K block
             self.buf = torch.zeros(guard * 2 + frames * hp * wp * self.cp, device=self.device, dtype=BF16)
             self.all = self.buf[guard:guard + frames * hp * wp * self.cp].view(frames, hp, wp, self.cp)
@@ -319,9 +320,75 @@ class _ConvS2D:
             self.shape = (h2, w2)
         return self.img
 
-    def run(self, t, h2, w2, out_dtype=F32):
-        return hip.gemm(self.img.view(-1, 4 * self.cs), self.weight, self.bias, a_koff=self._koff, m=t * (h2 + 2) * (w2 + 2),
-                        k=self.weight.shape[1], out_dtype=out_dtype)
+    def run(self, t, h2, w2, out_dtype=F32, residual_into=None):
+        rows = t * (h2 + 2) * (w2 + 2)
+        if residual_into is not None:                  # residual_into[rows, Cout] += conv (fp32, in the GEMM epilogue)
+            return hip.gemm_gate_residual(self.img.view(-1, 4 * self.cs), self.weight, self.bias, residual_into[:rows], a_koff=self._koff)
+        return hip.gemm(self.img.view(-1, 4 * self.cs), self.weight, self.bias, a_koff=self._koff, m=rows, k=self.weight.shape[1], out_dtype=out_dtype)
+
+
+class _ConvUp2x:
+    """Nearest-exact 2x spatial upsample followed by Conv2d(3x3, padding 1) (Resample upsample2d / upsample3d, VAE.py:76-99) WITHOUT the
+    upsampled image.  Output pixel (2y + a, 2x + b) sees, through the 3x3 window on the upsampled image, only the 2x2 block of
+    LOW-resolution pixels (y - 1 + a + r, x - 1 + b + c), r, c in {0, 1}: rows 2y - 1 | 2y, 2y + 1 of the upsampled image are rows
+    y - 1 | y, y of the input (a = 0) and rows 2y, 2y + 1 | 2y + 2 are rows y, y | y + 1 (a = 1).  So every parity (a, b) is a 2x2
+    convolution of the low-resolution image with taps that are SUMS of the original ones (fp32 sums, rounded to bf16 once):
+        W'[a][r] = { a=0: (W[-1], W[0] + W[1]);  a=1: (W[-1] + W[0], W[1]) }   (the same along x)
+    -- four implicit GEMMs with K = 4 Cin over the low-resolution rows instead of one with K = 9 Cin over four times as many: 16
+    instead of 36 tap products per low-resolution pixel (2.25x fewer FLOPs: these convolutions were 10 % of a decode), a quarter of the
+    image bytes, and the zero border of the low-resolution image IS the convolution's zero padding (row 2H of the upsampled image
+    does not exist, neither does row H of the input).  The four outputs [4, rows, Cout] fp32 are interleaved into the high-
+    resolution residual stream by flexam_phase_dupup_cl together with the DupUp3D shortcut."""
+    SETS = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}        # (parity, r) -> original tap indices (dy + 1)
+
+    def __init__(self, weight, bias, device, t_cap: int):
+        w = weight.detach().to(device, F32)
+        co, ci, kh, kw = w.shape
+        assert (kh, kw) == (3, 3)
+        self.co, self.ci, self.cp = co, ci, _round_up(ci, 64)
+        self.weights = []
+        for a in (0, 1):
+            for b in (0, 1):
+                wp = torch.zeros(co, 2, 2, self.cp, device=device, dtype=F32)
+                for r in (0, 1):
+                    for c in (0, 1):
+                        wp[:, r, c, :ci] = sum(w[:, :, i, j] for i in self.SETS[(a, r)] for j in self.SETS[(b, c)])
+                # K order (r, channel block, c, 64): the two column taps of a row are consecutive K blocks on the same 64 channels (see _Conv)
+                wp = wp.view(co, 2, 2, self.cp // 64, 64).permute(0, 1, 3, 2, 4)
+                self.weights.append(wp.reshape(co, 4 * self.cp).to(BF16).contiguous())
+        self.bias = bias.detach().to(device, F32).contiguous()
+        self.t_cap, self.device, self.shape = t_cap, device, None
+        self.hist = 0
+
+    def image(self, h, w):
+        """h, w: INPUT (low) resolution.  Zero-bordered [t_cap, h + 2, w + 2, cp] with guard rows on both sides (the taps of the first
+        and last padded rows reach one row past the image)."""
+        if self.shape != (h, w):
+            hp, wp, cp = h + 2, w + 2, self.cp
+            guard = _round_up((wp + 1) * cp + 64, 8)
+            self.buf = torch.zeros(2 * guard + self.t_cap * hp * wp * cp, device=self.device, dtype=BF16)
+            self.img = self.buf[guard:guard + self.t_cap * hp * wp * cp].view(self.t_cap, hp, wp, cp)
+            self._koff = []
+            for a in (0, 1):
+                for b in (0, 1):
+                    offs = [((a + r - 1) * wp + (b + c - 1)) * cp + cb * 64 for r in (0, 1) for cb in range(cp // 64) for c in (0, 1)]
+                    self._koff.append(torch.tensor(offs, dtype=I64, device=self.device))
+            self.shape = (h, w)
+            self._ph = None
+        return self.img
+
+    def run(self, t, h, w):
+        """-> phases [4, t*(h+2)*(w+2), Cout] fp32 (rows of the padded LOW-resolution image; border rows hold garbage, never read)."""
+        rows = t * (h + 2) * (w + 2)
+        if self._ph is None or self._ph.shape[1] < rows:
+            self._ph = torch.empty(4, self.t_cap * (h + 2) * (w + 2), self.co, device=self.device, dtype=F32)
+        a = self.img.view(-1, self.cp)
+        for p in range(4):
+            hip.gemm(a, self.weights[p], self.bias, a_koff=self._koff[p], m=rows, k=4 * self.cp, out=self._ph[p, :rows])
+        return self._ph[:, :rows]
+
+    def reset(self):
+        pass
 
 
 class _EngineBase:
@@ -409,13 +476,19 @@ class _DecoderEngine(_EngineBase):
         self.z_dim, self.temporal_up = cfg["z_dim"], tuple(cfg["temporal_up"])
         dims = [cfg["dec_dim"] * m for m in [cfg["dim_mult"][-1]] + list(cfg["dim_mult"][::-1])]
         self.dims = dims
-        tmul = [1]
+        # Latent frames per chunk after the first (1-frame) chunk.  The reference decodes one latent frame at a time (VAE.py:1046-1052) to
+        # bound memory; the convolutions are causal over their own input history, so the output does not depend on the chunk length.
+        # Several latent frames per chunk fill the 32 x 56 / 64 x 112 stages (1972 / 15048 GEMM rows per latent frame: pure split-K
+        # launches at a third of the matrix rate) and cut the launch count.  FLEXAM_VAE_DEC_CHUNK=1 is the reference's walk.
+        self.chunk = n = max(1, int(os.environ.get("FLEXAM_VAE_DEC_CHUNK", "2")))
+        tmul = [n]
         for up in self.temporal_up:
             tmul.append(tmul[-1] * (2 if up else 1))                       # frames per chunk entering stage i
         conv, res = self._mk_conv, self._mk_res
+        self.phase_up = os.environ.get("FLEXAM_VAE_UPCONV", "phase") != "image"
         self.conv2 = conv("conv2")
-        self.conv1 = conv("decoder.conv1")
-        self.mid = [res("decoder.middle.0", 1), None, res("decoder.middle.2", 1)]
+        self.conv1 = conv("decoder.conv1", n)
+        self.mid = [res("decoder.middle.0", n), None, res("decoder.middle.2", n)]
         self.attn = self._mk_attn("decoder.middle.1", dims[0])
         self.stages = []
         n_stage = len(dims) - 1
@@ -424,7 +497,10 @@ class _DecoderEngine(_EngineBase):
             st = dict(res=[res(f"{p}.{j}", tmul[i]) for j in range(3)], up=i != n_stage - 1, cout=dims[i + 1])
             if st["up"]:
                 st["temporal"] = bool(self.temporal_up[i])
-                st["resample"] = conv(f"{p}.3.resample.1", tmul[i] * (2 if st["temporal"] else 1))
+                t_rs = tmul[i] * (2 if st["temporal"] else 1)
+                # FLEXAM_VAE_UPCONV=image: the earlier form (upsampled image + one 3x3 convolution over it), A/B and cross-check only
+                st["resample"] = (_ConvUp2x(sd[f"{p}.3.resample.1.weight"], sd[f"{p}.3.resample.1.bias"], dev, t_rs) if self.phase_up
+                                  else conv(f"{p}.3.resample.1", t_rs))
                 st["time_conv"] = conv(f"{p}.3.time_conv", tmul[i]) if st["temporal"] else None
             self.stages.append(st)
         self.head_gamma = self._f32(sd["decoder.head.0.gamma"], dev)
@@ -443,11 +519,10 @@ class _DecoderEngine(_EngineBase):
                 out.append(st["time_conv"])
         return out
 
-    def _chunk(self, src_rows, h, w, first, video, f0, stripe=None):
-        """Decoder3d.forward on one latent frame (VAE.py:677-728); writes 1 or 4 frames into `video`.
-        stripe = (cut, a, b): stages < cut run on full frames, then rows [a, b) of the activation entering stage
+    def _chunk(self, src_rows, h, w, first, video, f0, stripe=None, t=1):
+        """Decoder3d.forward on `t` latent frames (VAE.py:677-728; the first chunk is always the single first frame); writes 1 or 4 t
+        frames into `video`.  stripe = (cut, a, b): stages < cut run on full frames, then rows [a, b) of the activation entering stage
         `cut` are kept and everything after works on that row band (`video` is then the band's buffer)."""
-        t = 1
         c1 = self.conv1
         hip.vae_prep_cl(src_rows, c1.ci, t, h, w, c1.image(h, w), mode=0, t0=c1.hist)
         x = c1.run(t, h, w, out_dtype=F32)
@@ -461,7 +536,9 @@ class _DecoderEngine(_EngineBase):
                 band[:, 1:-1] = x.view(t, h + 2, w + 2, -1)[:, a + 1:b + 1]
                 x, h = band.view(-1, x.shape[1]), b - a
             x_in, cin = x, x.shape[1]
-            main = x.clone() if st["up"] else x
+            # the residual blocks update their input in place unless the first one has a shortcut convolution (a new tensor): only then
+            # does x_in survive without a copy for the DupUp3D shortcut below
+            main = x.clone() if (st["up"] and st["res"][0]["short"] is None) else x
             for r in st["res"]:
                 main = self._res(r, main, t, h, w)
             if not st["up"]:
@@ -469,18 +546,28 @@ class _DecoderEngine(_EngineBase):
                 continue
             co = st["cout"]
             rs = st["resample"]
+            ft = 2 if st["temporal"] else 1
+            y = None
             if st["temporal"] and not first:
                 tc = st["time_conv"]
                 hip.vae_prep_cl(main, co, t, h, w, tc.image(h, w), mode=0, t0=tc.hist)
-                y = tc.run(t, h, w, out_dtype=BF16)                                        # [rows, 2*co]
-                t2 = 2 * t
-                hip.upsample2x_cl(y, co, t, h, w, rs.image(2 * h, 2 * w), interleave=True)
+                y = tc.run(t, h, w, out_dtype=BF16)                                        # [rows, 2*co]: frames 2i | 2i + 1 side by side
+            t2 = 2 * t if y is not None else t
+            if self.phase_up:                     # 2x2 phase convolutions on the low-resolution frames (_ConvUp2x), then interleave + shortcut
+                if y is not None:
+                    hip.deinterleave_cl(y, co, t, h, w, rs.image(h, w))
+                else:
+                    hip.vae_prep_cl(main, co, t, h, w, rs.image(h, w), mode=0, t0=0)
+                ph = rs.run(t2, h, w)
+                out = torch.empty(t2 * (2 * h + 2) * (2 * w + 2), co, device=self.device, dtype=F32)      # border rows: never read
+                hip.phase_dupup_cl(ph, out, co, t2, 2 * h, 2 * w, x_in, cin, ft, (ft - 1) if first else 0)
             else:
-                t2 = t
-                hip.upsample2x_cl(main, co, t, h, w, rs.image(2 * h, 2 * w), interleave=False)
-            out = rs.run(t2, 2 * h, 2 * w, out_dtype=F32)
-            ft = 2 if st["temporal"] else 1
-            hip.dupup_add_cl(out, co, t2, 2 * h, 2 * w, x_in, cin, ft, (ft - 1) if first else 0)
+                if y is not None:
+                    hip.upsample2x_cl(y, co, t, h, w, rs.image(2 * h, 2 * w), interleave=True)
+                else:
+                    hip.upsample2x_cl(main, co, t, h, w, rs.image(2 * h, 2 * w), interleave=False)
+                out = rs.run(t2, 2 * h, 2 * w, out_dtype=F32)
+                hip.dupup_add_cl(out, co, t2, 2 * h, 2 * w, x_in, cin, ft, (ft - 1) if first else 0)
             x, t, h, w = out, t2, 2 * h, 2 * w
         hc = self.head_conv
         hip.vae_prep_cl(x, hc.ci, t, h, w, hc.image(h, w), mode=2, gamma=self.head_gamma, t0=hc.hist)
@@ -530,16 +617,20 @@ class _DecoderEngine(_EngineBase):
         frames = 1 + tfac * (tz - 1)
         if stripe is None or stripe[1] == 1:
             video = torch.empty(3, frames, h * scale * 2, w * scale * 2, device=self.device, dtype=F32)
-            f0 = 0
-            for i in range(tz):
-                f0 += self._chunk(x0[i * rows:(i + 1) * rows], h, w, i == 0, video, f0)
+            self._walk(x0, rows, tz, h, w, video, None)
             return video
         cut, a, b, lo, hi, sc = self.stripe_plan(h, *stripe)
         band = torch.empty(3, frames, (b - a) * sc, w * scale * 2, device=self.device, dtype=F32)
-        f0 = 0
-        for i in range(tz):
-            f0 += self._chunk(x0[i * rows:(i + 1) * rows], h, w, i == 0, band, f0, stripe=(cut, a, b))
+        self._walk(x0, rows, tz, h, w, band, (cut, a, b))
         return band[:, :, lo:hi].contiguous()
+
+    def _walk(self, x0, rows, tz, h, w, video, stripe):
+        """The chunk walk over the latent frames: frame 0 alone, then `self.chunk` frames at a time."""
+        f0, i = 0, 0
+        while i < tz:
+            t = 1 if i == 0 else min(self.chunk, tz - i)
+            f0 += self._chunk(x0[i * rows:(i + t) * rows], h, w, i == 0, video, f0, stripe=stripe, t=t)
+            i += t
 
 
 class _EncoderEngine(_EngineBase):
@@ -553,7 +644,13 @@ class _EncoderEngine(_EngineBase):
         self.temporal_down = tuple(cfg["temporal_down"])
         dims = [cfg["enc_dim"] * m for m in [1] + list(cfg["dim_mult"])]
         self.dims = dims
-        tcap = [4]
+        # Frames per chunk after the first (1-frame) chunk.  The reference walks the clip in chunks of 4 frames (VAE.py:1029-1037) to bound
+        # memory; every convolution here is causal over its own input history, so the result does not depend on where the chunks are cut
+        # (only on their being multiples of 4, which keeps the stride-2 time convolutions' frame pairs together).  Long chunks fill the
+        # GPU in the low-resolution stages -- at 4 frames the 64 x 112 stage launches 150 tiles and the 32 x 56 stage 24 on 256 CUs --
+        # and cut the launch count; 288 GB of HBM hold a whole 97-frame clip's activations.  FLEXAM_VAE_ENC_CHUNK=4 is the reference's walk.
+        self.chunk = max(4, int(os.environ.get("FLEXAM_VAE_ENC_CHUNK", "24")) // 4 * 4)
+        tcap = [self.chunk]
         for down in self.temporal_down:
             tcap.append(max(1, tcap[-1] // (2 if down else 1)))             # frames per chunk entering stage i
         tcap += [tcap[-1]] * (len(dims) - len(tcap))
@@ -602,14 +699,26 @@ class _EncoderEngine(_EngineBase):
         x = c1.run(t, h, w, out_dtype=F32)
         for st in self.stages:
             x_in, cin, t_in = x, x.shape[1], t
-            main = x.clone() if st["res"][0]["short"] is None else x
+            co = st["cout"]
+            # Stage 0 (same width in and out, spatial downsample only): the AvgDown3D shortcut is taken FIRST, into the buffer the
+            # stride-2 convolution then adds its result to (fp32 residual epilogue) -- the residual blocks can overwrite x in place, and
+            # neither a copy of x (0.3 GB per 4 frames at 256 x 448) nor a second pass over the downsampled rows is needed
+            fold = st["down"] and not st["temporal"] and st["res"][0]["short"] is None and cin == co
+            if fold:
+                short = torch.zeros(t * (h // 2 + 2) * (w // 2 + 2), co, device=self.device, dtype=F32)
+                hip.avgdown_add_cl(short, co, t, h // 2, w // 2, x_in, cin, t_in, 1, 2)
+                main = x
+            else:
+                main = x.clone() if st["res"][0]["short"] is None else x
             for r in st["res"]:
                 main = self._res(r, main, t, h, w)
-            co = st["cout"]
             if st["down"]:
                 ds = st["resample"]
                 h, w = h // 2, w // 2
                 hip.space_to_depth_cl(main, co, t, 2 * h, 2 * w, ds.image(h, w), ds.cs)
+                if fold:
+                    x = ds.run(t, h, w, residual_into=short)
+                    continue
                 main = ds.run(t, h, w, out_dtype=F32)
                 if st["temporal"]:
                     tc = st["time_conv"]
@@ -639,12 +748,14 @@ class _EncoderEngine(_EngineBase):
             cv.reset()
         video = x.to(self.device, F32).contiguous()
         h, w = hh // 2, ww // 2
-        outs, t_out = [], 0
-        for i in range(1 + (frames - 1) // 4):
-            f0, t = (0, 1) if i == 0 else (1 + 4 * (i - 1), 4)
-            rows, to, ho, wo = self._chunk(video, f0, t, h, w, i == 0)
+        frames = 1 + (frames - 1) // 4 * 4                 # trailing frames past 1 + 4k are not encoded (VAE.py:1029: iter_ = 1 + (t - 1) // 4)
+        outs, t_out, f0 = [], 0, 0
+        while f0 < frames:
+            t = 1 if f0 == 0 else min(self.chunk, frames - f0)
+            rows, to, ho, wo = self._chunk(video, f0, t, h, w, f0 == 0)
             outs.append(rows)
             t_out += to
+            f0 += t
         return hip.unpack_cl(torch.cat(outs) if len(outs) > 1 else outs[0], self.z2, t_out, ho, wo)
 
 

@@ -289,6 +289,16 @@ int flexam_upsample2x_cl(const void* src, int src_is_bf16, int64_t ld_src, int C
                          int Cp, void* stream);
 int flexam_dupup_add_cl(float* x_main, int64_t ld_main, int Co, int To, int Ho, int Wo, const float* x_in, int64_t ld_in, int Ci,
                         int ft, int drop, void* stream);
+/* Phase-decomposed "nearest 2x upsample + Conv2d 3x3" (Resample upsample2d / upsample3d, wan_vae3_8.py:76-99,153-160): output pixels of
+ * parity (a, b) are a 2x2 convolution of the LOW-resolution image with pre-summed taps -- four flexam_gemm_bf16 launches over the low-
+ * resolution image (16 instead of 36 tap products per low-resolution pixel; the upsampled image is never built).
+ * deinterleave_cl: rows [T, 2C] -> padded image of 2T frames at the same resolution, frame 2t + s = channels [sC, (s+1)C) of frame t
+ *   (the temporal half of upsample3d, :153-156).
+ * phase_dupup_cl: x_main[(t', h', w')] = phases[(h'&1)*2 + (w'&1)][(t', h'>>1, w'>>1)] + DupUp3D(x_in) (the shortcut of dupup_add_cl,
+ *   :375-417); phases = four [rows of the padded low-resolution image, Co] fp32 matrices `phase_stride` elements apart. */
+int flexam_deinterleave_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, void* dst, int Cp, void* stream);
+int flexam_phase_dupup_cl(const float* phases, int64_t ld_ph, int64_t phase_stride, float* x_main, int64_t ld_main, int Co, int To, int Ho,
+                          int Wo, const float* x_in, int64_t ld_in, int Ci, int ft, int drop, void* stream);
 int flexam_softmax_rows(const float* s, int64_t ld_s, int64_t M, int N, float scale, void* out, int64_t ld_out, int Npad, void* stream);
 int flexam_scatter_add_cl(float* x, int64_t ldx, const void* y, int64_t ldy, int C, int T, int H, int W, void* stream);
 int flexam_vae_unpatchify_clamp(const float* src, int64_t ld_src, int T, int H, int W, float* video, int Ftot, int f0, float lo,

@@ -2,24 +2,10 @@
 async K|V all-gather pieces and `device_id=` initialisation on real collectives.  Skipped on the one-GPU boxes of the build
 rounds; on an N-GPU box every case with world <= N runs.  Both layouts SURVEY 8(e) asks for: 2 CFG rows x N/2 token chunks
 (cfg_parallel None = the default) and pure N-way token chunks with the CFG pair batched (cfg_parallel False)."""
-import socket
-
 import pytest
 import torch
-import torch.multiprocessing as mp
-
-from oracle import cases as C
-from oracle import dit as O
 
 pytestmark = pytest.mark.gpu
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
 
 
 @pytest.mark.parametrize("world,cfg_parallel,mode", [
@@ -29,38 +15,17 @@ def _free_port():
 def test_ranks_under_rccl_match_single_process(world, cfg_parallel, mode, monkeypatch):
     if torch.cuda.device_count() < world:
         pytest.skip(f"needs >= {world} GPUs (RCCL refuses two ranks on one device)")
-    from test_sp_gpu import _wide_cfg, _worker
-    monkeypatch.setenv("FLEXAM_SP_MODE", mode.split("-")[0])
-    monkeypatch.setenv("FLEXAM_SP_OVERLAP", "0" if mode.endswith("-wait") else ("2" if mode.endswith("-o2") else "1"))   # -o2: attention per sample too
-    monkeypatch.setenv("FLEXAM_SP_PIECES", "1" if "-p1" in mode else "2")
+    from test_sp_gpu import rel_rms, ranks_agree, run_world, single_process
     monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sp = world // 2 if (cfg_parallel is None and world % 2 == 0 and (world == 2 or not mode.startswith("ulysses"))) else world
     wide = mode.startswith("ulysses") and sp > 2        # the all-to-all needs heads % ranks == 0: four 128-wide heads
     if wide and 4 % sp:
         pytest.skip("the four-head test model does not divide over this many sequence-parallel ranks")
-    port = _free_port()
-    ctx = mp.get_context("spawn")
-    ret = ctx.Manager().dict()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, cfg_parallel, wide, "nccl")) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
-    out0, lat0 = ret[0]
-    for r in range(1, world):
-        torch.testing.assert_close(out0, ret[r][0], rtol=0, atol=0)
-        torch.testing.assert_close(lat0, ret[r][1], rtol=0, atol=0)
-    from flexam_amd import Wan2_2Transformer3DModel_FlexAM
-    cfg = _wide_cfg() if wide else dict(O.DIT_TINY)
-    kw = dict(cfg)
-    kw.pop("eps")
-    m = Wan2_2Transformer3DModel_FlexAM(**kw)
-    m.load_state_dict(C.dit_weights(cfg, 7), strict=True)
-    m = m.to("cuda:0")
-    case = C.dit_case(cfg, 41, per_token_t=True)
-    d = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
-    single = m(**d).float().cpu()
-    rel = ((out0 - single).pow(2).mean().sqrt() / single.pow(2).mean().sqrt()).item()
+    case = (cfg_parallel, mode.replace("-o2", "-ov2"))                   # -o2: attention per sample too (FLEXAM_SP_OVERLAP=2)
+    # one spawned world per case here (on the one-GPU boxes test_sp_gpu.py batches the cases of a world): under real RCCL a hung case must
+    # not take the others with it
+    out0, lat0 = ranks_agree(run_world(world, [case], wide, backend="nccl"), case)
+    single, _ = single_process(wide)
+    rel = rel_rms(out0, single)
     print(f"RCCL {world} ranks, cfg_parallel={cfg_parallel}, {mode}: rel-rms vs single process {rel:.2e}")
     assert rel < 4e-3 and bool(torch.isfinite(lat0).all())

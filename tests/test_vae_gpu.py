@@ -134,3 +134,73 @@ def test_vae_decode_ring_wraps_are_consumed(frames, monkeypatch):
     torch.testing.assert_close(out, out1, rtol=0, atol=0)
     # last frames alone: an error in a consumed wrap would show there even if the clip-level PSNR hid it
     check(out[:, :, -8:], want[:, :, -8:], "last two chunks")
+
+
+# ----------------------------------------------------------------------------- r5: chunk length is a schedule, not a result
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+def test_vae_decode_does_not_depend_on_the_chunk_length(monkeypatch):
+    """The reference decodes ONE latent frame per chunk (VAE.py:1046-1052); the engine's default is two (FLEXAM_VAE_DEC_CHUNK), any length
+    gives the same causal convolutions.  8 latent frames: chunk lengths 1 (the reference's walk), 2 (1 + 2 + 2 + 2 + 1: a short last
+    chunk), 3 and 7 (everything after frame 0 at once) against the fp32 oracle and against each other (different GEMM shapes -> different
+    split-K sums: fp32 rounding only)."""
+    z = C.vae_case(seed=86, frames=8, h=2, w=4)
+    outs = {}
+    for n in (1, 2, 3, 7):
+        monkeypatch.setenv("FLEXAM_VAE_DEC_CHUNK", str(n))
+        vae, sd = build(seed=85)
+        assert vae.engine().chunk == n
+        outs[n] = vae.decode(z.cuda()).sample
+        assert outs[n].shape == (1, 3, 29, 32, 64)
+    want = OV.vae_decode(sd, z, C.VAE_SMALL["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
+    for n, o in outs.items():
+        check(o, want, f"vae decode, {n} latent frame(s) per chunk")
+        r = _rel(o, outs[1])
+        print(f"chunk {n} vs chunk 1: rel-rms {r:.2e}")
+        assert r <= 2e-3
+
+
+def test_vae_encode_does_not_depend_on_the_chunk_length(monkeypatch):
+    """Encoder: the reference walks 1 + 4 + 4 + ... frames (VAE.py:1029-1037); default here 1 + 24 + ... (FLEXAM_VAE_ENC_CHUNK).  25 frames:
+    chunk lengths 4, 8 (1 + 8 + 8 + 8), 16 (1 + 16 + 8) and 24 against the oracle and each other; trailing frames past 1 + 4k are dropped
+    like the reference's `iter_ = 1 + (t - 1) // 4`."""
+    x = C.vae_enc_case(seed=94, frames=25, h=32, w=32)
+    outs = {}
+    for n in (4, 8, 16, 24):
+        monkeypatch.setenv("FLEXAM_VAE_ENC_CHUNK", str(n))
+        vae, sd = build_encoder(seed=93)
+        assert vae.encoder_engine().chunk == n
+        outs[n] = vae.encode(x.cuda()).latent_dist.mode()
+        assert outs[n].shape == (1, 48, 7, 2, 2)
+    want = OV.vae_encode(sd, x, C.VAE_ENC_SMALL["temporal_down"], OV.LATENT_MEAN, OV.LATENT_STD)
+    for n, o in outs.items():
+        check_latent(o, want, f"vae encode, {n} frames per chunk")
+        r = _rel(o, outs[4])
+        print(f"chunk {n} vs chunk 4: rel-rms {r:.2e}")
+        assert r <= 2e-3
+    x27 = torch.cat([x, x[:, :, -2:]], dim=2)                 # 27 = 1 + 4 * 6 + 2: the last two frames are not encoded
+    torch.testing.assert_close(vae.encode(x27.cuda()).latent_dist.mode(), outs[24], rtol=0, atol=0)
+
+
+def test_phase_decomposed_upsample_convolution_equals_the_upsampled_image_form(monkeypatch):
+    """Resample upsample2d / upsample3d (VAE.py:76-99,153-160): "nearest-exact 2x upsample, then Conv2d 3x3" runs as four 2x2 phase
+    convolutions of the LOW-resolution frames with pre-summed taps (_ConvUp2x: 16 instead of 36 tap products per low-resolution pixel)
+    and flexam_phase_dupup_cl interleaves the phases into the residual stream.  FLEXAM_VAE_UPCONV=image keeps the earlier form (upsampled
+    image + one 3x3 convolution): same video up to the bf16 rounding of the summed taps; both against the fp32 oracle, 4 latent frames
+    (first-chunk branch without the time convolution, de-interleaved temporal upsample after it)."""
+    z = C.vae_case(seed=88, frames=4, h=4, w=6)
+    outs = {}
+    for form in ("phase", "image"):
+        monkeypatch.setenv("FLEXAM_VAE_UPCONV", form)
+        vae, sd = build(seed=87)
+        assert vae.engine().phase_up == (form == "phase")
+        outs[form] = vae.decode(z.cuda()).sample
+    want = OV.vae_decode(sd, z, C.VAE_SMALL["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
+    for form, o in outs.items():
+        check(o, want, f"vae decode, upsample convolutions in the {form} form")
+    r = _rel(outs["phase"], outs["image"])
+    print(f"phase form vs image form: rel-rms {r:.2e}")
+    assert r <= 5e-3

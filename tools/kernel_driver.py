@@ -18,10 +18,8 @@ def rnd(*s, scale=0.5):
     return (torch.randn(*s, generator=g) * scale).to(BF).to(dev)
 
 
-def main():
-    args = [a for a in sys.argv[1:]]
-    reps = int(args.pop(0)) if args and args[0].isdigit() else 3
-    want = set(args)
+def build_kernels():
+    """{name: launch closure} of every hot kernel of one DiT block at the config-2 shapes (tools/power_model.py loops them too)."""
     x = torch.randn(M, d, device=dev)                                  # fp32 residual stream
     hb = torch.empty(M, d, dtype=BF, device=dev)
     tab = torch.randn(4, 6, d, device=dev) * 0.1
@@ -60,6 +58,14 @@ def main():
         "gate_residual": lambda: H.gate_residual(x, hb, tab[:, 2], rows),
         "cfg_euler_blend": lambda: H.cfg_euler_blend(tok[0], tok[1], 448, 6.0, -0.02, lat, known, mask),
     }
+    return KERNELS
+
+
+def main():
+    args = [a for a in sys.argv[1:]]
+    reps = int(args.pop(0)) if args and args[0].isdigit() else 3
+    want = set(args)
+    KERNELS = build_kernels()
     for name, fn in KERNELS.items():
         if want and name not in want:
             continue
