@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void vae_prep_vec_kernel(const TI* __restrict_
                                                            int t0, int dst_compact) {
   // PIX positions per wave and iteration, their loads issued together: with <= 256 channels a position is one 0.5-1 KB access per
   // wave, too little in flight to cover the HBM latency (counters: 2.7 / 3.8 TB/s at 256 channels against 5.3 at 512)
-  constexpr int PIX = NSLAB == 1 ? 4 : NSLAB == 2 ? 2 : 1;
+  constexpr int PIX = NSLAB == 1 ? 8 : NSLAB == 2 ? 4 : NSLAB == 3 ? 2 : 2;      // r5: twice the positions in flight per wave (r4: 4 / 2 / 1 / 1)
   const int lane = threadIdx.x & 63;
   const int Hp = H + 2, Wp = W + 2;
   const int64_t npos = (int64_t)T * H * W;
@@ -248,6 +248,38 @@ __global__ __launch_bounds__(256) void phase_dupup_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] += xi[((co + j) * ft * 4 + sub) / repeats];
     *(f32x4*)(xm + (((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + co) = x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[(t, h, w), o] = bias[o] + sum over the kt x 3 x 3 taps of  Y[(t + dt, h + dh - 1, w + dw - 1), tap * Co + o]
+// A causal convolution with FEW output channels (the decoder head: 256 -> 12) as "one product per input pixel and tap, then a
+// gather": Y = image x [kt*9*Co, Cin]^T is ONE plain GEMM over the input pixels (K = Cin, every activation read once) instead of
+// an implicit GEMM whose K = 27 Cin re-reads every activation 27 times for 12 useful output columns of a 160-wide tile.
+// Y rows: padded positions of the (kt - 1) history frames + T current frames; border rows of Y are exact zeros (zero image rows,
+// no bias in the GEMM).  Four consecutive output channels per thread (Co % 4 == 0).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ y, int64_t ldy, int T, int H, int W, int kt, int Co,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int64_t ldo) {
+  const int Hp = H + 2, Wp = W + 2;
+  const int cvec = Co >> 2;
+  const int64_t total = (int64_t)T * H * W * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int o = (int)(i % cvec) * 4;
+    int64_t r = i / cvec;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int t = (int)(r / H);
+    f32x4 acc = bias ? *(const f32x4*)(bias + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < kt; ++dt)
+#pragma unroll
+      for (int dh = 0; dh < 3; ++dh) {
+        const float* row = y + (((int64_t)(t + dt) * Hp + h + dh) * Wp + w) * ldy + ((dt * 3 + dh) * 3) * Co + o;
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) acc += __builtin_nontemporal_load((const f32x4*)(row + dw * ldy + dw * Co));
+      }
+    *(f32x4*)(out + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * ldo + o) = acc;
   }
 }
 
@@ -475,6 +507,17 @@ extern "C" int flexam_phase_dupup_cl(const float* phases, int64_t ld_ph, int64_t
   hipLaunchKernelGGL(phase_dupup_kernel, dim3(grid_for((int64_t)To * Ho * Wo * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, phases, ld_ph,
                      phase_stride, x_main, ld_main, Co, To, Ho, Wo, x_in, ld_in, Ci, ft, drop);
   return flexam_check_launch("flexam_phase_dupup_cl");
+}
+
+extern "C" int flexam_tapsum_cl(const float* y, int64_t ld_y, int T, int H, int W, int kt, int Co, const float* bias, float* out,
+                                int64_t ld_out, void* stream) {
+  FX_REQUIRE(y && out, FLEXAM_E_ARG, "tapsum_cl: null pointer");
+  FX_REQUIRE(T > 0 && H > 0 && W > 0 && kt >= 1 && kt <= 3 && Co > 0 && Co % 4 == 0 && ld_y >= (int64_t)kt * 9 * Co && ld_y % 4 == 0 && ld_out % 4 == 0 &&
+             (uintptr_t)y % 16 == 0 && (uintptr_t)out % 16 == 0 && (!bias || (uintptr_t)bias % 16 == 0), FLEXAM_E_SHAPE,
+             "tapsum_cl: Co=%d must be a multiple of 4, ld_y=%ld >= kt*9*Co, 16-byte aligned rows", Co, (long)ld_y);
+  hipLaunchKernelGGL(tapsum_kernel, dim3(grid_for((int64_t)T * H * W * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, y, ld_y, T, H, W, kt, Co,
+                     bias, out, ld_out);
+  return flexam_check_launch("flexam_tapsum_cl");
 }
 
 extern "C" int flexam_softmax_rows(const float* s, int64_t ld_s, int64_t M, int N, float scale, void* out, int64_t ld_out, int Npad,

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "flexam_upsample2x_cl": ([_P, _I, _L, _I, _I, _I, _I, _I, _P, _I, _P], c_int),
     "flexam_dupup_add_cl": ([_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _P], c_int),
     "flexam_deinterleave_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _P], c_int),
+    "flexam_tapsum_cl": ([_P, _L, _I, _I, _I, _I, _I, _P, _P, _L, _P], c_int),
     "flexam_phase_dupup_cl": ([_P, _L, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _P], c_int),
     "flexam_softmax_rows": ([_P, _L, _L, _I, _F, _P, _L, _I, _P], c_int),
     "flexam_scatter_add_cl": ([_P, _L, _P, _L, _I, _I, _I, _I, _P], c_int),
@@ -722,6 +723,13 @@ def phase_dupup_cl(phases, x_main, Co, To, Ho, Wo, x_in, Ci, ft, drop):
     _check(lib().flexam_phase_dupup_cl(_ptr(phases, F32), phases.stride(1), phases.stride(0), _ptr(x_main, F32), x_main.stride(0), Co, To, Ho, Wo,
                                        _ptr(x_in, F32), x_in.stride(0), Ci, ft, drop, _stream()), "flexam_phase_dupup_cl")
     return x_main
+
+
+def tapsum_cl(y, T, H, W, kt, Co, bias, out):
+    """y [(kt - 1 + T) * (H+2) * (W+2), >= kt*9*Co] fp32 per-tap products -> out rows [T * (H+2) * (W+2), Co] fp32 (interior positions)."""
+    _check(lib().flexam_tapsum_cl(_ptr(y, F32), y.stride(0), T, H, W, kt, Co, _ptr(bias, F32), _ptr(out, F32), out.stride(0), _stream()),
+           "flexam_tapsum_cl")
+    return out
 
 
 def softmax_rows(s, scale, out, n_valid):

@@ -283,6 +283,39 @@ class _Conv:
         return out
 
 
+class _ConvFold(_Conv):
+    """A causal convolution with few output channels (the decoder head, 256 -> 12) as a per-tap product + gather: ONE plain GEMM over
+    the input pixels, Y[pixel, tap * Cout + o] = W[o, :, tap] . x[pixel, :] (K = Cin: every activation is read once; N = 27 * 12 = 324),
+    then flexam_tapsum_cl adds, for every output pixel, the 27 products of its neighbours.  As an implicit GEMM the same convolution has
+    K = 27 Cin -- every activation re-read 27 times -- for 12 useful columns of a 160-wide tile: 0.73 ms per 4 frames at 256 x 448, 2.4 %
+    of a decode.  Y is recomputed for the two history frames of a chunk (they are the chunk before's last frames)."""
+
+    def __init__(self, weight, bias, device, t_cap: int):
+        w = weight.detach().to(device, F32)
+        co, ci, kt, kh, kw = w.shape
+        assert (kh, kw) == (3, 3)
+        self.co, self.ci, self.kt, self.kh, self.kw = co, ci, kt, kh, kw
+        self.run_pack, self.k_rowmajor = False, True
+        self.cp = _round_up(ci, 64)
+        wf = torch.zeros(kt * 9 * co, self.cp, device=device, dtype=F32)
+        wf[:, :ci] = w.permute(2, 3, 4, 0, 1).reshape(kt * 9 * co, ci)              # row (dt*9 + dh*3 + dw) * co + o
+        self.weight = wf.to(BF16).contiguous()
+        self.bias = bias.detach().to(device, F32).contiguous()
+        self.hist, self.t_cap, self.device, self.shape, self._koff, self._y = kt - 1, t_cap, device, None, None, None
+
+    def run(self, t, h, w, out_dtype=F32, residual_into=None):
+        assert out_dtype == F32 and residual_into is None
+        hp, wp = h + 2, w + 2
+        rows_all = (self.hist + t) * hp * wp
+        if self._y is None or self._y.shape[0] < rows_all:
+            self._y = torch.empty((self.hist + self.t_cap) * hp * wp, self.weight.shape[0], device=self.device, dtype=F32)
+        y = hip.gemm(self.img.view(-1, self.cp)[:rows_all], self.weight, None, out=self._y[:rows_all])
+        out = torch.empty(t * hp * wp, self.co, device=self.device, dtype=F32)      # border rows: never read
+        hip.tapsum_cl(y, t, h, w, self.kt, self.co, self.bias, out)
+        self.roll(t)
+        return out
+
+
 class _ConvS2D:
     """ZeroPad2d((0,1,0,1)) + Conv2d(3x3, stride 2) (Resample downsample2d/3d, VAE.py:104-113) as a unit-stride
     implicit GEMM over a space-to-depth image [t, H/2+2, W/2+2, 4*Cs]: tap (dh, dw) of the strided conv is
@@ -504,7 +537,11 @@ class _DecoderEngine(_EngineBase):
                 st["time_conv"] = conv(f"{p}.3.time_conv", tmul[i]) if st["temporal"] else None
             self.stages.append(st)
         self.head_gamma = self._f32(sd["decoder.head.0.gamma"], dev)
-        self.head_conv = conv("decoder.head.2", tmul[-1])
+        # FLEXAM_VAE_HEADCONV=implicit: the head as an implicit GEMM like every other convolution (A/B and cross-check)
+        if os.environ.get("FLEXAM_VAE_HEADCONV", "fold") != "implicit" and sd["decoder.head.2.weight"].shape[0] % 4 == 0:
+            self.head_conv = _ConvFold(sd["decoder.head.2.weight"], sd["decoder.head.2.bias"], dev, tmul[-1])
+        else:
+            self.head_conv = conv("decoder.head.2", tmul[-1])
         self.mean = torch.tensor(vae.latent_mean, device=dev, dtype=F32)
         self.std = torch.tensor(vae.latent_std, device=dev, dtype=F32)
         del self.sd

@@ -299,6 +299,12 @@ int flexam_dupup_add_cl(float* x_main, int64_t ld_main, int Co, int To, int Ho, 
 int flexam_deinterleave_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, void* dst, int Cp, void* stream);
 int flexam_phase_dupup_cl(const float* phases, int64_t ld_ph, int64_t phase_stride, float* x_main, int64_t ld_main, int Co, int To, int Ho,
                           int Wo, const float* x_in, int64_t ld_in, int Ci, int ft, int drop, void* stream);
+/* tapsum_cl: a causal kt x 3 x 3 convolution with FEW output channels (decoder head 256 -> 12, wan_vae3_8.py:668-672) as one plain GEMM
+ * over the input pixels (Y[pixel, tap * Co + o] = W[o, :, tap] . x[pixel, :], K = Cin: every activation read once) and this gather:
+ * out[(t,h,w), o] = bias[o] + sum_taps Y[(t + dt, h + dh - 1, w + dw - 1), tap * Co + o].  Y rows = padded positions of the kt - 1 history
+ * frames followed by the T current frames; out rows = padded positions of the T current frames (interior written). */
+int flexam_tapsum_cl(const float* y, int64_t ld_y, int T, int H, int W, int kt, int Co, const float* bias, float* out, int64_t ld_out,
+                     void* stream);
 int flexam_softmax_rows(const float* s, int64_t ld_s, int64_t M, int N, float scale, void* out, int64_t ld_out, int Npad, void* stream);
 int flexam_scatter_add_cl(float* x, int64_t ldx, const void* y, int64_t ldy, int C, int T, int H, int W, void* stream);
 int flexam_vae_unpatchify_clamp(const float* src, int64_t ld_src, int T, int H, int W, float* video, int Ftot, int f0, float lo,

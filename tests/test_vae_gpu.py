@@ -204,3 +204,21 @@ def test_phase_decomposed_upsample_convolution_equals_the_upsampled_image_form(m
     r = _rel(outs["phase"], outs["image"])
     print(f"phase form vs image form: rel-rms {r:.2e}")
     assert r <= 5e-3
+
+
+def test_decoder_head_as_per_tap_products_and_gather_equals_the_implicit_gemm(monkeypatch):
+    """The decoder head (3x3x3 causal convolution to 12 channels, VAE.py:668-672) runs as ONE plain GEMM over the input pixels (per-tap
+    products, N = 27 x 12) + flexam_tapsum_cl (_ConvFold); FLEXAM_VAE_HEADCONV=implicit keeps the implicit GEMM.  Same operands, fp32
+    sums in another order: the two decodes agree to fp32 rounding; 5 latent frames so that history frames carry over chunks."""
+    z = C.vae_case(seed=90, frames=5, h=4, w=4)
+    outs = {}
+    for form in ("fold", "implicit"):
+        monkeypatch.setenv("FLEXAM_VAE_HEADCONV", form)
+        vae, sd = build(seed=89)
+        assert type(vae.engine().head_conv).__name__ == ("_ConvFold" if form == "fold" else "_Conv")
+        outs[form] = vae.decode(z.cuda()).sample
+    want = OV.vae_decode(sd, z, C.VAE_SMALL["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
+    check(outs["fold"], want, "vae decode, head convolution as per-tap products + gather")
+    r = _rel(outs["fold"], outs["implicit"])
+    print(f"fold vs implicit head: rel-rms {r:.2e}")
+    assert r <= 1e-4
