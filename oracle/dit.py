@@ -89,19 +89,43 @@ def layer_norm(x: Tensor, eps: float, weight: Optional[Tensor] = None, bias: Opt
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
+_BF16_EMULATION = [False]
+
+
+class bf16_emulation:
+    """`with bf16_emulation():` -- the oracle with the ROUNDINGS of the reference's own GPU path put in: under `torch.autocast(bfloat16)`
+    every nn.Linear reads bf16 operands and writes a bf16 result (fp32 accumulation), and flash-attention takes bf16 q, k, v, multiplies
+    bf16 probabilities with V and returns bf16 (FX.py:242-262, ATT.py:66-122).  Norms, modulation, the residual stream and the softmax
+    stay fp32 as in the reference (FX.py:173-202,444-468).  Not a bit-level model of any kernel: it says how far a CORRECT bf16
+    implementation lands from the fp32 oracle on a given problem, which is the yardstick for problems where that distance is large
+    (peaked softmax rows: a bf16 rounding of q or k moves a score by 2^-9 of its size, and rows with 2-3 effective keys flip)."""
+
+    def __enter__(self):
+        self._prev = _BF16_EMULATION[0]
+        _BF16_EMULATION[0] = True
+
+    def __exit__(self, *exc):
+        _BF16_EMULATION[0] = self._prev
+        return False
+
+
+def _r(t: Optional[Tensor]) -> Optional[Tensor]:
+    return t.to(torch.bfloat16).to(torch.float32) if (_BF16_EMULATION[0] and t is not None) else t
+
+
 def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
     """ATT.py:174-233 semantics on the path: plain softmax(q k^T / sqrt(D)) v, non-causal, no
     mask (k_lens == L in self-attention, None in cross-attention).  Layout [B, L, N, D]."""
     if q.shape[2] > 1 and q.shape[0] * q.shape[1] * k.shape[1] * q.shape[2] > (1 << 28):
         # same arithmetic one head at a time: bounds the score matrix (13 GB at L = 11648, 24 heads)
         return torch.cat([attention(q[:, :, i:i + 1], k[:, :, i:i + 1], v[:, :, i:i + 1]) for i in range(q.shape[2])], dim=2)
-    q, k, v = (u.transpose(1, 2) for u in (q, k, v))
+    q, k, v = (_r(u).transpose(1, 2) for u in (q, k, v))
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
-    return torch.matmul(s.softmax(dim=-1), v).transpose(1, 2)
+    return _r(torch.matmul(_r(s.softmax(dim=-1)), v)).transpose(1, 2)
 
 
 def linear(sd: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
-    return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+    return _r(F.linear(_r(x), _r(sd[name + ".weight"]), _r(sd.get(name + ".bias"))))
 
 
 # ----------------------------------------------------------------------------- block

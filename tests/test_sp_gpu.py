@@ -168,14 +168,18 @@ def _world_results(world, wide):
 _SINGLE = {}
 
 
-def single_process(wide):
-    """The single-process fused HIP result for the same inputs (DiT forward, 2-step sampler)."""
-    if wide not in _SINGLE:
+def single_process(wide, rebound=False):
+    """The single-process HIP result for the same inputs (DiT forward, 2-step sampler): the fused engine, or -- rebound -- the same
+    re-bound / wrapped blocks called as modules on the whole sequence."""
+    key = (wide, rebound)
+    if key not in _SINGLE:
         cfg = _wide_cfg() if wide else dict(O.DIT_TINY)
         m = _build(cfg, "cuda:0")
-        _SINGLE[wide] = _forward_and_sample(m, cfg, "cuda:0")
-        assert m.engine().fused
-    return _SINGLE[wide]
+        if rebound:
+            _rebind_and_wrap(m)
+        _SINGLE[key] = _forward_and_sample(m, cfg, "cuda:0")
+        assert m.engine().fused != rebound
+    return _SINGLE[key]
 
 
 def ranks_agree(per_rank, key):
@@ -215,11 +219,18 @@ def test_rebound_and_wrapped_blocks_under_sequence_parallelism(world, cfg_parall
     the native self-attention forward does the K|V exchange itself (flexam_amd.dist.sequence_parallel_context).  2 ranks = 2 token
     chunks with the CFG pair batched; 4 ranks = 2 CFG rows x 2 chunks.  Equal to the single-process fused engine."""
     out0, lat0 = ranks_agree(_world_results(world, False), (cfg_parallel, mode))
-    single, lat = single_process(False)
+    # (1) against the SAME module-seam blocks run on the whole sequence in one process: only the exchange differs (key order of the softmax)
+    single, lat = single_process(False, rebound=True)
     for name, a, b in (("DiT forward", out0, single), ("2-step sampler", lat0, lat)):
         rel = rel_rms(a, b)
-        print(f"re-bound / wrapped blocks, world={world}: {name} vs single-process fused engine rel-rms {rel:.2e}")
-        assert rel < 6e-3
+        print(f"re-bound / wrapped blocks, world={world}: {name} vs the same blocks on one rank rel-rms {rel:.2e}")
+        assert rel < 4e-3
+    # (2) against the fused engine: the module seam rounds a block's attention / FFN outputs to bf16 before the gated add where the fused
+    # epilogues add in fp32 (measured 1.9e-3 on the forward); the 2-step sampler multiplies that by the guidance combine (7.5e-3 at scale 6)
+    fused, lat_f = single_process(False)
+    rel_f, rel_l = rel_rms(out0, fused), rel_rms(lat0, lat_f)
+    print(f"re-bound / wrapped blocks, world={world}: vs single-process fused engine rel-rms {rel_f:.2e} (forward), {rel_l:.2e} (2-step sampler)")
+    assert rel_f < 6e-3 and rel_l < 2e-2
 
 
 @pytest.mark.parametrize("world,cfg_parallel,mode", WIDE_CASES)
