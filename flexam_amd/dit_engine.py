@@ -175,6 +175,7 @@ class DiTEngine:
         if pieces < 1 or self.nh % pieces:
             raise ValueError(f"FLEXAM_SP_PIECES={pieces}: must divide the {self.nh} heads")
         self.sp_pieces = pieces if sp_size > 1 else 1
+        self.sp_fused_qkv = os.environ.get("FLEXAM_SP_FUSED_QKV", "1") != "0"
         self.world_group = world_group if cfg_size > 1 else sp_group
         self.world_size = world_size if world_size is not None else sp_size
         self.cfg_size, self.cfg_row = cfg_size, cfg_row
@@ -490,8 +491,12 @@ class DiTEngine:
             elif sp > 1:
                 # K|V projection + K norm/RoPE first, written straight into the send buffer; their all-gather (RCCL over xGMI)
                 # runs under the Q projection, the Q norm/RoPE and the attention to the LOCAL chunk
-                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(d, None), qkv[:, d:])
-                self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0)
+                # (FLEXAM_SP_FUSED_QKV=1, default: ONE q|k|v launch instead -- at a rank's few thousand rows two launches of 24 and 12 tile
+                #  columns quantise worse on 256 CUs than one of 36 (emulated rank of 8, profiles/r5*: 119 + 80 us against ~135), and the
+                #  gather starts ~15 us later, not ~80)
+                fused_qkv = self.sp_fused_qkv
+                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None) if fused_qkv else slice(d, None), qkv if fused_qkv else qkv[:, d:])
+                self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0, q_done=fused_qkv)
                 hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
             else:
                 a8sa = fp8_here and (a8[:mb], sa[:mb])
@@ -721,7 +726,7 @@ class DiTEngine:
             return hip.gemm_fp8(a8sa[0], a8sa[1], w8[wname][rows], w8["s_" + wname][rows], p[bname][rows], out=out)
         return hip.gemm(hbuf, p[wname][rows], p[bname][rows], out=out)
 
-    def _allgather_attention(self, qkv, hbuf, a8sa, layer, p, ao4, q4, B, lc, tok0):
+    def _allgather_attention(self, qkv, hbuf, a8sa, layer, p, ao4, q4, B, lc, tok0, q_done=False):
         """K|V of this rank's tokens are in qkv[:, C:] (projected, not yet normed).  The RMSNorm+RoPE launch writes K (normed,
         rotated) and V into the send buffer, cut into `sp_pieces` groups of heads: [G, B, lc, 2*C/G].  One all-gather per group
         and CFG row assembles [G, B, L, 2*C/G] in token order (the rank-major concatenation IS the token order: no re-layout
@@ -755,7 +760,8 @@ class DiTEngine:
         # modelled (and delivered wrong chunks intermittently with 8 ranks on one device): there each gather completes before the next.
         overlapped = group_backend(self.sp_group) in ("nccl", "loopback")
         works = [[all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=overlapped) for b in range(B)] for g in range(G)]
-        self._proj(hbuf, a8sa, layer, p, "wqkv", "bqkv", slice(0, d), qkv[:, 0:d])
+        if not q_done:
+            self._proj(hbuf, a8sa, layer, p, "wqkv", "bqkv", slice(0, d), qkv[:, 0:d])
         hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0,
                          head_dim=hd)
         heads = lambda t: t.unflatten(2, (hg, hd))

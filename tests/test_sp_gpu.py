@@ -26,10 +26,12 @@ pytestmark = pytest.mark.gpu
 # mode: the exchange around self-attention -- "allgather" (K|V all-gather with local-chunk-first attention, the default),
 # "allgather-wait" (the same gather, one attention call after it: FLEXAM_SP_OVERLAP=0) or "ulysses" (all-to-all over heads);
 # "-p1": the gather in ONE piece (FLEXAM_SP_PIECES=1) instead of the default two head-group pieces; "-ovN": FLEXAM_SP_OVERLAP=N;
-# "-rebound": block 0's self_attn.forward re-bound and block 1 wrapped (the engine then calls blocks as modules).
+# "-rebound": block 0's self_attn.forward re-bound and block 1 wrapped (the engine then calls blocks as modules); "-splitqkv":
+# FLEXAM_SP_FUSED_QKV=0 (the K|V projection on its own launch in front of the gather, the Q projection under it).
 LAYOUT_CASES = [(2, False, "ulysses"), (2, False, "allgather"), (2, False, "allgather-wait"), (2, True, "allgather"), (4, True, "ulysses"),
                 (4, True, "allgather"), (4, False, "allgather"), (4, False, "allgather-wait"), (4, None, "allgather"), (2, None, "allgather"),
-                (2, False, "allgather-p1"), (4, False, "allgather-p1"), (4, True, "allgather-p1-wait")]
+                (2, False, "allgather-p1"), (4, False, "allgather-p1"), (4, True, "allgather-p1-wait"), (4, True, "allgather-splitqkv"),
+                (2, False, "allgather-splitqkv")]
 REBOUND_CASES = [(2, False, "allgather-rebound"), (4, True, "allgather-rebound")]
 WIDE_CASES = [(4, False, "ulysses-ov1"), (4, False, "ulysses-ov2"), (4, False, "ulysses-ov0")]
 
@@ -74,6 +76,7 @@ def set_mode_env(mode):
     else:
         os.environ["FLEXAM_SP_OVERLAP"] = "0" if "-wait" in mode else "1"
     os.environ["FLEXAM_SP_PIECES"] = "1" if "-p1" in mode else "2"
+    os.environ["FLEXAM_SP_FUSED_QKV"] = "0" if "-splitqkv" in mode else "1"       # r4 form: K|V projection, gather start, then the Q projection
 
 
 def _forward_and_sample(m, cfg, devname):

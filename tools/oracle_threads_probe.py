@@ -27,3 +27,12 @@ for name, kw in (("L=256 B=2", dict(frames=3, h=16, w=16)), ("L=2912 B=2", dict(
         with torch.no_grad():
             O.dit_forward(sd, big, **case)
         print(f"d=3072 one layer {name}: {nt:4d} threads {time.perf_counter() - t:6.2f} s", flush=True)
+# bench.py's cpu_baseline leg: ONE block at L = 11648, one sample
+import bench  # noqa: E402  (benchlib on the path)
+from benchlib.cpu_baseline import cpu_baseline
+for nt in (32, 64, 128):
+    if nt > (os.cpu_count() or 8):
+        continue
+    torch.set_num_threads(nt)
+    r = cpu_baseline(11648, dict(O.DIT_5B))
+    print(f"cpu_baseline block L=11648: {nt:4d} threads {r['block_seconds']:6.2f} s", flush=True)
