@@ -5,6 +5,17 @@ import time
 import torch
 
 
+BASELINE_THREADS = 32      # r5, tools/oracle_threads_probe.py on the GPU box (256 cores): the L = 11648 block takes 10.1 s on 32 threads, 12.0 s on 64
+                           # and 20.1 s on torch's default 128 -- the baseline is quoted at the thread count that is FASTEST for it
+
+
+def _baseline_threads():
+    n = torch.get_num_threads()
+    if n > BASELINE_THREADS:
+        torch.set_num_threads(BASELINE_THREADS)
+    return n
+
+
 def cpu_baseline(L, cfg):
     """fp32 oracle (oracle/dit.py: the restatement pinned to the reference by golden vectors) on the
     host cores: ONE WanAttentionBlock forward on ONE sample at the full token count = 1/60 of a step."""
@@ -21,12 +32,15 @@ def cpu_baseline(L, cfg):
     ctx = torch.randn(1, T, d, generator=g)
     grid = (26, 16, 28) if L == 11648 else (1, 1, L)
     ang = O.rope_angles(1024, d // nh)
+    restore = _baseline_threads()
     t0 = time.perf_counter()
     with torch.no_grad():
         O.block_forward(sd, "blocks.0", x, e0, dens0, grid, ang, ctx, nh)
     sec = time.perf_counter() - t0
+    used = torch.get_num_threads()
+    torch.set_num_threads(restore)
     steps_per_sec = 1.0 / (sec * 60.0)
-    return dict(value=steps_per_sec, unit="denoise-steps/sec", cores=torch.get_num_threads(), kind="port",
+    return dict(value=steps_per_sec, unit="denoise-steps/sec", cores=used, kind="port",
                 sample=f"1 of the 60 block-forwards of one step (oracle/dit.py block_forward, fp32, L={L}, d={d}) "
                        f"took {sec:.1f} s; value = 1/(60 x that), extrapolated", block_seconds=sec)
 
@@ -41,6 +55,7 @@ def cpu_baseline_legs(cfg, layers=3):
     from oracle import dit as O
     from oracle import sampler as S
     from oracle import vae as OV
+    restore = _baseline_threads()
     c1 = dict(cfg, num_layers=layers)
     sd = C.dit_weights(c1, 5)
     sc = C.sampler_case(c1)
@@ -59,7 +74,10 @@ def cpu_baseline_legs(cfg, layers=3):
     with torch.no_grad():
         OV.vae_decode(vsd, z, v["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD)
     sec2 = time.perf_counter() - t0
+    used = torch.get_num_threads()
+    torch.set_num_threads(restore)
     return {
+        "cores": used,
         "config1_4_steps": dict(seconds=sec1, layers_run=layers, sample=f"9x256x256, 4 Euler steps, CFG pair, {layers} of 30 layers at d=3072 (oracle loop + dit_forward)",
                                 extrapolated_seconds_30_layers=sec1 * 30.0 / layers),
         "vae_decode_chunk": dict(seconds=sec2, sample="true-width decoder, latent [1,48,2,8,14] (1/16 area): first chunk + one 4-frame chunk",
