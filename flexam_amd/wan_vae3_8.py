@@ -258,15 +258,6 @@ class _Conv:
         self.roll(t)
         return out
 
-    def run_at(self, f0, n, h, w, out=None, residual_into=None):
-        """Convolve current frames f0 .. f0 + n of the window WITHOUT sliding it (time slices of a long chunk, see _EngineBase._res;
-        the caller rolls once per chunk): out rows [n*(h+2)*(w+2), Cout] (bf16), or residual_into (fp32 rows of the same frames) += conv."""
-        rows = n * (h + 2) * (w + 2)
-        a = self.img[f0:].view(-1, self.cp)
-        if residual_into is not None:
-            return hip.gemm_gate_residual(a, self.weight, self.bias, residual_into, a_koff=self._koff)
-        return hip.gemm(a, self.weight, self.bias, a_koff=self._koff, m=rows, k=self.weight.shape[1], out=out)
-
     def roll(self, t):
         """The last `hist` frames of the chunk become the history of the next one: the window moves on by t frames."""
         if self.hist:
@@ -443,7 +434,6 @@ class _EngineBase:
             raise RuntimeError("flexam_amd: the VAE runs only on a GPU through libflexam_hip.so (no CPU fallback)")
         hip.device_check()
         self._scratch = {}
-        self.slice_bytes = float(os.environ.get("FLEXAM_VAE_SLICE_MB", "320")) * 2 ** 20
         return sd, dev
 
     @staticmethod
@@ -479,43 +469,16 @@ class _EngineBase:
         """ResidualBlock (VAE.py:198-240) on rows x [t*(h+2)*(w+2), Cin] fp32 -> [.., Cout] fp32
         (in place when there is no shortcut conv)."""
         c1, c2 = r["c1"], r["c2"]
-        rows_f = (h + 2) * (w + 2)
-        # Time slices: a long chunk (FLEXAM_VAE_*_CHUNK) fills the GPU in the low-resolution stages, but at 256 x 448 four frames of the
-        # fp32 stream are already 0.3-0.5 GB -- with a whole chunk per launch every elementwise pass re-reads from HBM what the GEMM in
-        # front of it just wrote (r5: prep +20...40 % per frame at 48-frame chunks).  So a residual block walks its chunk in slices of
-        # ~FLEXAM_VAE_SLICE_MB (default 320) of fp32 rows: norm -> conv -> norm -> conv(+=) per slice, each launch consuming what the
-        # 256 MB Infinity Cache still holds of the one before.  Causal history needs nothing extra: slice i's taps reach into slice
-        # i - 1's frames, already in the window.
-        per_frame = rows_f * max(c1.ci, c1.co) * 4
-        sl = max(1, min(t, int(self.slice_bytes // per_frame))) if self.slice_bytes > 0 else t
-        x_in = x
+        hip.vae_prep_cl(x, c1.ci, t, h, w, c1.image(h, w), mode=2, gamma=r["g0"], t0=c1.hist)
+        t1 = c1.run(t, h, w, out_dtype=BF16)
+        hip.vae_prep_cl(t1, c2.ci, t, h, w, c2.image(h, w), mode=2, gamma=r["g3"], t0=c2.hist)
         if r["short"] is not None:
             sc = r["short"]
             xb = self._plain_image(("short", sc.ci), t, h, w, sc.cp)
-            x = torch.empty(t * rows_f, sc.co, device=self.device, dtype=F32)
-        i1, i2 = c1.image(h, w), c2.image(h, w)
-        t1 = self._t1_buffer(sl * rows_f, c1.co)
-        for f0 in range(0, t, sl):
-            n = min(sl, t - f0)
-            xs = x_in[f0 * rows_f:(f0 + n) * rows_f]
-            hip.vae_prep_cl(xs, c1.ci, n, h, w, i1, mode=2, gamma=r["g0"], t0=c1.hist + f0)
-            c1.run_at(f0, n, h, w, out=t1[:n * rows_f])
-            hip.vae_prep_cl(t1[:n * rows_f], c2.ci, n, h, w, i2, mode=2, gamma=r["g3"], t0=c2.hist + f0)
-            xo = x[f0 * rows_f:(f0 + n) * rows_f]
-            if r["short"] is not None:                      # 1x1x1 shortcut convolution of the same slice: the rows conv2 then adds into
-                hip.vae_prep_cl(xs, sc.ci, n, h, w, xb[f0:], mode=0)
-                hip.gemm(xb[f0:f0 + n].view(-1, sc.cp), sc.weight, sc.bias, out=xo)
-            c2.run_at(f0, n, h, w, residual_into=xo)
-        c1.roll(t)
-        c2.roll(t)
+            hip.vae_prep_cl(x, sc.ci, t, h, w, xb, mode=0)
+            x = hip.gemm(xb.view(-1, sc.cp), sc.weight, sc.bias, out_dtype=F32)
+        c2.run(t, h, w, residual_into=x)
         return x
-
-    def _t1_buffer(self, rows, c):
-        k = ("t1", c)
-        buf = self._scratch.get(k)
-        if buf is None or buf.shape[0] < rows:
-            buf = self._scratch[k] = torch.empty(rows, c, device=self.device, dtype=BF16)
-        return buf
 
     def _attention(self, a, x, t, h, w):
         """AttentionBlock (VAE.py:243-282): per frame, one head with head_dim = C."""
@@ -723,7 +686,7 @@ class _EncoderEngine(_EngineBase):
         # (only on their being multiples of 4, which keeps the stride-2 time convolutions' frame pairs together).  Long chunks fill the
         # GPU in the low-resolution stages -- at 4 frames the 64 x 112 stage launches 150 tiles and the 32 x 56 stage 24 on 256 CUs --
         # and cut the launch count; 288 GB of HBM hold a whole 97-frame clip's activations.  FLEXAM_VAE_ENC_CHUNK=4 is the reference's walk.
-        self.chunk = max(4, int(os.environ.get("FLEXAM_VAE_ENC_CHUNK", "24")) // 4 * 4)
+        self.chunk = max(4, int(os.environ.get("FLEXAM_VAE_ENC_CHUNK", "48")) // 4 * 4)
         tcap = [self.chunk]
         for down in self.temporal_down:
             tcap.append(max(1, tcap[-1] // (2 if down else 1)))             # frames per chunk entering stage i

@@ -222,25 +222,3 @@ def test_decoder_head_as_per_tap_products_and_gather_equals_the_implicit_gemm(mo
     r = _rel(outs["fold"], outs["implicit"])
     print(f"fold vs implicit head: rel-rms {r:.2e}")
     assert r <= 1e-4
-
-
-def test_time_slices_of_a_residual_block_do_not_change_the_result(monkeypatch):
-    """_EngineBase._res walks a long chunk in time slices (norm -> conv -> norm -> conv per slice, FLEXAM_VAE_SLICE_MB) so that every
-    elementwise pass still finds its input in the Infinity Cache.  One-frame slices (a tiny budget) against whole-chunk launches
-    (budget 0 = off), decoder (7 latent frames per chunk) and encoder (24 frames per chunk): same convolutions, fp32 rounding only."""
-    z = C.vae_case(seed=96, frames=8, h=2, w=4)
-    x = C.vae_enc_case(seed=97, frames=25, h=32, w=32)
-    monkeypatch.setenv("FLEXAM_VAE_DEC_CHUNK", "7")
-    monkeypatch.setenv("FLEXAM_VAE_ENC_CHUNK", "24")
-    dec, enc = {}, {}
-    for mb in ("0", "0.0001"):
-        monkeypatch.setenv("FLEXAM_VAE_SLICE_MB", mb)
-        vae, sd = build(seed=95)
-        dec[mb] = vae.decode(z.cuda()).sample
-        vae_e, sd_e = build_encoder(seed=98)
-        enc[mb] = vae_e.encode(x.cuda()).latent_dist.mode()
-    check(dec["0.0001"], OV.vae_decode(sd, z, C.VAE_SMALL["temporal_up"], OV.LATENT_MEAN, OV.LATENT_STD), "vae decode in one-frame slices")
-    check_latent(enc["0.0001"], OV.vae_encode(sd_e, x, C.VAE_ENC_SMALL["temporal_down"], OV.LATENT_MEAN, OV.LATENT_STD), "vae encode in one-frame slices")
-    rd, re_ = _rel(dec["0.0001"], dec["0"]), _rel(enc["0.0001"], enc["0"])
-    print(f"one-frame slices vs whole chunks: decode rel-rms {rd:.2e}, encode {re_:.2e}")
-    assert rd <= 2e-3 and re_ <= 2e-3

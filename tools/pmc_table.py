@@ -70,7 +70,7 @@ if "--attn-traffic" in sys.argv:
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, repo)
     from benchlib.kernels import attn_source_sha
-    main = [k for k in table if "attn_fwd_kernel<0, true, true>" in k.replace("(anonymous namespace)::", "") or "attn_fwd_kernel<0,true,true>" in k.replace(" ", "")]
+    main = [k for k in table if "attn_fwd_kernel<0,true,true" in k.replace("(anonymous namespace)::", "").replace(" ", "")]   # <KIND = self, PRE, FULL, ...>
     merge = [k for k in table if "attn_merge_kernel" in k]
     if not main or "hbm_bytes" not in table[main[0]]:
         sys.exit("pmc_table --attn-traffic: no attn_fwd_kernel<0, true, true> row with FETCH_SIZE / WRITE_SIZE in " + root)
