@@ -69,10 +69,10 @@ def main():
     ap.add_argument("--logit-scale", type=float, default=None, metavar="S",
                     help="multiply every self_attn.norm_q / norm_k weight by sqrt(S): q.k / sqrt(128) then has std ~S instead of ~1 (peaked softmax rows, "
                          "the attention kernel's deferred-rescale branch taken); a SEPARATE line that says so, never the headline")
-    ap.add_argument("--emulate-rank", type=int, default=8, metavar="N",
+    ap.add_argument("--emulate-rank", type=int, default=None, metavar="N",
                     help="after the single-GPU measurement: one rank's share of an N-GPU step per layout, collectives replaced by same-size device "
-                         "copies on a side stream -> `emulated_ranks` / `predicted_scaling_no_comm` (benchlib/emulate.py); default 8 on the headline "
-                         "workload (a few seconds, after the timed region), 0 = off")
+                         "copies on a side stream -> `emulated_ranks` / `predicted_scaling_no_comm` (benchlib/emulate.py); default: 8 on the headline "
+                         "workload (a few seconds, after the timed region), off on the variant lines; 0 = off")
     ap.add_argument("--emulate-which", type=int, default=None, help="which rank of the sequence-parallel group to emulate (default: a middle chunk)")
     args = ap.parse_args()
 
@@ -246,12 +246,14 @@ def main():
             if (b_local > 1 and lvl > 0) else "")
     vae_sec = enc_sec = enc_stream_sec = None
     emulated = None
-    if args.emulate_rank and rank == 0 and world == 1 and not (args.fp8 or args.sage or args.logit_scale is not None or args.mask != "motion" or args.layers != 30):
+    headline = not (args.fp8 or args.sage or args.logit_scale is not None or args.mask != "motion" or args.layers != 30)
+    n_emulate = args.emulate_rank if args.emulate_rank is not None else (8 if headline else 0)
+    if n_emulate and rank == 0 and world == 1:
         from benchlib.emulate import emulate
         pipe = eng = None
         torch.cuda.empty_cache()
         try:                                             # an add-on after the timed region: it must not cost the steps/s line if it fails
-            emulated = emulate(model, lambda: Wan2_2FunControlPipeline_FlexAM(transformer=model), inp, cond, args.emulate_rank, args.steps, args.warmup,
+            emulated = emulate(model, lambda: Wan2_2FunControlPipeline_FlexAM(transformer=model), inp, cond, n_emulate, args.steps, args.warmup,
                                total_steps, rank=args.emulate_which)
         except Exception as e:                           # noqa: BLE001
             emulated = [{"error": f"{type(e).__name__}: {e}"}]
@@ -341,7 +343,7 @@ def main():
                                              "rescale branch (any lane maximum > 2^8 above the running reference) is taken; compare ms_per_step and "
                                              "roofline.launch_ms with the default line of the same box"}
         if emulated is not None:
-            result["emulated_ranks"] = {"world": args.emulate_rank, "layouts": emulated,
+            result["emulated_ranks"] = {"world": n_emulate, "layouts": emulated,
                                         "predicted_scaling_no_comm": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step"], 3) for r in emulated if "ms_per_step" in r},
                                         "what": "ONE process ran one rank's share of an N-GPU step per layout at full size: the real engine on that rank's token chunk / "
                                                 "CFG row with every launch, piece, partial attention and merge of the multi-GPU path, collectives replaced by device "
