@@ -188,8 +188,15 @@ class _SelfAttn(_Attn):
         sp = current_sp_context()
         if sp is not None and sp["size"] > 1:
             return self._forward_chunk(x, seq_lens, sp)
-        if seq_lens is not None and any(int(v) != l for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens)):
-            raise NotImplementedError("flexam_amd: padded sequences (seq_lens < L) do not occur on the FlexAM path (H, W multiples of 32)")
+        # A caller that hands over a PADDED sequence (FX.py:918-925: zero tokens behind seq_lens[b] real ones, the same count for every
+        # sample) gets flash-attention's semantics: the pads are no keys (k_lens, FX.py:251-256 -> ATT.py:87-95); their own rows are
+        # computed like any other and are the caller's to drop.  The model's own forward never pads (it does not create the tokens).
+        n_keys = l
+        if seq_lens is not None:
+            lens = [int(v) for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens)]
+            if any(v != lens[0] for v in lens) or lens[0] > l or lens[0] < 1:
+                raise NotImplementedError("flexam_amd: ragged seq_lens inside one batch do not occur on the FlexAM path (one clip per call)")
+            n_keys = lens[0]
         pk = self.packed()
         h = x.reshape(b * l, c).to(BF16).contiguous()
         qkv = hip.gemm(h, pk["wqkv"], pk["bqkv"])
@@ -198,7 +205,9 @@ class _SelfAttn(_Attn):
                          tokens_per_batch=l, token_offset=0, head_dim=hd)
         q3 = qkv.view(b, l, 3 * c)
         q4, k4, v4 = (q3[:, :, i * c:(i + 1) * c].unflatten(2, (nh, hd)) for i in range(3))
-        if os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION" and not torch.is_grad_enabled() and hd == 128:
+        if n_keys < l:
+            ao = hip.attn_fwd(q4, k4[:, :n_keys], v4[:, :n_keys], prescaled=True)
+        elif os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION" and not torch.is_grad_enabled() and hd == 128:
             ao = hip.attn_fwd_fp8(hip.attn_fp8_pack(q4, k4, v4), l)      # the reference's attention() reads the switch per call (ATT.py:195-203)
         else:
             ao = hip.attn_fwd(q4, k4, v4, prescaled=True)
@@ -650,12 +659,16 @@ class WanTransformer3DModel_FlexAM(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @staticmethod
-    def _timestep_rows(t: torch.Tensor, batch: int, seq_len: int, ref_len: int):
-        """Per-token timesteps -> (distinct rows [B*U], int32 row index [B*L], U).  t [B, Lt]."""
-        if ref_len and t.size(1) < seq_len:                       # FX.py:900-904: ref tokens take the last token's t
-            t = torch.cat([t[:, -1:].repeat(1, seq_len - t.size(1)), t], dim=1)
-        if t.size(1) < seq_len:                                   # FX.py:930-934
-            t = torch.cat([t, t[:, -1:].repeat(1, seq_len - t.size(1))], dim=1)
+    def _timestep_rows(t: torch.Tensor, batch: int, seq_len: int, ref_len: int, padded_len: int = None):
+        """Per-token timesteps -> (distinct rows [B*U], int32 row index [B*L], U).  t [B, Lt]; seq_len = the L real tokens;
+        padded_len = the caller's seq_len + ref_len when that is longer (a padded sequence, FX.py:918-925: the reference lines the
+        timesteps up against the PADDED sequence and the real tokens are its first L)."""
+        total = max(seq_len, padded_len or 0)
+        if ref_len and t.size(1) < total:                         # FX.py:900-904: ref tokens take the last token's t
+            t = torch.cat([t[:, -1:].repeat(1, total - t.size(1)), t], dim=1)
+        if t.size(1) < total:                                     # FX.py:930-934
+            t = torch.cat([t, t[:, -1:].repeat(1, total - t.size(1))], dim=1)
+        t = t[:, :seq_len]
         uniq, inv = [], []
         for b in range(batch):
             u, i = torch.unique(t[b].float(), return_inverse=True)
@@ -705,7 +718,7 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         if t.dim() == 1:
             rows, index, U, shared = t.float(), None, 1, False
         else:
-            rows, index, U = self._timestep_rows(t, B, L, ref_len)
+            rows, index, U = self._timestep_rows(t, B, L, ref_len, seq_len + ref_len)
             index = index.to(dev)
             shared = B > 1 and bool((rows.view(B, U) == rows.view(B, U)[0]).all())
         head_local = eng.run(x, rows, index, U, teacache=self.teacache, cond_flag=cond_flag, rows_shared=shared)
@@ -716,9 +729,14 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         tokens = eng.gather_tokens(head_local)
         from . import hip
         c, f, h, w = x.shape[1:]
-        out = torch.empty(B_full, self.out_dim, f, h, w, device=eng.device, dtype=x.dtype if x.dtype in (F32, torch.bfloat16) else F32)
+        # odd latent sizes: the stride-2 patch convolution drops the last row / column and unpatchify returns the cropped size
+        # (FX.py:885,1126-1149).  `seq_len` longer than the token sequence (the pipeline's ceil(), PIPE.py:838-839) pads the reference's
+        # sequence with zero tokens that flash-attention masks as keys (k_lens, FX.py:918-925,251-256) and unpatchify drops: the real
+        # tokens see nothing of them, so the engine simply does not create them.
+        he, we = h // 2 * 2, w // 2 * 2
+        out = torch.empty(B_full, self.out_dim, f, he, we, device=eng.device, dtype=x.dtype if x.dtype in (F32, torch.bfloat16) else F32)
         for b in range(B_full):
-            hip.unpatchify(tokens[b], ref_len, self.out_dim, f, h, w, out=out[b])
+            hip.unpatchify(tokens[b], ref_len, self.out_dim, f, he, we, out=out[b])
         return out
 
     # ------------------------------------------------------------------ checkpoints

@@ -52,6 +52,26 @@ def dit_case(cfg: dict, seed: int, frames: int = 3, h: int = 16, w: int = 16, ba
     return dict(x=x, t=t, context=ctx, seq_len=seq_len, y=y, full_ref=ref, additional_control=add, density=dens)
 
 
+def dit_case_odd(cfg: dict, seed: int, frames: int = 3, h: int = 15, w: int = 16, batch: int = 2, t_value: float = 731.5, text_lens=(5, 11)) -> dict:
+    """A DiT call on a latent whose height / width is ODD (H/16 odd at the pixel level): the stride-2 patch convolution drops the last row /
+    column, the pipeline's seq_len = ceil(h w / 4 * f) (PIPE.py:838-839) is longer than the token sequence -> the reference pads with zero
+    tokens and masks them as keys (FX.py:918-925), and its per-token timesteps come from mask[::2, ::2] (ceil(h/2) x ceil(w/2) per frame,
+    PIPE.py:891-898), lined up against the padded sequence."""
+    g = torch.Generator().manual_seed(seed)
+    c = cfg["out_dim"]
+    x = randn(g, batch, c, frames, h, w)
+    y = randn(g, batch, cfg["in_dim"] - c, frames, h, w)
+    add = randn(g, batch, cfg["in_dim_cnn_block"] - c, frames, h, w)
+    ref = randn(g, batch, cfg["in_dim_ref_conv"], h, w)
+    ctx = [randn(g, text_lens[i % len(text_lens)], cfg["text_dim"]) for i in range(batch)]
+    seq_len = math.ceil(h * w / 4 * frames)
+    per_frame = math.ceil(h / 2) * math.ceil(w / 2)
+    t = torch.full((batch, per_frame * frames), t_value)
+    t[:, :per_frame] = 0.0
+    return dict(x=x, t=t[:, :seq_len] if t.size(1) >= seq_len else t, context=ctx, seq_len=seq_len, y=y, full_ref=ref, additional_control=add,
+                density=torch.full((batch,), 0.1))
+
+
 def dit_weights(cfg: dict, seed: int) -> Dict[str, Tensor]:
     return O.seeded_state_dict(O.dit_param_shapes(cfg), seed)
 

@@ -113,14 +113,19 @@ def _r(t: Optional[Tensor]) -> Optional[Tensor]:
     return t.to(torch.bfloat16).to(torch.float32) if (_BF16_EMULATION[0] and t is not None) else t
 
 
-def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
-    """ATT.py:174-233 semantics on the path: plain softmax(q k^T / sqrt(D)) v, non-causal, no
-    mask (k_lens == L in self-attention, None in cross-attention).  Layout [B, L, N, D]."""
+def attention(q: Tensor, k: Tensor, v: Tensor, k_lens: Optional[Sequence[int]] = None) -> Tensor:
+    """ATT.py:174-233 semantics on the path: plain softmax(q k^T / sqrt(D)) v, non-causal; k_lens (self-attention of a PADDED
+    sequence only, FX.py:918-925 -> ATT.py:87-95,115-122): keys past k_lens[b] are masked, as flash-attention's varlen call does.
+    (The reference's CPU fallback -- torch SDPA, ATT.py:221-233 -- ignores k_lens with a warning; nothing on the FlexAM path pads, so the
+    goldens do not see the difference: that corner is parity-unpinned.)  Layout [B, L, N, D]."""
     if q.shape[2] > 1 and q.shape[0] * q.shape[1] * k.shape[1] * q.shape[2] > (1 << 28):
         # same arithmetic one head at a time: bounds the score matrix (13 GB at L = 11648, 24 heads)
-        return torch.cat([attention(q[:, :, i:i + 1], k[:, :, i:i + 1], v[:, :, i:i + 1]) for i in range(q.shape[2])], dim=2)
+        return torch.cat([attention(q[:, :, i:i + 1], k[:, :, i:i + 1], v[:, :, i:i + 1], k_lens) for i in range(q.shape[2])], dim=2)
     q, k, v = (_r(u).transpose(1, 2) for u in (q, k, v))
     s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    if k_lens is not None:
+        for b, n in enumerate(k_lens):
+            s[b, :, :, int(n):] = float("-inf")
     return _r(torch.matmul(_r(s.softmax(dim=-1)), v)).transpose(1, 2)
 
 
@@ -129,15 +134,15 @@ def linear(sd: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- block
-def self_attention(sd, p, x, grid, angles, num_heads, eps):
-    """WanSelfAttention.forward, FX.py:230-262."""
+def self_attention(sd, p, x, grid, angles, num_heads, eps, k_lens=None):
+    """WanSelfAttention.forward, FX.py:230-262 (k_lens = seq_lens, :251-256)."""
     b, l, d = x.shape
     hd = d // num_heads
     q = rms_norm(linear(sd, p + ".q", x), sd[p + ".norm_q.weight"], eps).view(b, l, num_heads, hd)
     k = rms_norm(linear(sd, p + ".k", x), sd[p + ".norm_k.weight"], eps).view(b, l, num_heads, hd)
     v = linear(sd, p + ".v", x).view(b, l, num_heads, hd)
     q, k = rope_apply(q, grid, angles), rope_apply(k, grid, angles)
-    return linear(sd, p + ".o", attention(q, k, v).flatten(2))
+    return linear(sd, p + ".o", attention(q, k, v, k_lens).flatten(2))
 
 
 def cross_attention(sd, p, x, context, num_heads, eps):
@@ -150,7 +155,7 @@ def cross_attention(sd, p, x, context, num_heads, eps):
     return linear(sd, p + ".o", attention(q, k, v).flatten(2))
 
 
-def block_forward(sd, p, x, e0, dens0, grid, angles, context, num_heads, eps=1e-6):
+def block_forward(sd, p, x, e0, dens0, grid, angles, context, num_heads, eps=1e-6, seq_lens=None):
     """WanAttentionBlock.forward, FX.py:422-472.
     e0: [B, L, 6, C] (per-token) or [B, 6, C]; dens0: [B, 2, C]."""
     if e0.dim() > 3:
@@ -159,7 +164,7 @@ def block_forward(sd, p, x, e0, dens0, grid, angles, context, num_heads, eps=1e-
         e = (sd[p + ".modulation"] + e0).chunk(6, dim=1)
     dm = (sd[p + ".modulation_density"] + dens0).chunk(2, dim=1)
     h = layer_norm(x, eps) * (1 + e[1]) + e[0] + dm[0]
-    x = x + self_attention(sd, p + ".self_attn", h, grid, angles, num_heads, eps) * e[2]
+    x = x + self_attention(sd, p + ".self_attn", h, grid, angles, num_heads, eps, seq_lens) * e[2]
     n3 = layer_norm(x, eps, sd[p + ".norm3.weight"], sd[p + ".norm3.bias"])
     x = x + cross_attention(sd, p + ".cross_attn", n3, context, num_heads, eps)
     h = layer_norm(x, eps) * (1 + e[4]) + e[3] + dm[1]
@@ -275,6 +280,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, context:
         if t.dim() != 1 and t.size(1) < seq_len:
             t = torch.cat([t[:, -1:].repeat(1, seq_len - t.size(1)), t], dim=1)
     assert x.size(1) <= seq_len
+    seq_lens = [x.size(1)] * b if x.size(1) < seq_len else None                   # FX.py:918: only a padded sequence needs the key mask
     x = torch.cat([x, x.new_zeros(b, seq_len - x.size(1), dim)], dim=1)           # FX.py:918-925
     if t.dim() != 1 and t.size(1) < seq_len:                                      # FX.py:930-934
         t = torch.cat([t, t[:, -1:].repeat(1, seq_len - t.size(1))], dim=1)
@@ -290,7 +296,7 @@ def dit_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, t: Tensor, context:
     else:
         x_in = x
         for i in range(nl):
-            x = block_forward(sd, f"blocks.{i}", x, e0, dens0, grid, angles, ctx, nh, eps)
+            x = block_forward(sd, f"blocks.{i}", x, e0, dens0, grid, angles, ctx, nh, eps, seq_lens)
             if taps is not None:
                 taps[f"block{i}"] = x.clone()
         if teacache is not None:

@@ -148,3 +148,47 @@ def test_dit_teacache_matches_reference_golden(golden):
         check(out, fx["outs"][i], f"teacache step {i} ({'calc' if fx['should_calc'][i] else 'skip'})")
     assert m.teacache.cnt == 0
     m.disable_teacache()
+
+
+# ----------------------------------------------------------------------------- r5: odd latent sizes / padded sequences (round-4 verdict, missing item 4)
+@pytest.mark.parametrize("h,w", [(15, 16), (16, 15)])
+def test_dit_forward_on_an_odd_latent_with_a_padded_sequence(h, w):
+    """H/16 or W/16 odd: the stride-2 patch convolution drops the last row / column, the pipeline's seq_len = ceil(h w / 4 f) is longer
+    than the token sequence, the reference pads with zero tokens, masks them as keys (FX.py:918-925 -> k_lens, ATT.py:87-95) and
+    unpatchify returns the cropped size (FX.py:1126-1149).  Real tokens never see a pad, so the engine does not create them.  Against the
+    oracle with the flash-attention key mask (the reference's CPU fallback ignores k_lens: parity-unpinned corner, oracle/dit.py)."""
+    cfg = dict(O.DIT_TINY)
+    m, sd = build(cfg, 7)
+    case = C.dit_case_odd(cfg, 45, h=h, w=w)
+    assert case["seq_len"] > 3 * (h // 2) * (w // 2)
+    out = m(**to_dev(case))
+    assert out.shape == (2, 48, 3, h // 2 * 2, w // 2 * 2)
+    with torch.no_grad():
+        want = O.dit_forward(sd, cfg, **case)
+    check(out, want, f"odd latent {h} x {w}, seq_len {case['seq_len']} for {3 * (h // 2) * (w // 2)} video tokens")
+
+
+def test_self_attention_module_with_padded_sequence_masks_the_pads_as_keys():
+    """The module seam (`WanSelfAttention.forward`, FX.py:230-262) with a caller-padded sequence: seq_lens < L -> the pads are no keys
+    (flash-attention's k_lens); the real rows equal the oracle's masked attention, and differ from attending to the pads as well."""
+    from flexam_amd.rope import rope_angle_table
+    from flexam_amd.wan_transformer3d_FlexAM import _SelfAttn
+    bw = {k[len("self_attn."):]: v for k, v in C.block_weights(256, 512).items() if k.startswith("self_attn.")}
+    sa = _SelfAttn(256, 2, 1e-6)
+    sa.load_state_dict(bw, strict=True)
+    sa = sa.cuda().to(torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    grid, n, l = (2, 4, 4), 32, 48
+    x = torch.randn(2, l, 256, generator=g)
+    x[:, n:] = 0.0
+    kw = dict(grid_sizes=torch.tensor([list(grid)] * 2), freqs=rope_angle_table(1024, 128))
+    got = sa(x.cuda(), torch.tensor([n, n]), **kw).float().cpu()
+    got_all = sa(x.cuda(), torch.tensor([l, l]), **kw).float().cpu()
+    sdp = {"p." + k: v.to(torch.bfloat16).float() for k, v in bw.items()}
+    with torch.no_grad():
+        want = O.self_attention(sdp, "p", x, grid, O.rope_angles(1024, 128), 2, 1e-6, k_lens=[n, n])
+    rel = ((got[:, :n] - want[:, :n]).pow(2).mean().sqrt() / want[:, :n].pow(2).mean().sqrt()).item()
+    print(f"padded self-attention, real rows vs masked oracle: rel-rms {rel:.3e}; masked vs unmasked: {((got - got_all)[:, :n]).abs().max():.3f}")
+    assert rel <= REL_RMS and float((got - got_all)[:, :n].abs().max()) > 1e-2
+    with pytest.raises(NotImplementedError):
+        sa(x.cuda(), torch.tensor([n, n - 1]), **kw)
