@@ -246,7 +246,8 @@ def main():
             if (b_local > 1 and lvl > 0) else "")
     vae_sec = enc_sec = enc_stream_sec = None
     emulated = None
-    headline = not (args.fp8 or args.sage or args.logit_scale is not None or args.mask != "motion" or args.layers != 30)
+    headline = not (args.fp8 or args.sage or args.logit_scale is not None or args.mask != "motion" or args.layers != 30
+                    or (args.frames, args.height, args.width) != (97, 512, 896))
     n_emulate = args.emulate_rank if args.emulate_rank is not None else (8 if headline else 0)
     if n_emulate and rank == 0 and world == 1:
         from benchlib.emulate import emulate

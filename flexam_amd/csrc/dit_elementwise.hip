@@ -759,7 +759,8 @@ extern "C" int flexam_sinusoid_embed(const float* t, float* out, int R, int dim,
 extern "C" int flexam_patchify(const void* src, int src_is_bf16, int C, int F, int H, int W, void* dst, int64_t ldd, int col0,
                                int64_t row0, void* stream) {
   FX_REQUIRE(src && dst, FLEXAM_E_ARG, "patchify: null pointer");
-  FX_REQUIRE(C > 0 && F > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, FLEXAM_E_SHAPE, "patchify: H, W must be even");
+  // odd H / W: the stride-2 patch convolution drops the last row / column (FX.py:885: Conv3d without padding), as the kernel's H / 2, W / 2 do
+  FX_REQUIRE(C > 0 && F > 0 && H >= 2 && W >= 2, FLEXAM_E_SHAPE, "patchify: needs at least one 2 x 2 patch (H = %d, W = %d)", H, W);
   const int64_t total = (int64_t)F * (H / 2) * (W / 2) * C * 4;
   if (src_is_bf16)
     hipLaunchKernelGGL(patchify_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, C, F, H, W, (bf16*)dst, ldd, col0, row0);

@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256) void vae_prep_vec_kernel(const TI* __restrict_
                                                            int t0, int dst_compact) {
   // PIX positions per wave and iteration, their loads issued together: with <= 256 channels a position is one 0.5-1 KB access per
   // wave, too little in flight to cover the HBM latency (counters: 2.7 / 3.8 TB/s at 256 channels against 5.3 at 512)
-  constexpr int PIX = NSLAB == 1 ? 8 : NSLAB == 2 ? 4 : NSLAB == 3 ? 2 : 2;      // r5: twice the positions in flight per wave (r4: 4 / 2 / 1 / 1)
+#ifdef FLEXAM_PREP_PIX_R4                               // diagnostic build only (tools/ab_prep_pix.py): r4's 4 / 2 / 1 / 1 positions per wave
+  constexpr int PIX = NSLAB == 1 ? 4 : NSLAB == 2 ? 2 : 1;
+#else
+  constexpr int PIX = NSLAB == 1 ? 8 : NSLAB == 2 ? 4 : 2;                         // r5: twice the positions in flight per wave
+#endif
   const int lane = threadIdx.x & 63;
   const int Hp = H + 2, Wp = W + 2;
   const int64_t npos = (int64_t)T * H * W;
