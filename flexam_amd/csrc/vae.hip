@@ -29,33 +29,35 @@ __device__ __forceinline__ float ld(const T* p) { return (float)*p; }
 // 16-byte (fp32) / 8-byte (bf16) access and kept in registers between the sum of squares and the write (8-byte bf16x4 stores);
 // the scalar form below remains for odd channel counts.  (r1's scalar form read every row twice with 2- / 4-byte accesses and
 // ran at ~2.5 TB/s: profiles/r2b_vae_notes.txt.)
+#ifndef FLEXAM_PREP_PIX1                                // diagnostic builds (tools/ab_prep_pix.py) override the positions per wave in flight
+#define FLEXAM_PREP_PIX1 4
+#define FLEXAM_PREP_PIX2 1
+#endif
 template <typename TI, int NSLAB>
 __global__ __launch_bounds__(256) void vae_prep_vec_kernel(const TI* __restrict__ src, int64_t lds_, int C, int T, int H, int W,
                                                            const float* __restrict__ gamma, int mode, bf16* __restrict__ dst, int Cp,
                                                            int t0, int dst_compact) {
   // PIX positions per wave and iteration, their loads issued together: with <= 256 channels a position is one 0.5-1 KB access per
   // wave, too little in flight to cover the HBM latency (counters: 2.7 / 3.8 TB/s at 256 channels against 5.3 at 512)
-#ifdef FLEXAM_PREP_PIX_R4                               // diagnostic build only (tools/ab_prep_pix.py): r4's 4 / 2 / 1 / 1 positions per wave
-  constexpr int PIX = NSLAB == 1 ? 4 : NSLAB == 2 ? 2 : 1;
-#else
-  constexpr int PIX = NSLAB == 1 ? 8 : NSLAB == 2 ? 4 : 2;                         // r5: twice the positions in flight per wave
-#endif
+  // r5 A/B at the VAE's shapes (profiles/r5i_vae_prep_positions_in_flight.txt): 8 / 4 positions are 20-40 % SLOWER than 4 / 2, 512 channels best at 1
+  constexpr int PIX = NSLAB == 1 ? FLEXAM_PREP_PIX1 : NSLAB == 2 ? FLEXAM_PREP_PIX2 : 1;
   const int lane = threadIdx.x & 63;
   const int Hp = H + 2, Wp = W + 2;
-  const int64_t npos = (int64_t)T * H * W;
-  for (int64_t pos0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PIX; pos0 < npos; pos0 += (int64_t)gridDim.x * 4 * PIX) {
+  // One image row (t, h) per blockIdx.y, 4 waves x PIX positions of it per blockIdx.x: no per-position division.  (r1-r4 walked a flat
+  // position index and split it with 64-bit divisions per position -- at 160 channels that arithmetic, not HBM, set the kernel's rate.)
+  const int t = blockIdx.y / H, h = blockIdx.y - t * H;
+  const TI* srow = src + (((int64_t)t * Hp + h + 1) * Wp + 1) * lds_;
+  bf16* drow = dst + (dst_compact ? ((int64_t)t * H + h) * W : (((int64_t)(t + t0) * Hp + h + 1) * Wp + 1)) * Cp;
+  for (int w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PIX; w0 < W; w0 += gridDim.x * 4 * PIX) {
     f32x4 v[PIX][NSLAB];
     const TI* s[PIX];
     bf16* d[PIX];
+    const int npos = W, pos0 = w0;
 #pragma unroll
     for (int p = 0; p < PIX; ++p) {
-      const int64_t pos = pos0 + p < npos ? pos0 + p : npos - 1;      // a clamped tail position is loaded, never stored
-      const int w = (int)(pos % W);
-      int64_t r = pos / W;
-      const int h = (int)(r % H);
-      const int t = (int)(r / H);
-      s[p] = src + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * lds_;
-      d[p] = dst + (dst_compact ? pos : (((int64_t)(t + t0) * Hp + h + 1) * Wp + w + 1)) * Cp;
+      const int w = pos0 + p < npos ? pos0 + p : npos - 1;             // a clamped tail position is loaded, never stored
+      s[p] = srow + (int64_t)w * lds_;
+      d[p] = drow + (int64_t)w * Cp;
     }
 #pragma unroll
     for (int p = 0; p < PIX; ++p)
@@ -99,6 +101,12 @@ __global__ __launch_bounds__(256) void vae_prep_vec_kernel(const TI* __restrict_
       }
     }
   }
+}
+
+// blocks along a row: every wave walks ~4 groups of PIX positions (a block per 16 PIX positions would live for a microsecond)
+inline int prep_grid_x(int W, int pix) {
+  const int groups = (W + 4 * pix - 1) / (4 * pix);
+  return groups >= 8 ? (groups + 3) / 4 : groups >= 2 ? (groups + 1) / 2 : 1;
 }
 
 template <typename TI>
@@ -436,6 +444,35 @@ __global__ __launch_bounds__(256) void avgdown_add_kernel(float* __restrict__ xm
   }
 }
 
+// The same with Ci == Co (g = ft * fs * fs: output channel c is the mean of input channel c over the ft x fs x fs block -- plain average
+// pooling, the encoder's first stage): four consecutive channels per thread, 16-byte loads of x_in and one 16-byte read-modify-write.
+// (The scalar form above moved 445 MB in 231 us at 256 x 448 x 160: 1.9 TB/s.)
+__global__ __launch_bounds__(256) void avgdown_add_same_kernel(float* __restrict__ xm, int64_t ldm, int C, int To, int Ho, int Wo,
+                                                               const float* __restrict__ xin, int64_t ldi, int ft, int fs, int pad_t) {
+  const int Hp = Ho * fs + 2, Wp = Wo * fs + 2, Hop = Ho + 2, Wop = Wo + 2;
+  const float inv = 1.f / (float)(ft * fs * fs);
+  const int cvec = C >> 2;
+  const int64_t total = (int64_t)To * Ho * Wo * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cvec) * 4;
+    int64_t r = i / cvec;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int to = (int)(r / Ho);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int st = 0; st < ft; ++st) {
+      const int t = to * ft + st - pad_t;
+      if (t < 0) continue;
+      for (int sh = 0; sh < fs; ++sh)
+        for (int sw = 0; sw < fs; ++sw)
+          acc += __builtin_nontemporal_load((const f32x4*)(xin + (((int64_t)t * Hp + ho * fs + sh + 1) * Wp + wo * fs + sw + 1) * ldi + c));
+    }
+    float* xo = xm + (((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + c;
+    *(f32x4*)xo = *(const f32x4*)xo + acc * inv;
+  }
+}
+
 }  // namespace
 
 extern "C" int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_src, int C, int T, int H, int W, const float* gamma,
@@ -446,11 +483,13 @@ extern "C" int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_s
   const int64_t npos = (int64_t)T * H * W;
   dim3 grid(grid_for(npos, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  FX_REQUIRE((int64_t)T * H <= 65535, FLEXAM_E_SHAPE, "vae_prep_cl: %ld image rows exceed the grid's 65535 (shorter chunks)", (long)T * H);
   const bool vec = C % 4 == 0 && C <= 1024 && ld_src % 4 == 0 && Cp % 4 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0 &&
                    (!gamma || (uintptr_t)gamma % 16 == 0);
+  // vector form: one image row per blockIdx.y, 4 waves x PIX positions per blockIdx.x (PIX as in the kernel)
 #define PREP_VEC(TI_, NS_)                                                                                                         \
-  hipLaunchKernelGGL((vae_prep_vec_kernel<TI_, NS_>), grid, block, 0, st, (const TI_*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, \
-                     Cp, t0, dst_compact)
+  hipLaunchKernelGGL((vae_prep_vec_kernel<TI_, NS_>), dim3(prep_grid_x(W, (NS_) == 1 ? FLEXAM_PREP_PIX1 : (NS_) == 2 ? FLEXAM_PREP_PIX2 : 1), T * H), \
+                     block, 0, st, (const TI_*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact)
   if (vec) {
     const int ns = (C + 255) / 256;
     if (src_is_bf16) {
@@ -582,7 +621,11 @@ extern "C" int flexam_avgdown_add_cl(float* x_main, int64_t ld_main, int Co, int
   FX_REQUIRE((ft == 1 || ft == 2) && (fs == 1 || fs == 2) && (Ci * ft * fs * fs) % Co == 0, FLEXAM_E_SHAPE, "avgdown_add_cl: bad factors");
   const int pad_t = (ft - Ti % ft) % ft;
   FX_REQUIRE((Ti + pad_t) / ft == To, FLEXAM_E_SHAPE, "avgdown_add_cl: %d input frames do not give %d output frames", Ti, To);
-  hipLaunchKernelGGL(avgdown_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * Co, 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
-                     Co, To, Ho, Wo, x_in, ld_in, Ci, ft, fs, pad_t);
+  if (Ci == Co && Co % 4 == 0 && ld_main % 4 == 0 && ld_in % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)x_in % 16 == 0)
+    hipLaunchKernelGGL(avgdown_add_same_kernel, dim3(grid_for((int64_t)To * Ho * Wo * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, x_main,
+                       ld_main, Co, To, Ho, Wo, x_in, ld_in, ft, fs, pad_t);
+  else
+    hipLaunchKernelGGL(avgdown_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * Co, 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
+                       Co, To, Ho, Wo, x_in, ld_in, Ci, ft, fs, pad_t);
   return flexam_check_launch("flexam_avgdown_add_cl");
 }

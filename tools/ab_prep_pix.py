@@ -1,13 +1,17 @@
-"""Dev tool: vae_prep (RMS-norm + SiLU + bf16 pack) with 8 / 4 / 2 positions per wave in flight (tree) against r4's 4 / 2 / 1
-(tools/probes/libflexam_hip_prep_pix_r4.so: the tree's vae.hip compiled with -DFLEXAM_PREP_PIX_R4=1), round-robin in one process at the
-VAE's shapes.  usage: ab_prep_pix.py"""
+"""Dev tool: vae_prep (RMS-norm + SiLU + bf16 pack): positions per wave in flight.  The tree (4 / 2 / 1 for <= 256 / <= 512 / more channels)
+against diagnostic builds tools/probes/libflexam_hip_prep_pix_<a>_<b>.so (the tree's vae.hip compiled with -DFLEXAM_PREP_PIX1=a
+-DFLEXAM_PREP_PIX2=b), round-robin in one process at the VAE's shapes.  usage: ab_prep_pix.py"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from flexam_amd import hip as H
 
-libs = {"tree (8/4/2)": H.lib(), "r4 (4/2/1)": ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "libflexam_hip_prep_pix_r4.so"))}
+import glob
+libs = {"tree 4/2": H.lib()}
+for path in sorted(glob.glob(os.path.join(ROOT, "tools", "probes", "libflexam_hip_prep_pix_*_*.so"))):
+    a, b = os.path.basename(path)[:-3].split("_")[-2:]
+    libs[f"{a}/{b}"] = ctypes.CDLL(path)
 for l in libs.values():
     l.flexam_vae_prep_cl.restype = ctypes.c_int
     l.flexam_vae_prep_cl.argtypes = H._SIGNATURES["flexam_vae_prep_cl"][0]
@@ -34,5 +38,5 @@ for name, t, h, w, c, dt in SHAPES:
             e.record(); torch.cuda.synchronize()
             res.setdefault(k, []).append(s.elapsed_time(e) * 100.0)
     nbytes = t * h * w * c * (src.element_size() + 2)
-    line = "  ".join(f"{k}: {sorted(v)[len(v) // 2]:7.1f} us ({nbytes / sorted(v)[len(v) // 2] / 1e6:5.2f} TB/s)" for k, v in res.items())
+    line = "  ".join(f"{k}: {sorted(v)[len(v) // 2]:6.1f} us ({nbytes / sorted(v)[len(v) // 2] / 1e6:4.2f})" for k, v in res.items())
     print(f"{name:26s} {line}", flush=True)
