@@ -20,6 +20,19 @@ inline int grid_for(int64_t total, int block) {
 template <typename T>
 __device__ __forceinline__ float ld(const T* p) { return (float)*p; }
 
+// Row walk of the elementwise kernels (r5): blockIdx.y is one image row (t, h) of the kernel's iteration space, the threads of the
+// blocks along x walk its (w, 4-channel vector) pairs with 32-bit arithmetic.  (r1-r4 split a flat 64-bit element index with three
+// 64-bit divisions per thread: for 16-32 bytes moved per thread that arithmetic, not HBM, set the rate -- vae_prep 2.9 -> 3.7 TB/s at
+// 160 channels once it was gone, profiles/r5j_*.)
+inline dim3 row_grid(int T, int H, int per_row) {
+  int gx = (per_row + 255) / 256;
+  if (gx > 8) gx = (gx + 3) / 4;                       // ~4 iterations per thread on long rows
+  return dim3(gx, T * H);
+}
+#define ROW_WALK(H_, per_row_, j_)                                     \
+  const int t = blockIdx.y / (H_), h = blockIdx.y - t * (H_);          \
+  for (int j_ = blockIdx.x * 256 + threadIdx.x; j_ < (per_row_); j_ += gridDim.x * 256)
+
 // ------------------------------------------------------------------------------------------
 // prep: rows -> image / matrix, one wave per interior position.
 //   mode 0: cast;  mode 1: F.normalize(x, channel) * sqrt(C) * gamma;  mode 2: mode 1 + SiLU.
@@ -213,19 +226,14 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const TI* __restrict_
                                                            bf16* __restrict__ dst, int Cp) {
   const int Hp = H + 2, Wp = W + 2;
   const int cvec = C >> 2;
-  const int64_t total = (int64_t)2 * T * H * W * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cvec) * 4;
-    int64_t r = i / cvec;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int to = (int)(r / H);
+  ROW_WALK(H, W * cvec, j) {                            // iteration space: the 2T output frames
+    const int w = j / cvec, c = (j - w * cvec) * 4;
+    const int to = t;
     const int64_t pos = (((int64_t)(to >> 1) * Hp + h + 1) * Wp + w + 1);
     const TI* s = src + pos * lds_ + (to & 1) * C + c;
     bf16x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f2bf(ld(s + j));
+    for (int q = 0; q < 4; ++q) o[q] = f2bf(ld(s + q));
     *(bf16x4*)(dst + (((int64_t)to * Hp + h + 1) * Wp + w + 1) * Cp + c) = o;
   }
 }
@@ -243,17 +251,12 @@ __global__ __launch_bounds__(256) void phase_dupup_kernel(const float* __restric
   const int Hp = H + 2, Wp = W + 2, Hop = Ho + 2, Wop = Wo + 2;
   const int repeats = Co * ft * 4 / Ci;
   const int cvec = Co >> 2;
-  const int64_t total = (int64_t)To * Ho * Wo * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int co = (int)(i % cvec) * 4;
-    int64_t r = i / cvec;
-    const int wo = (int)(r % Wo);
-    r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int to = (int)(r / Ho);
+  ROW_WALK(Ho, Wo * cvec, j) {                          // iteration space: the To x Ho output rows
+    const int wo = j / cvec, co = (j - wo * cvec) * 4;
+    const int to = t, ho = h;
     const int tt = to + drop;
-    const int t = tt / ft, st = tt - t * ft;
-    const float* xi = xin + (((int64_t)t * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldi;
+    const int ti = tt / ft, st = tt - ti * ft;
+    const float* xi = xin + (((int64_t)ti * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldi;
     const int sub = st * 4 + (ho & 1) * 2 + (wo & 1);
     const float* pp = ph + (int64_t)((ho & 1) * 2 + (wo & 1)) * phase_stride + (((int64_t)to * Hp + (ho >> 1) + 1) * Wp + (wo >> 1) + 1) * ldp + co;
     f32x4 x = __builtin_nontemporal_load((const f32x4*)pp);
@@ -275,14 +278,8 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ y
                                                      const float* __restrict__ bias, float* __restrict__ out, int64_t ldo) {
   const int Hp = H + 2, Wp = W + 2;
   const int cvec = Co >> 2;
-  const int64_t total = (int64_t)T * H * W * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int o = (int)(i % cvec) * 4;
-    int64_t r = i / cvec;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int t = (int)(r / H);
+  ROW_WALK(H, W * cvec, j) {
+    const int w = j / cvec, o = (j - w * cvec) * 4;
     f32x4 acc = bias ? *(const f32x4*)(bias + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int dt = 0; dt < kt; ++dt)
 #pragma unroll
@@ -398,14 +395,8 @@ __global__ __launch_bounds__(256) void space_to_depth_kernel(const TI* __restric
                                                              bf16* __restrict__ dst, int Cs, int t0) {
   const int Hp = H + 2, Wp = W + 2, H2p = H / 2 + 2, W2p = W / 2 + 2;
   const int cvec = C >> 2;
-  const int64_t total = (int64_t)T * H * W * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cvec) * 4;
-    int64_t r = i / cvec;
-    const int w = (int)(r % W);
-    r /= W;
-    const int h = (int)(r % H);
-    const int t = (int)(r / H);
+  ROW_WALK(H, W * cvec, j) {
+    const int w = j / cvec, c = (j - w * cvec) * 4;
     const TI* s = src + (((int64_t)t * Hp + h + 1) * Wp + w + 1) * lds_ + c;
     bf16x4 o;
     o[0] = f2bf(ld(s));
@@ -452,21 +443,16 @@ __global__ __launch_bounds__(256) void avgdown_add_same_kernel(float* __restrict
   const int Hp = Ho * fs + 2, Wp = Wo * fs + 2, Hop = Ho + 2, Wop = Wo + 2;
   const float inv = 1.f / (float)(ft * fs * fs);
   const int cvec = C >> 2;
-  const int64_t total = (int64_t)To * Ho * Wo * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cvec) * 4;
-    int64_t r = i / cvec;
-    const int wo = (int)(r % Wo);
-    r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int to = (int)(r / Ho);
+  ROW_WALK(Ho, Wo * cvec, j) {                          // iteration space: the To x Ho output rows
+    const int wo = j / cvec, c = (j - wo * cvec) * 4;
+    const int to = t, ho = h;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int st = 0; st < ft; ++st) {
-      const int t = to * ft + st - pad_t;
-      if (t < 0) continue;
+      const int ti = to * ft + st - pad_t;
+      if (ti < 0) continue;
       for (int sh = 0; sh < fs; ++sh)
         for (int sw = 0; sw < fs; ++sw)
-          acc += __builtin_nontemporal_load((const f32x4*)(xin + (((int64_t)t * Hp + ho * fs + sh + 1) * Wp + wo * fs + sw + 1) * ldi + c));
+          acc += __builtin_nontemporal_load((const f32x4*)(xin + (((int64_t)ti * Hp + ho * fs + sh + 1) * Wp + wo * fs + sw + 1) * ldi + c));
     }
     float* xo = xm + (((int64_t)to * Hop + ho + 1) * Wop + wo + 1) * ldm + c;
     *(f32x4*)xo = *(const f32x4*)xo + acc * inv;
@@ -533,11 +519,11 @@ extern "C" int flexam_deinterleave_cl(const void* src, int src_is_bf16, int64_t 
   FX_REQUIRE(src && dst, FLEXAM_E_ARG, "deinterleave_cl: null pointer");
   FX_REQUIRE(C % 4 == 0 && C <= Cp && Cp % 4 == 0 && 2 * C <= ld_src && T > 0 && H > 0 && W > 0, FLEXAM_E_SHAPE,
              "deinterleave_cl: C=%d must be a multiple of 4 and 2C <= ld_src=%ld", C, (long)ld_src);
-  const int64_t total = (int64_t)2 * T * H * W * (C / 4);
+  FX_REQUIRE((int64_t)2 * T * H <= 65535, FLEXAM_E_SHAPE, "deinterleave_cl: %ld image rows exceed the grid's 65535", (long)2 * T * H);
   if (src_is_bf16)
-    hipLaunchKernelGGL(deinterleave_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cp);
+    hipLaunchKernelGGL(deinterleave_kernel<bf16>, row_grid(2 * T, H, W * (C / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cp);
   else
-    hipLaunchKernelGGL(deinterleave_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, (bf16*)dst, Cp);
+    hipLaunchKernelGGL(deinterleave_kernel<float>, row_grid(2 * T, H, W * (C / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, (bf16*)dst, Cp);
   return flexam_check_launch("flexam_deinterleave_cl");
 }
 
@@ -547,7 +533,8 @@ extern "C" int flexam_phase_dupup_cl(const float* phases, int64_t ld_ph, int64_t
   FX_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0 && (ft == 1 || ft == 2) && (Co * ft * 4) % Ci == 0, FLEXAM_E_SHAPE, "phase_dupup_cl: bad shape");
   FX_REQUIRE(Co % 4 == 0 && ld_main % 4 == 0 && ld_ph % 4 == 0 && phase_stride % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)phases % 16 == 0,
              FLEXAM_E_SHAPE, "phase_dupup_cl: Co, ld_main, ld_ph and phase_stride must be multiples of 4");
-  hipLaunchKernelGGL(phase_dupup_kernel, dim3(grid_for((int64_t)To * Ho * Wo * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, phases, ld_ph,
+  FX_REQUIRE((int64_t)To * Ho <= 65535, FLEXAM_E_SHAPE, "phase_dupup_cl: %ld image rows exceed the grid's 65535", (long)To * Ho);
+  hipLaunchKernelGGL(phase_dupup_kernel, row_grid(To, Ho, Wo * (Co / 4)), dim3(256), 0, (hipStream_t)stream, phases, ld_ph,
                      phase_stride, x_main, ld_main, Co, To, Ho, Wo, x_in, ld_in, Ci, ft, drop);
   return flexam_check_launch("flexam_phase_dupup_cl");
 }
@@ -558,7 +545,8 @@ extern "C" int flexam_tapsum_cl(const float* y, int64_t ld_y, int T, int H, int 
   FX_REQUIRE(T > 0 && H > 0 && W > 0 && kt >= 1 && kt <= 3 && Co > 0 && Co % 4 == 0 && ld_y >= (int64_t)kt * 9 * Co && ld_y % 4 == 0 && ld_out % 4 == 0 &&
              (uintptr_t)y % 16 == 0 && (uintptr_t)out % 16 == 0 && (!bias || (uintptr_t)bias % 16 == 0), FLEXAM_E_SHAPE,
              "tapsum_cl: Co=%d must be a multiple of 4, ld_y=%ld >= kt*9*Co, 16-byte aligned rows", Co, (long)ld_y);
-  hipLaunchKernelGGL(tapsum_kernel, dim3(grid_for((int64_t)T * H * W * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, y, ld_y, T, H, W, kt, Co,
+  FX_REQUIRE((int64_t)T * H <= 65535, FLEXAM_E_SHAPE, "tapsum_cl: %ld image rows exceed the grid's 65535", (long)T * H);
+  hipLaunchKernelGGL(tapsum_kernel, row_grid(T, H, W * (Co / 4)), dim3(256), 0, (hipStream_t)stream, y, ld_y, T, H, W, kt, Co,
                      bias, out, ld_out);
   return flexam_check_launch("flexam_tapsum_cl");
 }
@@ -607,11 +595,11 @@ extern "C" int flexam_space_to_depth_cl(const void* src, int src_is_bf16, int64_
   FX_REQUIRE(src && dst, FLEXAM_E_ARG, "space_to_depth_cl: null pointer");
   FX_REQUIRE(C % 4 == 0 && C <= Cs && Cs % 4 == 0 && C <= ld_src && H % 2 == 0 && W % 2 == 0 && T > 0, FLEXAM_E_SHAPE,
              "space_to_depth_cl: bad shape C=%d Cs=%d H=%d W=%d", C, Cs, H, W);
-  const int64_t total = (int64_t)T * H * W * (C / 4);
+  FX_REQUIRE((int64_t)T * H <= 65535, FLEXAM_E_SHAPE, "space_to_depth_cl: %ld image rows exceed the grid's 65535", (long)T * H);
   if (src_is_bf16)
-    hipLaunchKernelGGL(space_to_depth_kernel<bf16>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cs, t0);
+    hipLaunchKernelGGL(space_to_depth_kernel<bf16>, row_grid(T, H, W * (C / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cs, t0);
   else
-    hipLaunchKernelGGL(space_to_depth_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, (bf16*)dst, Cs, t0);
+    hipLaunchKernelGGL(space_to_depth_kernel<float>, row_grid(T, H, W * (C / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, C, T, H, W, (bf16*)dst, Cs, t0);
   return flexam_check_launch("flexam_space_to_depth_cl");
 }
 
@@ -621,8 +609,8 @@ extern "C" int flexam_avgdown_add_cl(float* x_main, int64_t ld_main, int Co, int
   FX_REQUIRE((ft == 1 || ft == 2) && (fs == 1 || fs == 2) && (Ci * ft * fs * fs) % Co == 0, FLEXAM_E_SHAPE, "avgdown_add_cl: bad factors");
   const int pad_t = (ft - Ti % ft) % ft;
   FX_REQUIRE((Ti + pad_t) / ft == To, FLEXAM_E_SHAPE, "avgdown_add_cl: %d input frames do not give %d output frames", Ti, To);
-  if (Ci == Co && Co % 4 == 0 && ld_main % 4 == 0 && ld_in % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)x_in % 16 == 0)
-    hipLaunchKernelGGL(avgdown_add_same_kernel, dim3(grid_for((int64_t)To * Ho * Wo * (Co / 4), 256)), dim3(256), 0, (hipStream_t)stream, x_main,
+  if (Ci == Co && Co % 4 == 0 && ld_main % 4 == 0 && ld_in % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)x_in % 16 == 0 && (int64_t)To * Ho <= 65535)
+    hipLaunchKernelGGL(avgdown_add_same_kernel, row_grid(To, Ho, Wo * (Co / 4)), dim3(256), 0, (hipStream_t)stream, x_main,
                        ld_main, Co, To, Ho, Wo, x_in, ld_in, ft, fs, pad_t);
   else
     hipLaunchKernelGGL(avgdown_add_kernel, dim3(grid_for((int64_t)To * Ho * Wo * Co, 256)), dim3(256), 0, (hipStream_t)stream, x_main, ld_main,
