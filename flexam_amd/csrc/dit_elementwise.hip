@@ -259,10 +259,12 @@ __global__ __launch_bounds__(RT) void rmsnorm_rope_kernel(RmsRopeArgs a, int C, 
   }
   const float r = __builtin_amdgcn_rsqf(row_sum(s, red) / (float)C + eps);
   const float* w = a.w[which];
-  bf16* orow = SCATTER ? a.out[which] + (m / tokens_per_batch) * a.out_bs + (m % tokens_per_batch) * a.ld_out[which]
+  bf16* orow = SCATTER ? a.out[which] + (int64_t)((uint32_t)m / (uint32_t)tokens_per_batch) * a.out_bs +
+                             (int64_t)((uint32_t)m % (uint32_t)tokens_per_batch) * a.ld_out[which]
                        : a.out[which] + m * a.ld_out[which];
   const int half = head_dim >> 1;
-  const int64_t tok = token_offset + (m % tokens_per_batch);
+  // 32-bit: a 64-bit modulo per thread costs as much as the rest of a thread's work here (three 16-byte loads and stores)
+  const int64_t tok = token_offset + (int64_t)((uint32_t)m % (uint32_t)tokens_per_batch);
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
     const int vec = threadIdx.x + i * RT;
