@@ -171,3 +171,13 @@ def test_one_gpu_line_carries_an_emulated_rank_of_four():
     # and without the flag a debug-size run (not the headline workload) does not emulate
     r = _run(["--gpus", "1", *SMALL], {})
     assert r.returncode == 0 and "emulated_ranks" not in json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+
+
+@pytest.mark.gpu
+def test_logit_scale_line_says_what_it_measured():
+    """`bench.py --logit-scale S`: norm_q / norm_k x sqrt(S) on the random-init model (peaked softmax rows); a variant line, never the headline."""
+    r = _run(["--gpus", "1", *SMALL, "--logit-scale", "6"], {})
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["logit_scale"]["std_asked"] == 6.0 and "logits scaled to std ~6" in res["config"]["workload"] and "not the headline" in res["config"]["workload"]
+    assert res["finite"] and "emulated_ranks" not in res
