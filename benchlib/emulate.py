@@ -21,6 +21,8 @@ def layouts(world: int, num_heads: int):
         out.append((f"cfg2 x sp{world // 2}, K|V all-gather (default)", "allgather", True, None))
     if world >= 4 and num_heads % world == 0:
         out.append((f"cfg1 x sp{world}, all-to-all over heads", "ulysses", False, None))
+    if world >= 4 and world % 2 == 0 and num_heads % (world // 2) == 0:
+        out.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, None))
     if world % 2 or world == 2:
         out.append((f"cfg1 x sp{world}, K|V all-gather", "allgather", False, None))
     return out

@@ -162,7 +162,8 @@ def test_one_gpu_line_carries_an_emulated_rank_of_four():
     em = res["emulated_ranks"]
     assert res["n_gpus"] == 1 and "invalid" not in res and em["world"] == 4
     names = [row["layout"] for row in em["layouts"]]
-    assert names[0].startswith("cfg2 x sp2, K|V all-gather") and names[1].startswith("cfg1 x sp4, all-to-all over heads") and len(names) == 2
+    assert names[0].startswith("cfg2 x sp2, K|V all-gather") and names[1].startswith("cfg1 x sp4, all-to-all over heads")
+    assert names[2].startswith("cfg2 x sp2, all-to-all over heads") and len(names) == 3
     row = em["layouts"][0]
     assert row["sp_size"] == 2 and row["cfg_size"] == 2 and row["samples_per_rank"] == 1 and row["tokens_per_rank"] * 2 == 256 and row["ms_per_step"] > 0
     row = em["layouts"][1]
