@@ -46,7 +46,7 @@ def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
     assert res["finite"]
     if world >= 4 and not env:             # nothing pinned: two steps of every candidate layout were timed and the fastest one ran
         lp = res["layout_probe"]
-        assert len(lp["candidates"]) == 4 and lp["chosen"] in [c["layout"] for c in lp["candidates"]]
+        assert len(lp["candidates"]) == 5 and lp["chosen"] in [c["layout"] for c in lp["candidates"]]
         assert all(c["ms_per_step"] > 0 and c["wall_sec"] > 0 for c in lp["candidates"])
         assert lp["communicators"] <= 3, lp                 # world + the two CFG halves, however many layouts were selected
     else:
@@ -126,13 +126,13 @@ def test_probe_skips_a_candidate_that_raises_or_blows_its_budget_and_goes_on():
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     lp = res["layout_probe"]
-    assert len(lp["candidates"]) == 3 and len(lp["skipped"]) == 1 and "RuntimeError" in lp["skipped"][0]["error"]
+    assert len(lp["candidates"]) == 4 and len(lp["skipped"]) == 1 and "RuntimeError" in lp["skipped"][0]["error"]
     assert lp["chosen"] in [c["layout"] for c in lp["candidates"]] and res["check"]["ok"] and lp["communicators"] <= 3
     r = _run(["--gpus", "4", *SMALL], {**base, "FLEXAM_BENCH_PROBE_BUDGET": "0"})
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     lp = res["layout_probe"]
-    assert lp["candidates"] == [] and len(lp["skipped"]) == 4 and lp["chosen"].startswith("none measured")
+    assert lp["candidates"] == [] and len(lp["skipped"]) == 5 and lp["chosen"].startswith("none measured")
     assert res["check"]["ok"] and res["config"]["parallelism"].startswith("cfg2 x sp2")
 
 
@@ -146,7 +146,7 @@ def test_probe_retries_a_candidate_whose_first_touch_was_over_budget():
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     lp = res["layout_probe"]
-    assert len(lp["candidates"]) == 4 and "skipped" not in lp, lp
+    assert len(lp["candidates"]) == 5 and "skipped" not in lp, lp
     retried = [c for c in lp["candidates"] if c["retried"]]
     assert len(retried) == 1 and retried[0]["layout"].startswith("cfg2 x sp2, K|V all-gather") and lp["candidates"][-1] is not None
     assert lp["budget_covers"].startswith("denoise_step(0) only") and res["check"]["ok"]

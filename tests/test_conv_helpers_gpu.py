@@ -160,3 +160,50 @@ def test_patchify_s2d_avgdown_match_torch():
         H.avgdown_add_cl(xm, co, to, ho, wo, padded_rows(xin).to(dev()), ci, ti, ft, fs)
         got = xm.view(to, ho + 2, wo + 2, co)[:, 1:-1, 1:-1].permute(3, 0, 1, 2).cpu()
         torch.testing.assert_close(got, base + want, rtol=1e-5, atol=1e-5)
+
+
+def test_deinterleave_phase_dupup_and_tapsum_match_torch():
+    """r5 helpers of the VAE decoder: temporal de-interleave at the input resolution, interleave of the four phase outputs + DupUp3D
+    shortcut, and the 27-tap gather of the folded head convolution."""
+    from flexam_amd import hip as H
+    g = torch.Generator().manual_seed(9)
+    # deinterleave: rows [T, 2C] -> image of 2T frames, frame 2t + s = channels [sC, (s+1)C) of frame t
+    c, t, h, w = 8, 3, 4, 6
+    x = torch.randn(2 * c, t, h, w, generator=g)
+    img = torch.zeros(2 * t, h + 2, w + 2, 64, dtype=BF, device=dev())
+    H.deinterleave_cl(padded_rows(x).to(dev()), c, t, h, w, img)
+    y = x.view(2, c, t, h, w)
+    want = torch.stack((y[0], y[1]), dim=2).reshape(c, 2 * t, h, w)
+    bf16_close(img[:, 1:-1, 1:-1, :c].permute(3, 0, 1, 2), want)
+    assert float(img[..., c:].abs().max()) == 0 and float(img[:, 0].abs().max()) == 0
+    # phase_dupup: x_main[(t', 2y + a, 2x + b)] = phases[a * 2 + b][(t', y, x)] + DupUp3D(x_in); first-chunk crop and regular
+    ci, co = 32, 16
+    for first, t_in in ((True, 1), (False, 2)):
+        xin = torch.randn(ci, t_in, h, w, generator=g)
+        to = 1 if first else 2 * t_in
+        ph = torch.randn(4, co, to, h, w, generator=g)
+        ph_rows = torch.stack([padded_rows(ph[i]) for i in range(4)]).to(dev())
+        out = torch.full((to * (2 * h + 2) * (2 * w + 2), co), float("nan"), device=dev())
+        H.phase_dupup_cl(ph_rows, out, co, to, 2 * h, 2 * w, padded_rows(xin).to(dev()), ci, 2, 1 if first else 0)
+        inter = torch.zeros(co, to, 2 * h, 2 * w)
+        for a in range(2):
+            for b in range(2):
+                inter[:, :, a::2, b::2] = ph[a * 2 + b]
+        rep = co * 8 // ci
+        d = xin[None].repeat_interleave(rep, dim=1).view(1, co, 2, 2, 2, t_in, h, w).permute(0, 1, 5, 2, 6, 3, 7, 4).reshape(1, co, 2 * t_in, 2 * h, 2 * w)
+        d = d[:, :, 1:] if first else d
+        got = out.view(to, 2 * h + 2, 2 * w + 2, co)[:, 1:-1, 1:-1].permute(3, 0, 1, 2).cpu()
+        torch.testing.assert_close(got, inter + d[0], rtol=1e-6, atol=1e-6)
+    # tapsum: out = bias + sum over 3x3x3 taps of Y[(t + dt, h + dh - 1, w + dw - 1), tap * Co + o] == causal conv3d of the image
+    cin, co, kt, t = 6, 12, 3, 2
+    xs = torch.randn(cin, kt - 1 + t, h, w, generator=g)                       # history frames + current frames
+    wt = torch.randn(co, cin, kt, 3, 3, generator=g) / math.sqrt(cin * 27)
+    b = torch.randn(co, generator=g)
+    wf = wt.permute(2, 3, 4, 0, 1).reshape(kt * 9 * co, cin)
+    yrows = (padded_rows(xs) @ wf.t()).to(dev()).contiguous()                   # per-tap products, fp32
+    out = torch.zeros(t * (h + 2) * (w + 2), co, device=dev())
+    H.tapsum_cl(yrows, t, h, w, kt, co, b.to(dev()), out)
+    want = F.conv3d(F.pad(xs[None], (1, 1, 1, 1, 0, 0)), wt, b)[0]              # [co, t, h, w]
+    got = out.view(t, h + 2, w + 2, co)[:, 1:-1, 1:-1].permute(3, 0, 1, 2).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+    assert float(out.view(t, h + 2, w + 2, co)[:, 0].abs().max()) == 0          # border rows are not written
