@@ -1,5 +1,5 @@
-"""Dev tool: vae_prep (RMS-norm + SiLU + bf16 pack): positions per wave in flight.  The tree (4 / 2 / 1 for <= 256 / <= 512 / more channels)
-against diagnostic builds tools/probes/libflexam_hip_prep_pix_<a>_<b>.so (the tree's vae.hip compiled with -DFLEXAM_PREP_PIX1=a
+"""Dev tool: vae_prep (RMS-norm + SiLU + bf16 pack): the span form (<= 256 channels, r5) against the wave-per-position form
+(FLEXAM_VAE_PREP_WAVE=1) of the tree, and against diagnostic builds tools/probes/libflexam_hip_prep_pix_<a>_<b>.so (the tree's vae.hip compiled with -DFLEXAM_PREP_PIX1=a
 -DFLEXAM_PREP_PIX2=b), round-robin in one process at the VAE's shapes.  usage: ab_prep_pix.py"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,13 +8,15 @@ import torch
 from flexam_amd import hip as H
 
 import glob
-libs = {"tree 4/2": H.lib()}
+libs = {"tree": H.lib()}
 for path in sorted(glob.glob(os.path.join(ROOT, "tools", "probes", "libflexam_hip_prep_pix_*_*.so"))):
     a, b = os.path.basename(path)[:-3].split("_")[-2:]
     libs[f"{a}/{b}"] = ctypes.CDLL(path)
 for l in libs.values():
     l.flexam_vae_prep_cl.restype = ctypes.c_int
     l.flexam_vae_prep_cl.argtypes = H._SIGNATURES["flexam_vae_prep_cl"][0]
+# arms: (label, library, FLEXAM_VAE_PREP_WAVE): the tree's span form (<= 256 channels) against its wave-per-position form, + any diagnostic build
+arms = [("span", libs["tree"], None), ("wave", libs["tree"], "1")] + [(k, l, "1") for k, l in libs.items() if k != "tree"]
 dev = torch.device("cuda:0")
 st = torch.cuda.current_stream().cuda_stream
 # (name, frames, h, w, C, src dtype): encoder stage 0 / 1, decoder stages 3 / 2 / low resolution
@@ -30,7 +32,10 @@ for name, t, h, w, c, dt in SHAPES:
     dst = torch.zeros(t, h + 2, w + 2, cp, device=dev, dtype=torch.bfloat16)
     res = {}
     for rnd in range(5):
-        for k, l in libs.items():
+        for k, l, wave in arms:
+            os.environ.pop("FLEXAM_VAE_PREP_WAVE", None)
+            if wave:
+                os.environ["FLEXAM_VAE_PREP_WAVE"] = wave
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(10):
