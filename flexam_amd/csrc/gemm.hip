@@ -197,6 +197,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       }
     }
   };
+  // ---- gate rows of the wave tile through LDS the same way (gate-residual epilogue with a per-row table index): two dwords per lane
+  // (tile rows l and 64 + l of the wave's 16 MT rows) by LDS-DMA in front of the unit's K block 0.  Fetched inside the epilogue --
+  // `p.gate_row[m]` right in front of the gate loads that need it, once per batch of 32 rows -- the index loads were the YOUNGEST
+  // entries of the wave's in-order vmcnt queue: waiting for them drained every X load and the previous batch's stores, 4 times
+  // per tile.
+  constexpr bool GROW_LDS = STD && !TAIL && EPI == EPI_GATE_RESIDUAL;
+  constexpr int GROW_OFF = BIAS_OFF + 2 * 8 * 256;              // [2 slots][8 waves][128 ints]
+  auto grow_dma = [&](int m0, int slot) {
+    if constexpr (GROW_LDS) {
+      const int32_t* pg = p.gate_row;
+      asm volatile("" : "+s"(pg));
+      if (pg) {
+#pragma unroll
+        for (int h = 0; h < (16 * MT > 64 ? 2 : 1); ++h) {
+          const uint32_t voff = (uint32_t)min(m0 + wm * (16 * MT) + 64 * h + fresh_lane(), p.M - 1) * 4u;
+          const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(smem) + GROW_OFF + ((slot * 8 + wave) * 128 + 64 * h) * 4;
+          asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(pg), "s"(dst) : "memory");
+        }
+      }
+    }
+  };
   if constexpr (BIAS_LDS) {
     if (!p.bias) {                // no bias: both slots hold zeros for the whole launch (wave-local, ordered before any later read)
       float* z = (float*)(smem + BIAS_OFF + wave * 256);
@@ -283,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   bf16x8 f0[NF], f1[NF];
   if (!staged) {
     bias_dma(n0, it & 1);
+    grow_dma(m0, it & 1);
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma(i, kcol_a(kb0), (int64_t)kb0 * BK, smem);
     if (nkl > 1) {
@@ -357,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     tile_origin(ntile, nm0, nn0);
     stage_setup(nm0, nn0);
     bias_dma(nn0, (it + 1) & 1);
+    grow_dma(nm0, (it + 1) & 1);
 #pragma unroll
     for (int i = 0; i < NP; ++i) dma(i, kcol_a(nkb0), (int64_t)nkb0 * BK, smem);
     if (nnkl > 1) {
@@ -444,29 +467,44 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       auto rmw = [&](auto gate_c) {
         constexpr int GATE = decltype(gate_c)::value;
         constexpr int TPB = 32 / RT;                   // row tiles per batch of 32 rows (8 load / store instructions)
-#pragma unroll
-        for (int t0 = 0; t0 < NRT; t0 += TPB) {
+        constexpr int NB = (NRT + TPB - 1) / TPB;      // batches per wave tile
+        // TWO batches in flight: the X (and gate) loads of batch b + 1 are issued before batch b is consumed, so a wave pays
+        // NB / 2 + 1 HBM round trips per tile instead of NB (the accumulators are packed into yp by now: the registers are there)
+        f32x4 xv[2][8], gv[8];
+        auto load_x = [&](int b, f32x4 (&xb)[8]) {
+          const int t0 = b * TPB;
           const int ntb = NRT - t0 < TPB ? NRT - t0 : TPB;   // compile-time after unrolling
           const int nit = ntb * RT / 4;
-          f32x4 xv[8], gv[8];
-          int gr[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             if (i >= nit) continue;
-            const int m = mw + t0 * RT + 4 * i + rr;
             // X is 286 MB of fp32 at the DiT shapes -- larger than the Infinity Cache -- and every element is touched once per launch:
             // non-temporal loads and stores keep it from evicting the operands that ARE re-read (-0.8 ... -0.9 % of a step, profiles/r4as_*)
-            xv[i] = __builtin_nontemporal_load((const f32x4*)(xtile + (int64_t)(t0 * RT + 4 * i) * p.ldx * 4 + xlane));
-            if constexpr (GATE == 1) gr[i] = p.gate_row[m];
-            if constexpr (GATE == 2) gr[i] = m / p.rows_per_batch;
+            xb[i] = __builtin_nontemporal_load((const f32x4*)(xtile + (int64_t)(t0 * RT + 4 * i) * p.ldx * 4 + xlane));
           }
+        };
+        // gate rows of the wave tile: in LDS since this unit's K block 0 (grow_dma)
+        const int* growl = (const int*)(smem + GROW_OFF) + ((it & 1) * 8 + wave) * 128 + rr;
+        // the gate values come from a small table (L2): one batch of them at a time, fetched when the previous batch has been consumed
+        auto load_g = [&](int b) {
           if constexpr (GATE != 0) {
+            const int t0 = b * TPB;
+            const int ntb = NRT - t0 < TPB ? NRT - t0 : TPB;
+            const int nit = ntb * RT / 4;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               if (i >= nit) continue;
-              gv[i] = *(const f32x4*)(p.gate + (int64_t)gr[i] * p.gate_ld + nw);
+              const int row = t0 * RT + 4 * i;           // + rr
+              int gr;
+              if constexpr (GATE == 1) gr = growl[row];
+              else gr = (mw + row + rr) / p.rows_per_batch;
+              gv[i] = *(const f32x4*)(p.gate + (int64_t)gr * p.gate_ld + nw);
             }
           }
+        };
+        auto consume = [&](int b, const f32x4 (&xb)[8]) {
+          const int t0 = b * TPB;
+          const int ntb = NRT - t0 < TPB ? NRT - t0 : TPB;
 #pragma unroll
           for (int u = 0; u < TPB; ++u) {
             if (u >= ntb) continue;
@@ -476,13 +514,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
             for (int i = 0; i < RT / 4; ++i) {
               const int row = 4 * i + rr, idx = u * (RT / 4) + i;
               const bf16x4 y = *(const bf16x4*)(stg + row * 128 + (((cc >> 1) ^ (row & 7)) << 4) + (cc & 1) * 8);
-              f32x4 x = xv[idx];
+              f32x4 x = xb[idx];
 #pragma unroll
               for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[idx][j] : bf2f(y[j]);
               __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane));
             }
           }
-          __builtin_amdgcn_sched_barrier(0);           // one batch of loads in flight at a time: all of them at once would not fit the registers
+        };
+        __builtin_amdgcn_sched_barrier(0);             // (behind the conversion of the accumulators: in front of it the loads do not fit)
+        load_x(0, xv[0]);
+        load_g(0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          if (b + 1 < NB) load_x(b + 1, xv[(b + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);           // the next batch's X loads are on their way before this one is consumed
+          consume(b, xv[b & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (b + 1 < NB) load_g(b + 1);
         }
       };
       if (!p.gate) rmw(IC<0>{});
@@ -663,7 +711,7 @@ template <int EPI, typename OutT, int MT, int WMW = 2, int NTW = 4>
 int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
   auto kern = gemm_bf16_kernel<EPI, OutT, MT, false, WMW, NTW>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};          // per device: the attribute belongs to the device's copy of the code object
-  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 2 * 8 * 256;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots per wave
+  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 2 * 8 * 256 + 2 * 8 * 512;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots + two gate-row slots per wave
   const int dev = flexam_current_device();
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
