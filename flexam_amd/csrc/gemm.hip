@@ -730,7 +730,7 @@ int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff,
   static const int persist = [] { const char* e = getenv("FLEXAM_GEMM_PERSIST"); return e ? atoi(e) : 1; }();
   auto grid_for_units = [&](int nwg) {
     int grid = (nwg + 7) / 8 * 8;                        // a multiple of 8 so that blockIdx & 7 is the XCD
-    if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (144 / 160 KiB of LDS each)
+    if (persist && grid > num_cus()) grid = num_cus();   // one persistent workgroup per CU (156 of its 160 KiB of LDS)
     return grid;
   };
   if (p.split_full > 0) hipLaunchKernelGGL(kern, dim3(grid_for_units(p.split_full)), dim3(512), smem, s, p, a_koff);
