@@ -579,6 +579,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       continue;                                        // next tile of this persistent workgroup
     }
   }
+  if constexpr (EPI == EPI_GATE_RESIDUAL) {
+    // Read-modify-write in the accumulator layout (edge tiles; every tile of the 160-wide shape: the VAE's residual convolutions).
+    // The X (and gate) loads of a whole row tile are issued together and one row tile ahead of the stores.  (Written as one load,
+    // add, store per 16-byte unit, hipcc kept that order -- it cannot prove the units of different rows apart -- and put a
+    // vmcnt(0) in front of every store: NRT * NV serial HBM round trips per tile, each also waiting for the store before it.)
+    constexpr int DEPTH = STD ? 1 : 2;                 // the 256-wide instances have no registers to spare next to 128 accumulators
+    auto rmw_rows = [&](auto gate_c) {
+      constexpr bool GATE = decltype(gate_c)::value;
+      f32x4 xq[DEPTH][NV], gq[DEPTH][NV];
+      int grr[NRT];                                    // gate-table row per row tile, all fetched up front (a fetch per row tile would be
+      if constexpr (GATE) {                            // the youngest load in flight: waiting for it drains the queue)
+#pragma unroll
+        for (int t = 0; t < NRT; ++t) {
+          const int m = min(mrow + t * RT, p.M - 1);
+          grr[t] = p.gate_row ? p.gate_row[m] : (int)(m / p.rows_per_batch);
+        }
+      }
+      // loads are unconditional (rows / columns past the edge re-read the last valid ones), only the stores are predicated
+      auto ldt = [&](int t, f32x4 (&xb)[NV], f32x4 (&gb)[NV]) {
+        const int m = min(mrow + t * RT, p.M - 1);
+        const float* grow = nullptr;
+        if constexpr (GATE) grow = p.gate + (int64_t)grr[t] * p.gate_ld;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int n = min(ncol + v * (4 * NG), p.N - 4);
+          xb[v] = *(const f32x4*)(p.X + (int64_t)m * p.ldx + n);
+          if constexpr (GATE) gb[v] = *(const f32x4*)(grow + n);
+        }
+      };
+      if constexpr (DEPTH == 2) ldt(0, xq[0], gq[0]);
+#pragma unroll
+      for (int t = 0; t < NRT; ++t) {
+        if constexpr (DEPTH == 2) {
+          if (t + 1 < NRT) ldt(t + 1, xq[(t + 1) & 1], gq[(t + 1) & 1]);
+        } else {
+          ldt(t, xq[0], gq[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = mrow + t * RT;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int n = ncol + v * (4 * NG);
+          const f32x4 y4 = accv(t, v) + bias[v];
+          f32x4 x = xq[t % DEPTH][v];
+          // y is rounded to bf16 first, like the reference's bf16 Linear output (FX.py:456,461,468)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[j] += GATE ? bf2f(f2bf(y4[j])) * gq[t % DEPTH][v][j] : bf2f(f2bf(y4[j]));
+          if (m < p.M && n < p.N) *(f32x4*)(p.X + (int64_t)m * p.ldx + n) = x;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (p.gate) rmw_rows(std::integral_constant<bool, true>{});
+    else rmw_rows(std::integral_constant<bool, false>{});
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): an unknown number of stores, drained here (pend stays false)
+    continue;
+  }
 #pragma unroll
   for (int t = 0; t < NRT; ++t) {
     const int m = mrow + t * RT;
