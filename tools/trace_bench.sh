@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): bash tools/trace_bench.sh <outdir> [bench.py args...]   (environment is passed through)
-# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-vae --no-clip --no-kernel-timing`;
+# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-vae --no-clip --no-kernel-timing --emulate-rank 0`
+# (the emulated-rank legs of the default line launch the same kernels at other shapes: they would pollute the per-kernel averages);
 # copies the kernel stats CSV to <outdir>/kernel_stats.csv and prints the top rows
 set -euo pipefail
 : "${GRAFT_REPO_ROOT:?run through gpurun, from the repo root}"
@@ -9,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 mkdir -p "$R/$out"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out/trace" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-vae --no-clip --no-kernel-timing "$@" > "$R/$out/bench.json" 2> "$R/$out/trace.log" || { tail -20 "$R/$out/trace.log"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$out/trace" -- python3 "$R/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-vae --no-clip --no-kernel-timing --emulate-rank 0 "$@" > "$R/$out/bench.json" 2> "$R/$out/trace.log" || { tail -20 "$R/$out/trace.log"; exit 1; }
 f=$(find "$R/$out/trace" -name "*kernel_stats.csv" | head -1)
 cp "$f" "$R/$out/kernel_stats.csv"
 python3 - "$R/$out/kernel_stats.csv" <<'PY'
