@@ -849,10 +849,11 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
     // Tile-rows per L2 group.  Plain-store epilogues: 4 tile-rows x 8 tile-columns resident per XCD is the smallest panel set
     // (12 panels of 32 KiB per K block) and measured best (profiles/r1e notes; r3 round-robin over 1 / 2 / 4 / 8 / 16:
     // profiles/r3d_gemm_gm_ab.txt).  Gate-residual epilogues read-modify-write 1 KiB of an X row per tile: there the resident
-    // tiles' X footprint matters more than panel sharing -- one tile-row across all columns (whole 12 KiB rows of X, long K) or a
-    // tall group (short K, where the epilogue is a fifth of the tile) were 2.0 % / 2.6 % faster than 4.
+    // tiles' X footprint matters more than panel sharing with a long K -- one tile-row across all columns (whole 12 KiB rows of X):
+    // 3 % faster than 4 at K = 14336.  With a short K (o-proj) r3 measured a tall group of 16 ahead; with the r5 epilogue (two
+    // batches of X in flight) 4 ... 12 are level and 16 is 0.6 % behind (profiles/r5zb_gemm_gm_sweep.txt): 4 like the plain stores.
     const char* g = getenv("FLEXAM_GEMM_GM");
-    p.gm = g ? atoi(g) : (EPI == EPI_GATE_RESIDUAL && a_koff == nullptr ? (p.K >= 8192 ? 1 : 16) : 4);
+    p.gm = g ? atoi(g) : (EPI == EPI_GATE_RESIDUAL && a_koff == nullptr && p.K >= 8192 ? 1 : 4);
     if (p.gm < 1) p.gm = 4;
   }
 #ifdef FLEXAM_GEMM_ABLATE

@@ -20,6 +20,7 @@ gate = torch.randn(4, d, device=dev)
 rows = (torch.arange(M, device=dev) % 2).to(torch.int32)
 cases = {
     "qkv": (lambda: H.gemm(x, w_qkv, b3, out=out_q), 2.0 * M * 3 * d * d),
+    "cross-q": (lambda: H.gemm(x, w_o, bd, out=out_q[:, :d]), 2.0 * M * d * d),
     "ffn1 + gelu": (lambda: H.gemm(x, w_f1, bf_, out=out_f, epilogue=H.EPI_GELU_TANH), 2.0 * M * f * d),
     "ffn2 + residual": (lambda: H.gemm_gate_residual(hmid, w_f2, bd, xres, gate=gate, gate_row=rows), 2.0 * M * d * f),
     "o-proj + residual": (lambda: H.gemm_gate_residual(x, w_o, bd, xres, gate=gate, gate_row=rows), 2.0 * M * d * d),
@@ -27,7 +28,7 @@ cases = {
 var, arms = sys.argv[1], sys.argv[2:]
 for name, (fn, fl) in cases.items():
     res = {a: [] for a in arms}
-    for rnd in range(7):
+    for rnd in range(int(os.environ.get('FLEXAM_AB_ROUNDS', '7'))):
         for a in (arms if rnd % 2 == 0 else arms[::-1]):
             os.environ[var] = a
             fn(); torch.cuda.synchronize()
