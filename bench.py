@@ -245,7 +245,7 @@ def main():
              ", the samples of the CFG pair as pipeline stages: a sample's blocks travel under the other's projection / attention")
             if (b_local > 1 and lvl > 0) else "")
     vae_sec = enc_sec = enc_stream_sec = None
-    emulated = None
+    emulated = raster = None
     headline = not (args.fp8 or args.sage or args.logit_scale is not None or args.mask != "motion" or args.layers != 30
                     or (args.frames, args.height, args.width) != (97, 512, 896))
     n_emulate = args.emulate_rank if args.emulate_rank is not None else (8 if headline else 0)
@@ -268,6 +268,11 @@ def main():
         vae_sec, enc_stream_sec, enc_image_sec, vae_finite, vae = time_vae(device, args.frames, args.height, args.width)
         enc_sec = 7 * enc_stream_sec + enc_image_sec     # control, depth, 4 cos levels, masked video + the reference image
         finite = finite and vae_finite
+        try:                                             # the step before the encode: tracks -> conditioning videos
+            from benchlib.vae_clip import time_raster
+            raster = time_raster(device, args.frames, args.height, args.width, cpu_leg=not args.no_cpu_baseline)
+        except Exception as e:                           # noqa: BLE001
+            raster = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_clip and args.mask == "motion":
             try:                                         # the measured clip must not cost the steps/s line if it fails
                 sec, shape, ok = time_clip(model, vae, inp, args.frames, args.height, args.width, total_steps, device)
@@ -320,6 +325,7 @@ def main():
             "sec_per_clip_50_steps_denoise_only": total_steps / steps_per_sec,
             "vae_decode_sec": vae_sec, "vae_encode_sec_per_stream": enc_stream_sec, "conditioning_encode_sec_8_streams": enc_sec,
             "prepare_sec": prepare_sec,
+            "conditioning_raster": raster,
             "clip_end_to_end": clip,
             "sec_per_clip": (enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
             "dit_block_executed_tflops": executed_block_flops * steps_per_sec / 1e12,

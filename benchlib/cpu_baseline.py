@@ -84,3 +84,32 @@ def cpu_baseline_legs(cfg, layers=3):
                                  extrapolated_seconds_97x512x896=sec2 / 5.0 * 97.0 * 16.0),
     }
 
+
+
+def raster_inputs(frames, height, width, step=4, seed=0):
+    """Synthetic tracks of the clip's size: a `step`-pixel grid of points that drifts apart over the frames (28672 points per frame at
+    512 x 896), random depths, 5 % invisible.  [T, N, 3] float32 (u, v, depth), [T, N] bool."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    ys, xs = np.meshgrid(np.arange(step // 2, height, step), np.arange(step // 2, width, step), indexing="ij")
+    base = np.stack([xs.ravel(), ys.ravel()], -1).astype(np.float32)
+    n = base.shape[0]
+    pts = np.zeros((frames, n, 3), np.float32)
+    drift = rng.normal(0, 0.6, (n, 2)).astype(np.float32)
+    for t in range(frames):
+        pts[t, :, :2] = base + drift * t
+    pts[:, :, 2] = rng.uniform(0.5, 9, (frames, n))
+    return pts, rng.random((frames, n)) > 0.05
+
+
+def raster_port_leg(pts, vis, height, width, sample_frames=2):
+    """CPU leg of the conditioning rasteriser: the numpy oracle (oracle/raster.py: the reference's six videos, vectorised -- NOT its
+    per-point PIL loop, which takes ~125 s per clip in the build container) on `sample_frames` frames, extrapolated to the clip."""
+    from oracle import raster as O
+    t_n = pts.shape[0]
+    sub = [0] + list(range(t_n // 2, t_n // 2 + sample_frames - 1))
+    t0 = time.perf_counter()
+    O.visualize_tracking(pts[sub], vis[sub], 4, height, width, 4)
+    sec = time.perf_counter() - t0
+    return dict(seconds=sec, cores=1, kind="port", sample=f"{len(sub)} of {t_n} frames, all six videos (oracle/raster.py, numpy)",
+                extrapolated_seconds_clip=sec / len(sub) * t_n)

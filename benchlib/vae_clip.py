@@ -62,3 +62,29 @@ def time_clip(model, vae, inp, frames, height, width, steps, device):
     sec = time.perf_counter() - t0
     return sec, tuple(out.shape), bool(torch.isfinite(out.float()).all())
 
+
+
+def time_raster(device, frames, height, width, cpu_leg=True):
+    """The conditioning rasteriser at the clip's size: tracked points -> the six conditioning videos on the GPU
+    (flexam_amd.conditioning_raster.visualize_tracking_DELTA: host colour tables + csrc/raster.hip), best of 3 after a warm-up run."""
+    from flexam_amd import conditioning_raster as P
+    from .cpu_baseline import raster_inputs, raster_port_leg
+    pts, vis = raster_inputs(frames, height, width)
+    best = None
+    for it in range(4):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        tr, cos, dep = P.visualize_tracking_DELTA(pts, vis, False, 4, height, width, 4, device=device)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if it:
+            best = dt if best is None else min(best, dt)
+    painted = float((tr[0].sum(0) > 0).float().mean().item())
+    out = {"sec": best, "points_per_frame": int(pts.shape[1]), "frames": frames, "videos": 6, "painted_fraction_tracking": painted,
+           "what": "tracks [T, N, 3] + visibility on the host -> tracking, 4 cosine-level and depth videos [1, 3, T, H, W] fp32 on the GPU "
+                   "(pipelines.py:1852-1902); the reference's PIL loop for the same input: ~125 s in the build container (8 cores, 1 used)"}
+    del tr, cos, dep
+    torch.cuda.empty_cache()
+    if cpu_leg:
+        out["cpu_baseline"] = raster_port_leg(pts, vis, height, width)
+    return out

@@ -4,12 +4,13 @@ Exports the reference's names (FlexAM/models/__init__.py, FlexAM/pipeline/__init
 `pipelines.py` / ComfyUI nodes can import them unchanged:
     Wan2_2Transformer3DModel_FlexAM, WanTransformer3DModel_FlexAM, AutoencoderKLWan3_8,
     Wan2_2FunControlPipeline_FlexAM, attention
+and, for the step in front of the sampler, `visualize_tracking_DELTA` (pipelines.py:1852: tracks -> conditioning videos).
 Arithmetic runs in libflexam_hip.so (hand-written gfx950 HIP kernels, C ABI in
 include/flexam_hip.h); this package is the host-side mirror of the reference interface.
 """
 __all__ = ["Wan2_2Transformer3DModel_FlexAM", "WanTransformer3DModel_FlexAM", "AutoencoderKLWan3_8",
            "Wan2_2FunControlPipeline_FlexAM", "FlowMatchEulerDiscreteScheduler", "FlowUniPCMultistepScheduler",
-           "FlowDPMSolverMultistepScheduler", "WanT5EncoderModel", "attention"]
+           "FlowDPMSolverMultistepScheduler", "WanT5EncoderModel", "attention", "visualize_tracking_DELTA"]
 
 
 def __getattr__(name):
@@ -38,4 +39,7 @@ def __getattr__(name):
     if name == "attention":
         from .attention_utils import attention
         return attention
+    if name == "visualize_tracking_DELTA":
+        from .conditioning_raster import visualize_tracking_DELTA
+        return visualize_tracking_DELTA
     raise AttributeError(name)

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflexam_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attn.hip", "dit_elementwise.hip", "conv_cl.hip", "vae.hip", "text_encoder.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attn.hip", "dit_elementwise.hip", "conv_cl.hip", "vae.hip", "text_encoder.hip", "raster.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
          "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
 

@@ -66,6 +66,8 @@ _SIGNATURES = {
     "flexam_scatter_add_cl": ([_P, _L, _P, _L, _I, _I, _I, _I, _P], c_int),
     "flexam_vae_unpatchify_clamp": ([_P, _L, _I, _I, _I, _P, _I, _I, _F, _F, _P], c_int),
     "flexam_pack_affine_cl": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
+    "flexam_raster_keys": ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
+    "flexam_raster_resolve": ([_P, _P, _L, _I, _I, _I, _P, _P, _P], c_int),
     "flexam_t5_norm": ([_P, _L, _L, _I, _F, _P, _P, _L, _I, _P], c_int),
     "flexam_softmax_bias_rows": ([_P, _L, _L, _I, _F, _P, _L, _P, _P, _L, _I, _P], c_int),
     "flexam_mul_bf16": ([_P, _P, _P, _L, _P], c_int),
@@ -804,3 +806,46 @@ def mul_bf16(a, b, out=None):
         raise RuntimeError("mul_bf16: contiguous bf16 tensors of equal shape required")
     _check(lib().flexam_mul_bf16(_ptr(a, BF16), _ptr(b, BF16), _ptr(out, BF16), a.numel(), _stream()), "flexam_mul_bf16")
     return out
+
+
+# ----------------------------------------------------------------------------- conditioning rasteriser (csrc/raster.hip)
+def raster_keys(points, visible, height, width, half, y_min=0, mask=None, keys=None):
+    """points [T, N, 3] fp32 (u, v, depth), visible [T, N] uint8 / bool or None, mask [T, H, W] fp32 or None -> keys [T, H, W] int64
+    (the uint64 key image of flexam_raster_keys: per pixel the nearest drawn point, all ones = none)."""
+    if points.dim() != 3 or points.shape[2] != 3 or not points.is_contiguous():
+        raise RuntimeError(f"raster_keys: contiguous points [T, N, 3] required, got {tuple(points.shape)}")
+    T, N, _ = points.shape
+    if visible is not None:
+        if visible.dtype == torch.bool:
+            visible = visible.view(U8)
+        if visible.shape != (T, N) or not visible.is_contiguous():
+            raise RuntimeError(f"raster_keys: visible must be contiguous [T, N] = {(T, N)}, got {tuple(visible.shape)}")
+    if mask is not None and (mask.shape != (T, height, width) or not mask.is_contiguous()):
+        raise RuntimeError(f"raster_keys: mask must be contiguous [T, H, W] = {(T, height, width)}, got {tuple(mask.shape)}")
+    if keys is None:
+        keys = torch.empty(T, height, width, device=points.device, dtype=torch.int64)
+    elif keys.shape != (T, height, width) or keys.dtype != torch.int64 or not keys.is_contiguous():
+        raise RuntimeError("raster_keys: keys must be a contiguous int64 [T, H, W] buffer")
+    _check(lib().flexam_raster_keys(_ptr(points, F32), _ptr(visible, U8), T, N, height, width, half, y_min, _ptr(mask, F32), _ptr(keys), _stream()),
+           "flexam_raster_keys")
+    return keys
+
+
+def raster_resolve(keys, colors, out_u8=None, out_f32=None, want_u8=False, want_f32=True):
+    """keys [T, H, W] (raster_keys), colors [N, 3] or [T, N, 3] uint8 -> (bytes [T, H, W, 3] or None, planes [3, T, H, W] fp32 = byte / 255 or None)."""
+    T, H, W = keys.shape
+    if colors.dtype != U8 or colors.shape[-1] != 3 or not colors.is_contiguous() or colors.dim() not in (2, 3):
+        raise RuntimeError(f"raster_resolve: contiguous uint8 colours [N, 3] or [T, N, 3] required, got {tuple(colors.shape)} {colors.dtype}")
+    if colors.dim() == 3 and colors.shape[0] != T:
+        raise RuntimeError("raster_resolve: per-frame colours need one table per frame")
+    stride = colors.shape[1] * 3 if colors.dim() == 3 else 0
+    if out_u8 is None and want_u8:
+        out_u8 = torch.empty(T, H, W, 3, device=keys.device, dtype=U8)
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty(3, T, H, W, device=keys.device, dtype=F32)
+    for o, shp in ((out_u8, (T, H, W, 3)), (out_f32, (3, T, H, W))):
+        if o is not None and (tuple(o.shape) != shp or not o.is_contiguous()):
+            raise RuntimeError(f"raster_resolve: output must be contiguous {shp}, got {tuple(o.shape)}")
+    _check(lib().flexam_raster_resolve(_ptr(keys, torch.int64), _ptr(colors, U8), stride, T, H, W, _ptr(out_u8, U8), _ptr(out_f32, F32), _stream()),
+           "flexam_raster_resolve")
+    return out_u8, out_f32

@@ -337,6 +337,25 @@ int flexam_softmax_bias_rows(const float* s, int64_t ld_s, int64_t M, int N, flo
                              const float* key_mask, void* out, int64_t ld_out, int Npad, void* stream);
 int flexam_mul_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 
+
+
+/* Conditioning rasteriser: tracked points [T, N, 3] (u, v, depth; fp32) -> conditioning video frames.  Replaces the per-point PIL
+ * drawing loops of the reference's pipelines.py -- fun_visualize_tracking_with_depth :1501-1575 (valid_mask :1200-1212,
+ * sort_points_by_depth :1214-1232, draw_rectangle :1234-1253), _render_cosine_encoded_frame :1694-1728, _visualize_depth_tracking
+ * :1763-1820, _should_draw_point :1842-1850, _convert_frames_to_tensor :1658-1660 -- whose result per pixel is the colour of the
+ * NEAREST point among the squares covering it (far-to-near painting).
+ * raster_keys: keys[T][H][W] (uint64) = min over the drawn points whose square [x - half, x + half] x [y - half, y + half] (clipped to
+ *   the frame) covers the pixel of (order-preserving code of the depth << 32 | point index); all ones = no point.  A point is drawn when
+ *   visible[t][n] != 0 (NULL: all), its (u, v) are finite, (x, y) = (u, v) truncated towards zero lie in [0, W) x [y_min, H) (y_min = 1
+ *   for the tracking video, whose frame test is y > 0, else 0) and, with a mask video [T][H][W], mask[t][y][x] > 0.5.  Equal depths: the
+ *   lower index wins; NaN depths lose against everything.  The call clears `keys` itself.
+ * raster_resolve: out_u8[T][H][W][3] and / or out_f32[3][T][H][W] (= byte / 255, correctly rounded) from the winners' colours;
+ *   colors[N][3] bytes shared by all frames (color_frame_stride = 0) or [T][N][3] (stride N * 3: the depth video's per-frame colours). */
+int flexam_raster_keys(const float* points, const unsigned char* visible, int T, int N, int H, int W, int half, int y_min,
+                       const float* mask, unsigned long long* keys, void* stream);
+int flexam_raster_resolve(const unsigned long long* keys, const unsigned char* colors, int64_t color_frame_stride, int T, int H, int W,
+                          unsigned char* out_u8, float* out_f32, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,149 @@
+"""GPU: the HIP conditioning rasteriser (csrc/raster.hip behind flexam_amd/conditioning_raster.py, through the C ABI) -- bit-exact
+against the reference's fixtures (tests/golden/g13_raster_*) and the numpy oracle, and at the clip's full size (97 x 512 x 896, a
+4-pixel grid of 28672 tracked points) through properties that do not need the oracle: every painted pixel shows a point whose square
+covers it and no nearer drawn point does, point order does not matter, a second run is identical."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import make_golden_raster as G
+from oracle import raster as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _bytes(video):
+    """[1, 3, T, H, W] float in [0, 1] -> [T, H, W, 3] uint8; the float must be EXACTLY byte / 255 in float32."""
+    v = video[0].permute(1, 2, 3, 0).cpu()
+    b = (v * 255).round().to(torch.uint8)
+    assert torch.equal(b.float() / 255.0, v)
+    return b.numpy()
+
+
+@pytest.mark.parametrize("name", ("plain", "edges", "foreground", "wide"))
+def test_hip_rasteriser_matches_reference_fixture(golden, name):
+    from flexam_amd import conditioning_raster as P
+    g = golden(f"g13_raster_{name}")
+    pts, vis, mask, gen, point_wise = G.case(name)
+    tracking, cos, depth = P.visualize_tracking_DELTA(torch.from_numpy(pts), torch.from_numpy(vis), False, point_wise, G.H, G.W, 4, gen,
+                                                      mask_video=mask, device=DEV)
+    assert tracking.shape == (1, 3, G.T, G.H, G.W) and tracking.dtype == torch.float32 and tracking.is_cuda
+    assert np.array_equal(_bytes(tracking), g["tracking"].numpy())
+    for i in range(4):
+        assert np.array_equal(_bytes(cos[i]), g[f"cos{i}"].numpy())
+    assert np.array_equal(_bytes(depth), g["depth"].numpy())
+    fr = P.fun_visualize_tracking_with_depth(torch.from_numpy(pts), torch.from_numpy(vis), G.H, G.W, point_wise, mask, gen, device=DEV)
+    assert fr.dtype == torch.uint8 and np.array_equal(fr.cpu().numpy(), g["tracking"].numpy())
+
+
+def test_hip_rasteriser_vs_oracle_ties_nan_depths_and_background_mask():
+    """What the fixtures cannot hold (the reference's order among equal depths is not reproducible): many equal depths, NaN and
+    negative depths, -0.0, a [T, N, 1] visibility tensor, background_edit with a mask."""
+    from flexam_amd import conditioning_raster as P
+    rng = np.random.default_rng(5)
+    t_n, n, h, w = 5, 3000, 72, 104
+    pts = np.stack([rng.uniform(-8, w + 8, (t_n, n)), rng.uniform(-8, h + 8, (t_n, n)), rng.integers(1, 6, (t_n, n)).astype(np.float64)], -1).astype(np.float32)
+    pts[1, :50, 2] = np.nan
+    pts[2, 50:90, 2] = -pts[2, 50:90, 2]
+    pts[3, 90:120, 2] = -0.0
+    pts[3, 120:150, 2] = 0.0
+    vis = rng.random((t_n, n, 1)) > 0.15
+    mask = (rng.random((t_n, h, w)) > 0.5).astype(np.float32)
+    for gen, m, pw in (("full_edit", None, 4), ("background_edit", mask, 4), ("full_edit", mask, 8)):
+        tr, cos, dep = P.visualize_tracking_DELTA(pts, torch.from_numpy(vis), False, pw, h, w, 2, gen, mask_video=m, device=DEV)
+        o_t, o_c, o_d = O.visualize_tracking(pts, vis, pw, h, w, 2, gen, m)
+        assert torch.equal(tr.cpu(), o_t) and torch.equal(dep.cpu(), o_d)
+        for i in range(2):
+            assert torch.equal(cos[i].cpu(), o_c[i])
+
+
+def test_raster_resolve_float_is_the_correctly_rounded_quotient():
+    """out_f32 = byte / 255 for every byte value, as torch's `.float() / 255.0` gives it (pipelines.py:1660)."""
+    from flexam_amd import hip as H
+    pts = torch.zeros(1, 256, 3, device=DEV)
+    pts[0, :, 0] = torch.arange(256, device=DEV) + 0.5
+    pts[0, :, 1] = 0.5
+    pts[0, :, 2] = 1.0
+    colors = torch.arange(256, dtype=torch.uint8, device=DEV)[:, None].repeat(1, 3).contiguous()
+    keys = H.raster_keys(pts.contiguous(), None, 1, 256, 0)
+    u8, f32 = H.raster_resolve(keys, colors, want_u8=True, want_f32=True)
+    assert torch.equal(u8[0, 0, :, 0].cpu(), torch.arange(256, dtype=torch.uint8))
+    assert torch.equal(f32[1, 0, 0].cpu(), torch.arange(256, dtype=torch.uint8).float() / 255.0)
+
+
+def _grid_clip(t_n, h, w, step, seed):
+    rng = np.random.default_rng(seed)
+    ys, xs = np.meshgrid(np.arange(step // 2, h, step), np.arange(step // 2, w, step), indexing="ij")
+    base = np.stack([xs.ravel(), ys.ravel()], -1).astype(np.float32)
+    n = base.shape[0]
+    pts = np.zeros((t_n, n, 3), np.float32)
+    drift = rng.normal(0, 0.6, (n, 2)).astype(np.float32)
+    for t in range(t_n):
+        pts[t, :, :2] = base + drift * t + rng.normal(0, 0.3, (n, 2))
+    pts[:, :, 2] = rng.permutation(t_n * n).reshape(t_n, n).astype(np.float32) / (t_n * n) * 9 + 0.5       # all depths distinct
+    return pts, rng.random((t_n, n)) > 0.05
+
+
+def test_full_size_clip_properties_and_two_frames_vs_oracle():
+    """BASELINE size: 97 x 512 x 896, 28672 points per frame (a 4-pixel grid that drifts apart)."""
+    from flexam_amd import conditioning_raster as P
+    from flexam_amd import hip as H
+    t_n, h, w = 97, 512, 896
+    pts, vis = _grid_clip(t_n, h, w, 4, 11)
+    n = pts.shape[1]
+    tr, cos, dep = P.visualize_tracking_DELTA(pts, vis, False, 4, h, w, 4, device=DEV)
+    assert tr.shape == (1, 3, t_n, h, w) and len(cos) == 4 and dep.shape == tr.shape
+    # (1) two frames against the oracle
+    enc3 = O.cosine_encodings(pts, h, w, 4)[3]                                                   # its depth code is normalised over the WHOLE clip
+    u8 = lambda v, t: (v[0, :, t].permute(1, 2, 0).cpu() * 255).round().to(torch.uint8).numpy()
+    for t in (0, 61):
+        sub_p, sub_v = pts[[0, t]], vis[[0, t]]                                                  # frame 0 defines the colours
+        assert np.array_equal(u8(tr, t), O.tracking_frames(sub_p, sub_v, h, w, 4)[1])
+        assert np.array_equal(u8(cos[3], t), O.cosine_frames(enc3[[0, t]], sub_p, sub_v, h, w)[1])
+        assert np.array_equal(u8(dep, t), O.depth_frames(sub_p, sub_v, h, w, 4)[1])
+    # (2) the key image: the winner of every painted pixel covers it, is drawn, and no drawn point covering it is nearer
+    d_pts, d_vis = torch.from_numpy(pts).to(DEV), torch.from_numpy(vis).to(DEV)
+    keys = H.raster_keys(d_pts, d_vis, h, w, 2, 0)
+    t_sel = 40
+    k = keys[t_sel].cpu().numpy().view(np.uint64)
+    win = (k & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    painted = k != np.uint64(0xFFFFFFFFFFFFFFFF)
+    yy, xx = np.nonzero(painted)
+    wi = win[painted]
+    px = pts[t_sel, wi, :2].astype(int)
+    assert vis[t_sel, wi].all() and (np.abs(px[:, 0] - xx) <= 2).all() and (np.abs(px[:, 1] - yy) <= 2).all()
+    drawn = np.nonzero(vis[t_sel])[0]
+    dp = pts[t_sel, drawn, :2].astype(int)
+    inside = (dp[:, 0] >= 0) & (dp[:, 0] < w) & (dp[:, 1] >= 0) & (dp[:, 1] < h)
+    best = np.full((h, w), np.inf, np.float32)
+    for dy in range(-2, 3):
+        for dx in range(-2, 3):
+            x, y = dp[inside, 0] + dx, dp[inside, 1] + dy
+            ok = (x >= 0) & (x < w) & (y >= 0) & (y < h)
+            np.minimum.at(best, (y[ok], x[ok]), pts[t_sel, drawn[inside][ok], 2])
+    assert np.array_equal(np.isfinite(best), painted) and np.array_equal(best[painted], pts[t_sel, wi, 2])
+    # (3) the order of the points does not matter (distinct depths), and a second run is identical
+    perm = np.random.default_rng(3).permutation(n)
+    tr2, cos2, dep2 = P.visualize_tracking_DELTA(pts[:, perm], vis[:, perm], False, 4, h, w, 4, device=DEV)
+    assert torch.equal(tr, tr2) and torch.equal(dep, dep2) and all(torch.equal(cos[i], cos2[i]) for i in range(4))
+    tr3, _, _ = P.visualize_tracking_DELTA(pts, vis, False, 4, h, w, 4, device=DEV)
+    assert torch.equal(tr, tr3)
+
+
+def test_raster_argument_errors():
+    from flexam_amd import conditioning_raster as P
+    from flexam_amd import hip as H
+    pts = torch.zeros(2, 5, 3, device=DEV)
+    with pytest.raises(RuntimeError):
+        H.raster_keys(pts[:, :, :2], None, 8, 8, 2)
+    with pytest.raises(RuntimeError):
+        H.raster_keys(pts, torch.ones(2, 4, dtype=torch.uint8, device=DEV), 8, 8, 2)
+    with pytest.raises(RuntimeError):
+        H.raster_resolve(H.raster_keys(pts, None, 8, 8, 2), torch.zeros(5, 4, dtype=torch.uint8, device=DEV))
+    with pytest.raises(NotImplementedError):
+        P.visualize_tracking_DELTA(pts.cpu(), None, True, 4, 8, 8)
+    with pytest.raises(NotImplementedError):
+        P.visualize_tracking_DELTA(pts.cpu(), None, False, 4, 8, 8, mask_path="mask.mp4")
+    with pytest.raises(ValueError):
+        P.visualize_tracking_DELTA(pts.cpu(), torch.ones(2, 4), False, 4, 8, 8)
