@@ -147,3 +147,30 @@ def test_raster_argument_errors():
         P.visualize_tracking_DELTA(pts.cpu(), None, False, 4, 8, 8, mask_path="mask.mp4")
     with pytest.raises(ValueError):
         P.visualize_tracking_DELTA(pts.cpu(), torch.ones(2, 4), False, 4, 8, 8)
+
+
+def test_tracks_to_conditioning_latents_through_the_pipeline():
+    """The whole hand-over the reference does on the host (pipelines.py:1874-1902 -> :1167-1185 -> PIPE.py:655-822): tracks -> six videos
+    (left on the GPU) -> the sampler's VAE encode.  The GPU-resident videos must encode to exactly what the same videos handed over as
+    host tensors encode to, and to what the oracle's videos give through the oracle's encoder (>= 40 dB)."""
+    from flexam_amd import conditioning_raster as P
+    from test_pipeline_pixels_gpu import FRAMES, H, W, make_pipe
+    from oracle import cases as C
+    from oracle import vae as OV
+    pipe, cfg, dsd, vsd = make_pipe()
+    rng = np.random.default_rng(9)
+    n = 500
+    pts = np.stack([rng.uniform(-4, W + 4, (FRAMES, n)), rng.uniform(-4, H + 4, (FRAMES, n)), rng.uniform(0.5, 5, (FRAMES, n))], -1).astype(np.float32)
+    vis = rng.random((FRAMES, n)) > 0.1
+    tr, cos, dep = P.visualize_tracking_DELTA(pts, vis, False, 4, H, W, 4, device=DEV)
+    shape = (1, 48, 3, H // 16, W // 16)
+    mask = torch.full((1, 1, FRAMES, H, W), 255.0)
+    on_gpu = pipe.encode_conditioning(tr, mask, tr, dep, cos, None, H, W, shape)          # all-255 mask: `video` is not encoded
+    on_host = pipe.encode_conditioning(tr.cpu(), mask, tr.cpu(), dep.cpu(), {k: v.cpu() for k, v in cos.items()}, None, H, W, shape)
+    assert torch.equal(on_gpu.control_latents, on_host.control_latents) and torch.equal(on_gpu.additional_control, on_host.additional_control)
+    o_tr, o_cos, o_dep = O.visualize_tracking(pts, vis, 4, H, W, 4)
+    enc = lambda v: OV.vae_encode(vsd, v * 2 - 1, C.VAE_ENC_SMALL["temporal_down"], OV.LATENT_MEAN, OV.LATENT_STD)
+    want_add = torch.cat([enc(o_dep)] + [enc(o_cos[k]) for k in sorted(o_cos)], dim=1)
+    p_c, p_a = C.psnr(on_gpu.control_latents.float().cpu(), enc(o_tr)), C.psnr(on_gpu.additional_control.float().cpu(), want_add)
+    print(f"tracks -> latents: control {p_c:.1f} dB, depth + cosine levels {p_a:.1f} dB")
+    assert p_c >= 40.0 and p_a >= 40.0
