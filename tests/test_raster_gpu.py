@@ -141,6 +141,10 @@ def test_raster_argument_errors():
         H.raster_keys(pts, torch.ones(2, 4, dtype=torch.uint8, device=DEV), 8, 8, 2)
     with pytest.raises(RuntimeError):
         H.raster_resolve(H.raster_keys(pts, None, 8, 8, 2), torch.zeros(5, 4, dtype=torch.uint8, device=DEV))
+    with pytest.raises(RuntimeError, match="y_min"):
+        H.raster_keys(pts, None, 8, 8, 2, y_min=2)                    # the C ABI's own check (FLEXAM_E_SHAPE + message)
+    with pytest.raises(RuntimeError, match="half"):
+        H.raster_keys(pts, None, 8, 8, -1)
     with pytest.raises(NotImplementedError):
         P.visualize_tracking_DELTA(pts.cpu(), None, True, 4, 8, 8)
     with pytest.raises(NotImplementedError):
