@@ -502,7 +502,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     const float m1 = vmax8(s_cur[8], s_cur[9], s_cur[10], s_cur[11], s_cur[12], s_cur[13], s_cur[14], s_cur[15]);
     // the test needs no row maximum: any(lane maximum > THR) over the wave is any(row maximum > THR); the exchange between the
     // two lanes of a row happens in the rare branch only (-0.7 % of a step, profiles/r4e_*)
+#ifdef A32_NOMAX_ABLATE      // TIMING ABLATION (WRONG results when a rescale would have been needed): what the 9 maxima of a half tile cost
+    const float mloc = s_cur[0];      // one score instead of the lane maximum: the test and its branch stay, the 9 maxima go
+#else
     const float mloc = vmax(m0, m1);
+#endif
     if constexpr (PRE) {
       // ---- deferred rescale (always taken for half 0, which sets the reference to the first row maximum): O, l, the pending
       // P(g-1), the scores of this half and the already started chain of the next half all move to the new reference
