@@ -328,6 +328,8 @@ def main():
             "conditioning_raster": raster,
             "clip_end_to_end": clip,
             "sec_per_clip": (enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec) if vae_sec is not None else None,
+            "sec_per_clip_from_tracks": ((enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec + raster["sec"])
+                                         if vae_sec is not None and raster and raster.get("sec") else None),
             "dit_block_executed_tflops": executed_block_flops * steps_per_sec / 1e12,
             "dit_block_executed_mfma_frac": executed_block_flops * steps_per_sec / 1e12 / (PEAK_BF16_TFLOPS * world),
             "dit_block_algorithmic_tflops": step_block_flops * steps_per_sec / 1e12,
