@@ -352,7 +352,8 @@ def main():
                                              "rescale branch (any lane maximum > 2^8 above the running reference) is taken; compare ms_per_step and "
                                              "roofline.launch_ms with the default line of the same box"}
         if emulated is not None:
-            result["emulated_ranks"] = {"world": n_emulate, "layouts": emulated,
+            from benchlib.emulate import HOST_NOTE
+            result["emulated_ranks"] = {"world": n_emulate, "layouts": emulated, "host_enqueue_note": HOST_NOTE,
                                         "predicted_scaling_no_comm": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step"], 3) for r in emulated if "ms_per_step" in r},
                                         "what": "ONE process ran one rank's share of an N-GPU step per layout at full size: the real engine on that rank's token chunk / "
                                                 "CFG row with every launch, piece, partial attention and merge of the multi-GPU path, collectives replaced by device "

@@ -158,13 +158,52 @@ ATTN_SOURCES = ("flexam_amd/csrc/attn.hip", "flexam_amd/csrc/attn_fp8.inc", "fle
 ATTN_TRAFFIC_FILE = "profiles/head_attn_traffic.json"
 
 
+# compile-time switches of DIAGNOSTIC builds (tools/build_attn_variants.py, -DFLEXAM_DIAGNOSTIC_BUILD): never defined in the product
+# library, so the text they guard is not part of what the counter record was measured on
+ATTN_DIAGNOSTIC_MACROS = ("FLEXAM_ATTN_STAMPS", "A32_NOMAX_ABLATE", "A32_VALU", "FLEXAM_ATTN_BODY16", "FLEXAM_DIAGNOSTIC_BUILD")
+
+
+def product_text(src: str, undefined=ATTN_DIAGNOSTIC_MACROS) -> str:
+    """The source text the PRODUCT build compiles: `#ifdef X ... [#else ...] #endif` / `#ifndef X` / `#if defined(X) ...` blocks of the
+    diagnostic macros resolved as "X is not defined", comments and blank lines dropped, runs of white space folded -- so that adding a
+    diagnostic switch or editing a comment does not orphan a committed counter record, while any change to compiled code does."""
+    import re
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    out, stack = [], []                # stack of [kind, keep_now, parent_keep]; kind "diag" = a block of ours, "other" = any other conditional
+    for line in src.split("\n"):
+        code = re.sub(r"//.*$", "", line).rstrip()
+        st = code.strip()
+        keep = all(k for _, k, _ in stack)
+        m = re.match(r"#\s*(ifdef|ifndef)\s+(\w+)", st)
+        m2 = re.match(r"#\s*if\b(.*)", st)
+        if m and m.group(2) in undefined:
+            stack.append(["diag", m.group(1) == "ifndef", keep])
+            continue
+        if m2 and not m and any(re.search(r"defined\s*\(?\s*" + u + r"\b", m2.group(1)) for u in undefined):
+            stack.append(["diag", False, keep])      # `#if defined(DIAG) ...` guards (the #error check): false in the product
+            continue
+        if m or m2:
+            stack.append(["other", True, keep])
+        elif re.match(r"#\s*else\b", st) and stack and stack[-1][0] == "diag":
+            stack[-1][1] = not stack[-1][1]
+            continue
+        elif re.match(r"#\s*endif\b", st) and stack:
+            kind = stack.pop()[0]
+            if kind == "diag":
+                continue
+        if keep and st:
+            out.append(re.sub(r"\s+", " ", st))
+    return "\n".join(out)
+
+
 def attn_source_sha(root):
-    """sha256 (16 hex digits) over the attention kernel's sources: what a committed counter record must have been taken from."""
+    """sha256 (16 hex digits) over the PRODUCT text (product_text) of the attention kernel's sources: what a committed counter record
+    must have been taken from."""
     import hashlib
     h = hashlib.sha256()
     for rel in ATTN_SOURCES:
-        with open(os.path.join(root, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(root, rel), "r") as f:
+            h.update(product_text(f.read()).encode())
     return h.hexdigest()[:16]
 
 

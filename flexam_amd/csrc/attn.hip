@@ -154,6 +154,9 @@ __device__ __forceinline__ float pair_sum(float x) {
 // (A 4-wave x 64-row variant -- each K/V fragment feeding two MFMAs -- was tried in r1: hipcc cannot keep
 //  Q in the accumulator file and spills 150+ VGPRs; see DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
+#if (defined(FLEXAM_ATTN_STAMPS) || defined(A32_NOMAX_ABLATE) || defined(A32_VALU) || defined(FLEXAM_ATTN_BODY16)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
+#error "FLEXAM_ATTN_STAMPS / A32_NOMAX_ABLATE / A32_VALU / FLEXAM_ATTN_BODY16 are switches of diagnostic builds (timing ablations give WRONG results): add -DFLEXAM_DIAGNOSTIC_BUILD (tools/build_attn_variants.py does)"
+#endif
 #ifndef A32_DEFER
 #define A32_DEFER 0      // scores of a half tile whose exp2 / sum / pack wait for part A of the next step (see stepA); 0 = none
 #endif

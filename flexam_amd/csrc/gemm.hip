@@ -63,6 +63,9 @@ struct GemmParams {
 template <int V>
 using IC = std::integral_constant<int, V>;
 
+#if defined(FLEXAM_GEMM_ABLATE) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
+#error "FLEXAM_GEMM_ABLATE builds give WRONG results (timing ablations): add -DFLEXAM_DIAGNOSTIC_BUILD"
+#endif
 #ifdef FLEXAM_GEMM_ABLATE
 #define ABLATE(p, bit) ((p).debug & (bit))
 #else

@@ -10,7 +10,8 @@ procs = []
 for spec in sys.argv[1:]:
     name, _, defs = spec.partition("=")
     obj = os.path.join("/tmp", f"attn_var_{name}.o")
-    cmd = ["/opt/rocm/bin/hipcc", *flags, *[d for d in defs.split(",") if d], "-c", os.path.join(csrc, "attn.hip"), "-o", obj]
+    # every variant is a diagnostic build: the ablation / stamp switches of attn.hip refuse to compile without this macro
+    cmd = ["/opt/rocm/bin/hipcc", *flags, "-DFLEXAM_DIAGNOSTIC_BUILD", *[d for d in defs.split(",") if d], "-c", os.path.join(csrc, "attn.hip"), "-o", obj]
     procs.append((name, obj, subprocess.Popen(cmd)))
 for name, obj, p in procs:
     if p.wait() != 0:
