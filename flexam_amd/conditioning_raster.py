@@ -105,7 +105,12 @@ def _tracking_colors(first_frame_pts: np.ndarray, height: int, width: int, gener
     colors[:, 1] = (np.clip((first_frame_pts[:, 1] - 0) / (height - 0), 0, 1) * 255).astype(np.uint8)
     z_values = first_frame_pts[:, 2]
     if np.all(z_values == 0):
-        colors[:, 2] = (generator or np.random).randint(0, 256, n, dtype=np.uint8)
+        # the reference draws from numpy's global state (np.random.randint, pipelines.py:1536); an explicit generator of either numpy
+        # kind makes the corner reproducible: np.random.Generator (default_rng) has `integers`, np.random.RandomState `randint`
+        if generator is not None and hasattr(generator, "integers"):
+            colors[:, 2] = generator.integers(0, 256, n, dtype=np.uint8)
+        else:
+            colors[:, 2] = (generator if generator is not None else np.random).randint(0, 256, n, dtype=np.uint8)
     else:
         inv_z = 1 / (z_values + 1e-10)
         p2, p98 = np.percentile(inv_z, 2), np.percentile(inv_z, 98)
@@ -164,10 +169,32 @@ class _Frames:
     def __init__(self, points: np.ndarray, vis: np.ndarray, height: int, width: int, mask, device):
         self.t_n, self.n = points.shape[:2]
         self.h, self.w, self.device = height, width, device
-        self.points = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
+        self.points = torch.from_numpy(self._kernel_points(points)).to(device)
         self.vis = torch.from_numpy(np.ascontiguousarray(vis).view(np.uint8)).to(device)
         self.mask = mask
         self._keys: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    @staticmethod
+    def _kernel_points(points: np.ndarray) -> np.ndarray:
+        """float32 [T, N, 3] for flexam_raster_keys, which truncates (u, v), tests the frame and orders depths in float32.  The
+        reference does all three in the INPUT's precision (`pixels.astype(int)`, `depths.argsort()`: pipelines.py:1556-1560, 1227), so
+        for tracks wider than float32 the decisions are taken here, in that precision, and handed over in a form float32 holds exactly:
+        (u, v) -> their truncation towards zero (63.99999999 must stay pixel 63, not round up to 64.0f and leave a 64-wide frame),
+        depth -> its dense rank within the frame (equal depths equal ranks, NaN stays NaN: the kernel's order and tie rule see exactly
+        the float64 order)."""
+        if points.dtype == np.float32 or points.dtype.itemsize < 4 or not np.issubdtype(points.dtype, np.floating):
+            return np.ascontiguousarray(points, dtype=np.float32)          # float32 itself, and everything float32 holds exactly
+        out = np.empty(points.shape, dtype=np.float32)
+        with np.errstate(invalid="ignore"):
+            xy = np.trunc(points[:, :, :2])
+            xy = np.where(np.isfinite(xy), np.clip(xy, -(1 << 24), 1 << 24), np.nan)      # non-finite stays rejected, far outside stays outside
+        out[:, :, :2] = xy
+        for t in range(points.shape[0]):
+            z = points[t, :, 2]
+            nan = np.isnan(z)
+            _, inv = np.unique(np.where(nan, 0.0, z), return_inverse=True)     # ascending distinct values; -0.0 == 0.0
+            out[t, :, 2] = np.where(nan, np.nan, inv.reshape(z.shape).astype(np.float32))
+        return out
 
     def keys(self, half: int, y_min: int) -> torch.Tensor:
         k = (half, y_min)
@@ -226,9 +253,12 @@ def _visualize_depth_tracking(points, vis_mask, height, width, point_wise=4, sav
 
 
 def visualize_tracking_DELTA(points, vis_mask=None, save_tracking=False, point_wise=4, height=480, width=720, cos_level=4,
-                             generate_type="full_edit", mask_path=None, mask_video=None, device=None, generator=None):
+                             generate_type="full_edit", mask_path=None, mask_video=None, device=None, generator=None, torch_generator=None):
     """pipelines.py:1852-1902: (tracking_video [1, 3, T, H, W], {level: [1, 3, T, H, W]}, depth_video [1, 3, T, H, W]), float32 in [0, 1],
-    on the GPU.  `mask_video` [T, H, W] replaces the reference's `mask_path` (a video file it decodes itself, pipelines.py:1822-1840)."""
+    on the GPU.  `mask_video` [T, H, W] replaces the reference's `mask_path` (a video file it decodes itself, pipelines.py:1822-1840).
+    All-zero depths are the one place the reference draws random numbers (pipelines.py:1536 numpy, :1611 torch, both from global state):
+    `generator` (np.random.Generator or RandomState) seeds the tracking video's blue channel, `torch_generator` the z code of the cosine
+    videos; None = the global states, as the reference."""
     if save_tracking:
         raise NotImplementedError("save_tracking=True writes mp4 files through moviepy in the reference (pipelines.py:1882-1885): not part of this build")
     if mask_path is not None:
@@ -240,7 +270,7 @@ def visualize_tracking_DELTA(points, vis_mask=None, save_tracking=False, point_w
     fr = _Frames(pts, vis, height, width, _mask_for(mask_video, generate_type, pts.shape[0], height, width, dev), dev)
     tracking_video = fr.video(_tracking_colors(pts[0], height, width, generator), point_wise // 2, 1)
     src = points if isinstance(points, torch.Tensor) else torch.from_numpy(pts)
-    encoded = apply_cosine_positional_encoding(src, height, width, cos_level)
+    encoded = apply_cosine_positional_encoding(src, height, width, cos_level, generator=torch_generator)
     cos_video_dict = _visualize_cosine_encoded_tracking(encoded, pts, vis, height, width, False, device=dev, _frames=fr)
     depth_video = _visualize_depth_tracking(pts, vis, height, width, point_wise, False, device=dev, _frames=fr)
     return tracking_video, cos_video_dict, depth_video

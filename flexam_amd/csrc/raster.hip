@@ -50,13 +50,13 @@ __global__ __launch_bounds__(256) void raster_keys_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void raster_resolve_kernel(const unsigned long long* __restrict__ keys, const unsigned char* __restrict__ colors,
-                                                             int64_t color_frame_stride, int64_t frame_px, int64_t total,
+                                                             int64_t color_frame_stride, unsigned n_colors, int64_t frame_px, int64_t total,
                                                              unsigned char* __restrict__ out_u8, float* __restrict__ out_f32) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const unsigned long long key = keys[i];
   unsigned char r = 0, g = 0, b = 0;
-  if (key != RASTER_EMPTY) {
+  if (key != RASTER_EMPTY && (unsigned)(key & 0xFFFFFFFFull) < n_colors) {      // an index past the table (keys of another point set) stays black
     const unsigned char* c = colors + (i / frame_px) * color_frame_stride + 3 * (int64_t)(unsigned)(key & 0xFFFFFFFFull);
     r = c[0]; g = c[1]; b = c[2];
   }
@@ -86,12 +86,14 @@ extern "C" int flexam_raster_keys(const float* points, const unsigned char* visi
   return flexam_check_launch("flexam_raster_keys");
 }
 
-extern "C" int flexam_raster_resolve(const unsigned long long* keys, const unsigned char* colors, int64_t color_frame_stride, int T, int H, int W,
+extern "C" int flexam_raster_resolve(const unsigned long long* keys, const unsigned char* colors, int64_t color_frame_stride, int N, int T, int H, int W,
                                      unsigned char* out_u8, float* out_f32, void* stream) {
   FX_REQUIRE(keys && colors && (out_u8 || out_f32), FLEXAM_E_ARG, "raster_resolve: null pointer (keys, colors and at least one output)");
-  FX_REQUIRE(T > 0 && H > 0 && W > 0 && color_frame_stride >= 0, FLEXAM_E_SHAPE, "raster_resolve: T=%d H=%d W=%d", T, H, W);
+  FX_REQUIRE(T > 0 && H > 0 && W > 0 && N > 0, FLEXAM_E_SHAPE, "raster_resolve: T=%d H=%d W=%d N=%d", T, H, W, N);
+  FX_REQUIRE(color_frame_stride == 0 || color_frame_stride == (int64_t)N * 3, FLEXAM_E_SHAPE,
+             "raster_resolve: colour tables are [N][3] (stride 0) or [T][N][3] (stride N * 3 = %ld), got stride %ld", (long)N * 3, (long)color_frame_stride);
   const int64_t frame_px = (int64_t)H * W, total = frame_px * T;
   hipLaunchKernelGGL(raster_resolve_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys, colors,
-                     color_frame_stride, frame_px, total, out_u8, out_f32);
+                     color_frame_stride, (unsigned)N, frame_px, total, out_u8, out_f32);
   return flexam_check_launch("flexam_raster_resolve");
 }

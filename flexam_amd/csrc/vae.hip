@@ -24,13 +24,18 @@ __device__ __forceinline__ float ld(const T* p) { return (float)*p; }
 // blocks along x walk its (w, 4-channel vector) pairs with 32-bit arithmetic.  (r1-r4 split a flat 64-bit element index with three
 // 64-bit divisions per thread: for 16-32 bytes moved per thread that arithmetic, not HBM, set the rate -- vae_prep 2.9 -> 3.7 TB/s at
 // 160 channels once it was gone, profiles/r5j_*.)
+// The grid's y extent ends at 65535: up to that many image rows they sit on gridDim.y alone, beyond (long encoder chunks at full
+// height, tall inputs) as (h on y, t on z) -- image_row() is t * H + h either way, with no bound check and no division more.
+inline dim3 rows_dim(int gx, int T, int H) { return (int64_t)T * H <= 65535 ? dim3(gx, T * H, 1) : dim3(gx, H, T); }
+inline bool rows_fit(int T, int H) { return (int64_t)T * H <= 65535 || (H <= 65535 && T <= 65535); }
+__device__ __forceinline__ int image_row() { return blockIdx.z * gridDim.y + blockIdx.y; }
 inline dim3 row_grid(int T, int H, int per_row) {
   int gx = (per_row + 255) / 256;
   if (gx > 8) gx = (gx + 3) / 4;                       // ~4 iterations per thread on long rows
-  return dim3(gx, T * H);
+  return rows_dim(gx, T, H);
 }
 #define ROW_WALK(H_, per_row_, j_)                                     \
-  const int t = blockIdx.y / (H_), h = blockIdx.y - t * (H_);          \
+  const int t = image_row() / (H_), h = image_row() - t * (H_);        \
   for (int j_ = blockIdx.x * 256 + threadIdx.x; j_ < (per_row_); j_ += gridDim.x * 256)
 
 // ------------------------------------------------------------------------------------------
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256) void vae_prep_vec_kernel(const TI* __restrict_
   const int Hp = H + 2, Wp = W + 2;
   // One image row (t, h) per blockIdx.y, 4 waves x PIX positions of it per blockIdx.x: no per-position division.  (r1-r4 walked a flat
   // position index and split it with 64-bit divisions per position -- at 160 channels that arithmetic, not HBM, set the kernel's rate.)
-  const int t = blockIdx.y / H, h = blockIdx.y - t * H;
+  const int t = image_row() / H, h = image_row() - t * H;
   const TI* srow = src + (((int64_t)t * Hp + h + 1) * Wp + 1) * lds_;
   bf16* drow = dst + (dst_compact ? ((int64_t)t * H + h) * W : (((int64_t)(t + t0) * Hp + h + 1) * Wp + 1)) * Cp;
   for (int w0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PIX; w0 < W; w0 += gridDim.x * 4 * PIX) {
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void vae_prep_span_kernel(const TI* __restrict
   __shared__ float part[PREP_SPAN * 64];
   __shared__ float rscale[PREP_SPAN];
   const int Hp = H + 2, Wp = W + 2;
-  const int t = blockIdx.y / H, h = blockIdx.y - t * H;
+  const int t = image_row() / H, h = image_row() - t * H;
   const TI* srow = src + (((int64_t)t * Hp + h + 1) * Wp + 1) * lds_;
   bf16* drow = dst + (dst_compact ? ((int64_t)t * H + h) * W : (((int64_t)(t + t0) * Hp + h + 1) * Wp + 1)) * Cp;
   const int vpp = C / VE;                                // vectors per position
@@ -553,12 +558,12 @@ extern "C" int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_s
   const int64_t npos = (int64_t)T * H * W;
   dim3 grid(grid_for(npos, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
-  FX_REQUIRE((int64_t)T * H <= 65535, FLEXAM_E_SHAPE, "vae_prep_cl: %ld image rows exceed the grid's 65535 (shorter chunks)", (long)T * H);
+  FX_REQUIRE(rows_fit(T, H), FLEXAM_E_SHAPE, "vae_prep_cl: T=%d x H=%d image rows do not fit a grid (each <= 65535)", T, H);
   const bool vec = C % 4 == 0 && C <= 1024 && ld_src % 4 == 0 && Cp % 4 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 8 == 0 &&
                    (!gamma || (uintptr_t)gamma % 16 == 0);
   // vector form: one image row per blockIdx.y, 4 waves x PIX positions per blockIdx.x (PIX as in the kernel)
 #define PREP_VEC(TI_, NS_)                                                                                                         \
-  hipLaunchKernelGGL((vae_prep_vec_kernel<TI_, NS_>), dim3(prep_grid_x(W, (NS_) == 1 ? FLEXAM_PREP_PIX1 : (NS_) == 2 ? FLEXAM_PREP_PIX2 : 1), T * H), \
+  hipLaunchKernelGGL((vae_prep_vec_kernel<TI_, NS_>), rows_dim(prep_grid_x(W, (NS_) == 1 ? FLEXAM_PREP_PIX1 : (NS_) == 2 ? FLEXAM_PREP_PIX2 : 1), T, H), \
                      block, 0, st, (const TI_*)src, ld_src, C, T, H, W, gamma, mode, (bf16*)dst, Cp, t0, dst_compact)
   // bf16 rows of <= 256 channels: the span form (16-byte vectors on a contiguous stretch of the row, every lane busy).  Measured r5s at
   // the VAE's shapes: 160 channels bf16 91.5 against 123.7 us, 256 channels 130 against 133; on fp32 rows it LOSES (135 against 117,
@@ -566,7 +571,7 @@ extern "C" int flexam_vae_prep_cl(const void* src, int src_is_bf16, int64_t ld_s
   const bool span = vec && src_is_bf16 && C <= 256 && C % 8 == 0 && ld_src % 8 == 0 && Cp % 8 == 0 && (uintptr_t)dst % 16 == 0 &&
                     ((uintptr_t)gamma % 16 == 0) && !getenv("FLEXAM_VAE_PREP_WAVE");
   if (span) {
-    hipLaunchKernelGGL(vae_prep_span_kernel<bf16>, dim3((W + PREP_SPAN - 1) / PREP_SPAN, T * H), block, 0, st, (const bf16*)src, ld_src, C, T, H, W,
+    hipLaunchKernelGGL(vae_prep_span_kernel<bf16>, rows_dim((W + PREP_SPAN - 1) / PREP_SPAN, T, H), block, 0, st, (const bf16*)src, ld_src, C, T, H, W,
                        gamma, mode, (bf16*)dst, Cp, t0, dst_compact);
   } else if (vec) {
     const int ns = (C + 255) / 256;
@@ -611,7 +616,7 @@ extern "C" int flexam_deinterleave_cl(const void* src, int src_is_bf16, int64_t 
   FX_REQUIRE(src && dst, FLEXAM_E_ARG, "deinterleave_cl: null pointer");
   FX_REQUIRE(C % 4 == 0 && C <= Cp && Cp % 4 == 0 && 2 * C <= ld_src && T > 0 && H > 0 && W > 0, FLEXAM_E_SHAPE,
              "deinterleave_cl: C=%d must be a multiple of 4 and 2C <= ld_src=%ld", C, (long)ld_src);
-  FX_REQUIRE((int64_t)2 * T * H <= 65535, FLEXAM_E_SHAPE, "deinterleave_cl: %ld image rows exceed the grid's 65535", (long)2 * T * H);
+  FX_REQUIRE(rows_fit(2 * T, H), FLEXAM_E_SHAPE, "deinterleave_cl: 2 T=%d x H=%d image rows do not fit a grid (each <= 65535)", 2 * T, H);
   if (src_is_bf16)
     hipLaunchKernelGGL(deinterleave_kernel<bf16>, row_grid(2 * T, H, W * (C / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cp);
   else
@@ -625,7 +630,7 @@ extern "C" int flexam_phase_dupup_cl(const float* phases, int64_t ld_ph, int64_t
   FX_REQUIRE(Ho % 2 == 0 && Wo % 2 == 0 && (ft == 1 || ft == 2) && (Co * ft * 4) % Ci == 0, FLEXAM_E_SHAPE, "phase_dupup_cl: bad shape");
   FX_REQUIRE(Co % 4 == 0 && ld_main % 4 == 0 && ld_ph % 4 == 0 && phase_stride % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)phases % 16 == 0,
              FLEXAM_E_SHAPE, "phase_dupup_cl: Co, ld_main, ld_ph and phase_stride must be multiples of 4");
-  FX_REQUIRE((int64_t)To * Ho <= 65535, FLEXAM_E_SHAPE, "phase_dupup_cl: %ld image rows exceed the grid's 65535", (long)To * Ho);
+  FX_REQUIRE(rows_fit(To, Ho), FLEXAM_E_SHAPE, "phase_dupup_cl: To=%d x Ho=%d image rows do not fit a grid (each <= 65535)", To, Ho);
   hipLaunchKernelGGL(phase_dupup_kernel, row_grid(To, Ho, Wo * (Co / 4)), dim3(256), 0, (hipStream_t)stream, phases, ld_ph,
                      phase_stride, x_main, ld_main, Co, To, Ho, Wo, x_in, ld_in, Ci, ft, drop);
   return flexam_check_launch("flexam_phase_dupup_cl");
@@ -637,7 +642,7 @@ extern "C" int flexam_tapsum_cl(const float* y, int64_t ld_y, int T, int H, int 
   FX_REQUIRE(T > 0 && H > 0 && W > 0 && kt >= 1 && kt <= 3 && Co > 0 && Co % 4 == 0 && ld_y >= (int64_t)kt * 9 * Co && ld_y % 4 == 0 && ld_out % 4 == 0 &&
              (uintptr_t)y % 16 == 0 && (uintptr_t)out % 16 == 0 && (!bias || (uintptr_t)bias % 16 == 0), FLEXAM_E_SHAPE,
              "tapsum_cl: Co=%d must be a multiple of 4, ld_y=%ld >= kt*9*Co, 16-byte aligned rows", Co, (long)ld_y);
-  FX_REQUIRE((int64_t)T * H <= 65535, FLEXAM_E_SHAPE, "tapsum_cl: %ld image rows exceed the grid's 65535", (long)T * H);
+  FX_REQUIRE(rows_fit(T, H), FLEXAM_E_SHAPE, "tapsum_cl: T=%d x H=%d image rows do not fit a grid (each <= 65535)", T, H);
   hipLaunchKernelGGL(tapsum_kernel, row_grid(T, H, W * (Co / 4)), dim3(256), 0, (hipStream_t)stream, y, ld_y, T, H, W, kt, Co,
                      bias, out, ld_out);
   return flexam_check_launch("flexam_tapsum_cl");
@@ -687,7 +692,7 @@ extern "C" int flexam_space_to_depth_cl(const void* src, int src_is_bf16, int64_
   FX_REQUIRE(src && dst, FLEXAM_E_ARG, "space_to_depth_cl: null pointer");
   FX_REQUIRE(C % 4 == 0 && C <= Cs && Cs % 4 == 0 && C <= ld_src && H % 2 == 0 && W % 2 == 0 && T > 0, FLEXAM_E_SHAPE,
              "space_to_depth_cl: bad shape C=%d Cs=%d H=%d W=%d", C, Cs, H, W);
-  FX_REQUIRE((int64_t)T * H <= 65535, FLEXAM_E_SHAPE, "space_to_depth_cl: %ld image rows exceed the grid's 65535", (long)T * H);
+  FX_REQUIRE(rows_fit(T, H), FLEXAM_E_SHAPE, "space_to_depth_cl: T=%d x H=%d image rows do not fit a grid (each <= 65535)", T, H);
   if (src_is_bf16)
     hipLaunchKernelGGL(space_to_depth_kernel<bf16>, row_grid(T, H, W * (C / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src, C, T, H, W, (bf16*)dst, Cs, t0);
   else
@@ -701,7 +706,7 @@ extern "C" int flexam_avgdown_add_cl(float* x_main, int64_t ld_main, int Co, int
   FX_REQUIRE((ft == 1 || ft == 2) && (fs == 1 || fs == 2) && (Ci * ft * fs * fs) % Co == 0, FLEXAM_E_SHAPE, "avgdown_add_cl: bad factors");
   const int pad_t = (ft - Ti % ft) % ft;
   FX_REQUIRE((Ti + pad_t) / ft == To, FLEXAM_E_SHAPE, "avgdown_add_cl: %d input frames do not give %d output frames", Ti, To);
-  if (Ci == Co && Co % 4 == 0 && ld_main % 4 == 0 && ld_in % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)x_in % 16 == 0 && (int64_t)To * Ho <= 65535)
+  if (Ci == Co && Co % 4 == 0 && ld_main % 4 == 0 && ld_in % 4 == 0 && (uintptr_t)x_main % 16 == 0 && (uintptr_t)x_in % 16 == 0 && rows_fit(To, Ho))
     hipLaunchKernelGGL(avgdown_add_same_kernel, row_grid(To, Ho, Wo * (Co / 4)), dim3(256), 0, (hipStream_t)stream, x_main,
                        ld_main, Co, To, Ho, Wo, x_in, ld_in, ft, fs, pad_t);
   else

@@ -67,7 +67,7 @@ _SIGNATURES = {
     "flexam_vae_unpatchify_clamp": ([_P, _L, _I, _I, _I, _P, _I, _I, _F, _F, _P], c_int),
     "flexam_pack_affine_cl": ([_P, _I, _I, _I, _I, _P, _P, _P, _I, _P], c_int),
     "flexam_raster_keys": ([_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
-    "flexam_raster_resolve": ([_P, _P, _L, _I, _I, _I, _P, _P, _P], c_int),
+    "flexam_raster_resolve": ([_P, _P, _L, _I, _I, _I, _I, _P, _P, _P], c_int),
     "flexam_t5_norm": ([_P, _L, _L, _I, _F, _P, _P, _L, _I, _P], c_int),
     "flexam_softmax_bias_rows": ([_P, _L, _L, _I, _F, _P, _L, _P, _P, _L, _I, _P], c_int),
     "flexam_mul_bf16": ([_P, _P, _P, _L, _P], c_int),
@@ -828,17 +828,24 @@ def raster_keys(points, visible, height, width, half, y_min=0, mask=None, keys=N
         raise RuntimeError("raster_keys: keys must be a contiguous int64 [T, H, W] buffer")
     _check(lib().flexam_raster_keys(_ptr(points, F32), _ptr(visible, U8), T, N, height, width, half, y_min, _ptr(mask, F32), _ptr(keys), _stream()),
            "flexam_raster_keys")
+    keys.raster_points = N                         # the point count these keys index: raster_resolve holds its colour table to it
     return keys
 
 
-def raster_resolve(keys, colors, out_u8=None, out_f32=None, want_u8=False, want_f32=True):
-    """keys [T, H, W] (raster_keys), colors [N, 3] or [T, N, 3] uint8 -> (bytes [T, H, W, 3] or None, planes [3, T, H, W] fp32 = byte / 255 or None)."""
+def raster_resolve(keys, colors, out_u8=None, out_f32=None, want_u8=False, want_f32=True, n_points=None):
+    """keys [T, H, W] (raster_keys), colors [N, 3] or [T, N, 3] uint8 -> (bytes [T, H, W, 3] or None, planes [3, T, H, W] fp32 = byte / 255 or None).
+    N must be the point count the keys were made with (raster_keys attaches it to its result; `n_points` for keys from elsewhere): a
+    shorter table would be read past its end, a longer per-frame one at another frame's rows."""
     T, H, W = keys.shape
+    n_keys = n_points if n_points is not None else getattr(keys, "raster_points", None)
     if colors.dtype != U8 or colors.shape[-1] != 3 or not colors.is_contiguous() or colors.dim() not in (2, 3):
         raise RuntimeError(f"raster_resolve: contiguous uint8 colours [N, 3] or [T, N, 3] required, got {tuple(colors.shape)} {colors.dtype}")
     if colors.dim() == 3 and colors.shape[0] != T:
         raise RuntimeError("raster_resolve: per-frame colours need one table per frame")
     stride = colors.shape[1] * 3 if colors.dim() == 3 else 0
+    N = colors.shape[-2]
+    if n_keys is not None and N != n_keys:
+        raise RuntimeError(f"raster_resolve: the keys index {n_keys} points, the colour table has {N} rows")
     if out_u8 is None and want_u8:
         out_u8 = torch.empty(T, H, W, 3, device=keys.device, dtype=U8)
     if out_f32 is None and want_f32:
@@ -846,6 +853,6 @@ def raster_resolve(keys, colors, out_u8=None, out_f32=None, want_u8=False, want_
     for o, shp in ((out_u8, (T, H, W, 3)), (out_f32, (3, T, H, W))):
         if o is not None and (tuple(o.shape) != shp or not o.is_contiguous()):
             raise RuntimeError(f"raster_resolve: output must be contiguous {shp}, got {tuple(o.shape)}")
-    _check(lib().flexam_raster_resolve(_ptr(keys, torch.int64), _ptr(colors, U8), stride, T, H, W, _ptr(out_u8, U8), _ptr(out_f32, F32), _stream()),
+    _check(lib().flexam_raster_resolve(_ptr(keys, torch.int64), _ptr(colors, U8), stride, N, T, H, W, _ptr(out_u8, U8), _ptr(out_f32, F32), _stream()),
            "flexam_raster_resolve")
     return out_u8, out_f32

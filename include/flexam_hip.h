@@ -350,10 +350,12 @@ int flexam_mul_bf16(const void* a, const void* b, void* out, int64_t n, void* st
  *   for the tracking video, whose frame test is y > 0, else 0) and, with a mask video [T][H][W], mask[t][y][x] > 0.5.  Equal depths: the
  *   lower index wins; NaN depths lose against everything.  The call clears `keys` itself.
  * raster_resolve: out_u8[T][H][W][3] and / or out_f32[3][T][H][W] (= byte / 255, correctly rounded) from the winners' colours;
- *   colors[N][3] bytes shared by all frames (color_frame_stride = 0) or [T][N][3] (stride N * 3: the depth video's per-frame colours). */
+ *   colors[N][3] bytes shared by all frames (color_frame_stride = 0) or [T][N][3] (stride N * 3: the depth video's per-frame colours).
+ *   N = rows of a colour table = the point count the keys were made with: a key whose index is >= N (keys of another point set) resolves
+ *   to black instead of reading past the table; a per-frame stride other than 0 or N * 3 is refused. */
 int flexam_raster_keys(const float* points, const unsigned char* visible, int T, int N, int H, int W, int half, int y_min,
                        const float* mask, unsigned long long* keys, void* stream);
-int flexam_raster_resolve(const unsigned long long* keys, const unsigned char* colors, int64_t color_frame_stride, int T, int H, int W,
+int flexam_raster_resolve(const unsigned long long* keys, const unsigned char* colors, int64_t color_frame_stride, int N, int T, int H, int W,
                           unsigned char* out_u8, float* out_f32, void* stream);
 
 #ifdef __cplusplus

@@ -207,3 +207,29 @@ def test_deinterleave_phase_dupup_and_tapsum_match_torch():
     got = out.view(t, h + 2, w + 2, co)[:, 1:-1, 1:-1].permute(3, 0, 1, 2).cpu()
     torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
     assert float(out.view(t, h + 2, w + 2, co)[:, 0].abs().max()) == 0          # border rows are not written
+
+
+def test_row_walk_kernels_beyond_65535_image_rows():
+    """T x H above the grid's y extent (round-5 advice: long encoder chunks at full height, tall inputs): the rows move to
+    (h on y, t on z).  vae_prep (span and wave-per-position forms, fp32 and bf16 rows) and space-to-depth on 200 x 352 = 70400 rows
+    against the same kernels run as four 50-frame calls (row counts the y extent holds)."""
+    from flexam_amd import hip as H
+    g = torch.Generator().manual_seed(9)
+    c, t, h, w, cp = 64, 200, 352, 4, 64
+    assert t * h > 65535
+    rows = torch.randn(t * (h + 2) * (w + 2), c, generator=g).to(dev())
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev())
+    per = (h + 2) * (w + 2)
+    for src in (rows, rows.to(BF)):
+        img = torch.zeros(t, h + 2, w + 2, cp, dtype=BF, device=dev())
+        H.vae_prep_cl(src, c, t, h, w, img, mode=2, gamma=gamma)
+        ref = torch.zeros_like(img)
+        for t0 in range(0, t, 50):
+            H.vae_prep_cl(src[t0 * per:(t0 + 50) * per], c, 50, h, w, ref[t0:t0 + 50], mode=2, gamma=gamma)
+        assert torch.equal(img, ref) and float(img[-1, 1:-1, 1:-1].abs().max()) > 0
+    s2d = torch.zeros(t, h // 2 + 2, w // 2 + 2, 4 * cp, dtype=BF, device=dev())
+    H.space_to_depth_cl(rows, c, t, h, w, s2d, cp)
+    ref = torch.zeros_like(s2d)
+    for t0 in range(0, t, 50):
+        H.space_to_depth_cl(rows[t0 * per:(t0 + 50) * per], c, 50, h, w, ref[t0:t0 + 50], cp)
+    assert torch.equal(s2d, ref) and float(s2d[-1, 1:-1, 1:-1].abs().max()) > 0

@@ -62,9 +62,47 @@ def test_all_zero_depths_take_the_random_branches():
     a = P._tracking_colors(pts[0], G.H, G.W, np.random.RandomState(3))
     b = P._tracking_colors(pts[0], G.H, G.W, np.random.RandomState(3))
     assert np.array_equal(a, b) and len(np.unique(a[:, 2])) > 50
+    # both numpy generator kinds (round-5 advice: default_rng() has no randint), each reproducible
+    c = P._tracking_colors(pts[0], G.H, G.W, np.random.default_rng(3))
+    d = P._tracking_colors(pts[0], G.H, G.W, np.random.default_rng(3))
+    assert np.array_equal(c, d) and len(np.unique(c[:, 2])) > 50 and c.dtype == np.uint8
+    assert np.array_equal(c[:, :2], a[:, :2])                                     # only the blue channel is random
     e = P.apply_cosine_positional_encoding(torch.from_numpy(pts), G.H, G.W, 2, generator=torch.Generator().manual_seed(5))
     f = P.apply_cosine_positional_encoding(torch.from_numpy(pts), G.H, G.W, 2, generator=torch.Generator().manual_seed(5))
     assert torch.equal(e[1], f[1]) and e[0][..., 2].std() > 0.1
+
+
+def test_float64_tracks_keep_the_decisions_of_their_own_precision():
+    """The reference truncates pixel coordinates and orders depths in the INPUT's dtype (pipelines.py:1556-1560, 1227).  The kernel
+    works in float32, so for float64 tracks the host hands it the truncated coordinates and per-frame depth ranks
+    (_Frames._kernel_points): same pixels, same frame test, same order as the float64 oracle -- where a plain float32 cast moves a
+    point out of the frame (63.99999999 -> 64.0f) or merges distinct depths into a tie."""
+    from flexam_amd.conditioning_raster import _Frames
+    w, h = 64, 48
+    pts = np.array([[[63.99999999, 10.2, 2.0], [w - 1e-9, h - 1e-9, 1.0 + 1e-12], [5.5, 0.99999999999, 1.0], [-0.5, -0.9999999, 3.0],
+                     [7.0, 7.0, np.nan], [np.inf, 3.0, 1.0], [-1.0, 5.0, 1.0], [1e300, 1.0, -0.0], [2.0, 2.0, 0.0]]], dtype=np.float64)
+    assert np.float32(pts[0, 0, 0]) == 64.0 and np.float32(pts[0, 1, 2]) == np.float32(pts[0, 2, 2])      # what the plain cast would do
+    kp = _Frames._kernel_points(pts)
+    assert kp.dtype == np.float32
+    vis = np.ones(pts.shape[1], bool)
+    idx, pixels, depths = O._visible_pixels(pts[0], vis, w, h, 0)                  # the oracle, in float64
+    # the kernel's decisions on kp: finite, -1 < u < W, -1 < v < H, then truncation
+    u, v = kp[0, :, 0], kp[0, :, 1]
+    with np.errstate(invalid="ignore"):
+        inside = (u > -1) & (u < w) & (v > -1) & (v < h)
+    assert np.array_equal(np.nonzero(inside)[0], np.sort(idx))
+    for i, (x, y) in zip(idx, pixels):
+        assert (int(kp[0, i, 0]), int(kp[0, i, 1])) == (int(x), int(y))
+    # depth order: ranks are exact in float32 and order like the float64 depths (ties stay ties, NaN stays NaN)
+    z64, z32 = pts[0, :, 2], kp[0, :, 2]
+    assert np.isnan(z32[4]) and z32[7] == z32[8]                                   # -0.0 == 0.0
+    fin = ~np.isnan(z64)
+    for a in np.nonzero(fin)[0]:
+        for b in np.nonzero(fin)[0]:
+            assert (z64[a] < z64[b]) == (z32[a] < z32[b]) and (z64[a] == z64[b]) == (z32[a] == z32[b])
+    # float32 and narrower inputs pass through untouched
+    p32 = pts.astype(np.float32)
+    assert np.array_equal(_Frames._kernel_points(p32), p32, equal_nan=True)
 
 
 def test_spectral_table_is_matplotlibs():

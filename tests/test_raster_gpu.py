@@ -58,6 +58,33 @@ def test_hip_rasteriser_vs_oracle_ties_nan_depths_and_background_mask():
             assert torch.equal(cos[i].cpu(), o_c[i])
 
 
+def test_float64_tracks_and_seeded_zero_depth_clip():
+    """float64 tracks: frames equal the float64 oracle's (truncation, frame test and depth order in the input's precision, where a
+    float32 cast moves points across pixel / frame borders and merges depths); all-zero depths: the clip is reproducible from the two
+    explicit generators (numpy for the tracking colours, torch for the cosine z code)."""
+    from flexam_amd import conditioning_raster as P
+    rng = np.random.default_rng(11)
+    t_n, n, h, w = 3, 2000, 64, 64
+    pts = np.stack([rng.uniform(-4, w + 4, (t_n, n)), rng.uniform(-4, h + 4, (t_n, n)), rng.uniform(1, 2, (t_n, n))], -1)      # float64
+    pts[:, :200, 0] = np.floor(pts[:, :200, 0]) + 1 - 1e-9          # just under a pixel border: float32 rounds these UP a pixel
+    pts[:, 200:300, 1] = h - 1e-10                                  # just inside the last row: float32 puts them outside the frame
+    pts[:, 300:600, 2] = 1.5 + rng.integers(0, 300, (t_n, 300)) * 1e-13      # distinct in float64, one value in float32
+    assert len(np.unique(pts[0, 300:600, 2].astype(np.float32))) == 1
+    vis = rng.random((t_n, n)) > 0.1
+    tr, cos, dep = P.visualize_tracking_DELTA(pts, vis, False, 4, h, w, 2, device=DEV)
+    o_t, o_c, o_d = O.visualize_tracking(pts, vis, 4, h, w, 2)
+    assert torch.equal(tr.cpu(), o_t) and torch.equal(dep.cpu(), o_d) and all(torch.equal(cos[i].cpu(), o_c[i]) for i in range(2))
+    tr32, _, _ = P.visualize_tracking_DELTA(pts.astype(np.float32), vis, False, 4, h, w, 2, device=DEV)
+    assert not torch.equal(tr32, tr)                                # the case does separate the two precisions
+    z0 = pts.astype(np.float32)
+    z0[..., 2] = 0
+    runs = [P.visualize_tracking_DELTA(z0, vis, False, 4, h, w, 2, device=DEV, generator=np.random.default_rng(4),
+                                       torch_generator=torch.Generator().manual_seed(9)) for _ in range(2)]
+    assert torch.equal(runs[0][0], runs[1][0]) and all(torch.equal(runs[0][1][i], runs[1][1][i]) for i in range(2))
+    other = P.visualize_tracking_DELTA(z0, vis, False, 4, h, w, 2, device=DEV, generator=np.random.default_rng(5), torch_generator=torch.Generator().manual_seed(10))
+    assert not torch.equal(other[0], runs[0][0]) and not torch.equal(other[1][0], runs[0][1][0])
+
+
 def test_raster_resolve_float_is_the_correctly_rounded_quotient():
     """out_f32 = byte / 255 for every byte value, as torch's `.float() / 255.0` gives it (pipelines.py:1660)."""
     from flexam_amd import hip as H
@@ -141,6 +168,17 @@ def test_raster_argument_errors():
         H.raster_keys(pts, torch.ones(2, 4, dtype=torch.uint8, device=DEV), 8, 8, 2)
     with pytest.raises(RuntimeError):
         H.raster_resolve(H.raster_keys(pts, None, 8, 8, 2), torch.zeros(5, 4, dtype=torch.uint8, device=DEV))
+    keys5 = H.raster_keys(pts, None, 8, 8, 2)
+    with pytest.raises(RuntimeError, match="index 5 points"):                     # a colour table of another point count (round-5 advice)
+        H.raster_resolve(keys5, torch.zeros(4, 3, dtype=torch.uint8, device=DEV))
+    with pytest.raises(RuntimeError, match="index 5 points"):
+        H.raster_resolve(keys5, torch.zeros(2, 7, 3, dtype=torch.uint8, device=DEV))
+    # keys from elsewhere (no point count attached): the C side clamps -- an index past the table resolves to black, not to a wild read
+    anon = keys5.clone()
+    u8, _ = H.raster_resolve(anon, torch.full((3, 3), 200, dtype=torch.uint8, device=DEV), want_u8=True, want_f32=False)
+    drawn = (keys5 != -1)
+    idx = (keys5 & 0xFFFFFFFF)
+    assert bool(drawn.any()) and torch.equal(u8[..., 0] == 200, drawn & (idx < 3)) and int(u8[drawn & (idx >= 3)].max(initial=0)) == 0
     with pytest.raises(RuntimeError, match="y_min"):
         H.raster_keys(pts, None, 8, 8, 2, y_min=2)                    # the C ABI's own check (FLEXAM_E_SHAPE + message)
     with pytest.raises(RuntimeError, match="half"):
