@@ -159,12 +159,23 @@ def current_sp_context():
     return _SP_CONTEXT[0]
 
 
+def padded_len(seq_len: int, world: int) -> int:
+    """The reference pads the token sequence to a multiple of the sequence-parallel size with zero tokens that attention masks as
+    keys (wan_transformer3d_FlexAM.py:919-925: `seq_len = ceil(seq_len / sp) * sp`, k_lens = the real lengths)."""
+    return -(-int(seq_len) // int(world)) * int(world)
+
+
 def chunk_bounds(seq_len: int, rank: int, world: int) -> Tuple[int, int]:
-    """[start, end) of this rank's token chunk.  The sequence must divide evenly (11648 = 8 * 1456)."""
-    if seq_len % world:
-        raise ValueError(f"sequence length {seq_len} is not divisible by the sequence-parallel size {world}")
-    lc = seq_len // world
+    """[start, end) of this rank's token chunk of the PADDED sequence (padded_len): every rank holds the same number of rows; the
+    rows at or beyond `seq_len` (only ever at the end of the last chunks) are the reference's zero pad tokens."""
+    lc = padded_len(seq_len, world) // world
     return rank * lc, (rank + 1) * lc
+
+
+def real_tokens(seq_len: int, rank: int, world: int) -> int:
+    """How many of this rank's chunk rows are real tokens (the rest are pads)."""
+    s, e = chunk_bounds(seq_len, rank, world)
+    return max(0, min(e, seq_len) - s)
 
 
 def all_gather_seq(local: torch.Tensor, group=None, out: torch.Tensor = None, scratch: torch.Tensor = None) -> torch.Tensor:
@@ -246,9 +257,13 @@ def all_to_all_blocks(outs, ins, group=None, async_op: bool = False):
 
 
 def shard_rows(full: torch.Tensor, batch: int, seq_len: int, rank: int, world: int) -> torch.Tensor:
-    """Per-token vector [B*L] (e.g. the AdaLN row index) -> this rank's [B*Lc] slice."""
+    """Per-token vector [B*L] (e.g. the AdaLN row index) -> this rank's [B*Lc] slice of the padded sequence; pad tokens repeat the
+    last real token's entry (the reference pads `t` with its last element, wan_transformer3d_FlexAM.py:930-934)."""
     s, e = chunk_bounds(seq_len, rank, world)
-    return full.view(batch, seq_len)[:, s:e].contiguous().view(-1)
+    v = full.view(batch, seq_len)
+    if e > seq_len:
+        v = torch.cat([v, v[:, -1:].expand(batch, e - seq_len)], dim=1)
+    return v[:, s:e].contiguous().view(-1)
 
 
 def shard_streams(jobs, encode, group=None):

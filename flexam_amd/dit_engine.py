@@ -108,6 +108,7 @@ class DiTEngine:
         self.table_limit = int(os.environ.get("FLEXAM_ADALN_TABLE_BYTES", str(1 << 30)))
         self.fp8 = False                            # BASELINE configs[4]: QKV / FFN GEMMs on fp8 MFMA (enable_fp8)
         self._fp8_w = None
+        self.fp8_modules = False                    # fp8 GEMMs inside blocks that are called as modules (not the fused path): enable_fp8
         self._pack()
 
     # ------------------------------------------------------------------ weights
@@ -186,8 +187,16 @@ class DiTEngine:
         row and per call (flexam_quantize_rows_fp8), fp32 accumulation, the same fused epilogues.  Attention, the output / cross
         projections, norms, modulation and the residual stream are unchanged.  BASELINE.json configs[4] ("fp8 MFMA QKV/FFN
         variant"); the reference's own fp8 mode only stores weights in fp8 (FlexAM/utils/fp8_optimization.py:1-57)."""
-        if on and not self.fused:
-            raise NotImplementedError("fp8 GEMMs run in the engine's fused block path (no replaced / re-bound blocks)")
+        if not self.fused:
+            # some block is replaced / wrapped / re-bound: every block is CALLED as a module and carries the switch itself
+            # (_Block.set_fp8, set by model.enable_fp8_gemm on every native block, also inside wrappers) -- the same GEMMs on the fp8 pipe
+            # with absmax row scales; the engine only has to keep its own fused-path state out of the way
+            for blk in self.model.modules():
+                if hasattr(blk, "set_fp8"):
+                    blk.set_fp8(on)
+            self.fp8 = False
+            self.fp8_modules = bool(on)
+            return
         # wo / cwo are quantised too: FLEXAM_FP8_OPROJ=1 (read per forward; an experiment, not part of configs[4]'s "QKV/FFN") runs the
         # self-attention and cross-attention output projections on the fp8 pipe as well -- the attention output is row-quantised by one
         # more pass (flexam_quantize_rows_fp8)
@@ -381,22 +390,30 @@ class DiTEngine:
         dens_emb = cd["dens_emb"][rsel] if cd["dens_emb"] is not None else None
         cx, f, h, w = cd["latent_shape"]
         sp, rank = self.sp_size, self.sp_rank
-        if L % sp:
-            raise RuntimeError(f"sequence length {L} is not divisible by the sequence-parallel size {sp}")
-        lc = L // sp
+        # A sequence that does not divide over the ranks is padded to the next multiple with zero tokens at its end, as the reference
+        # does (FX.py:919-925); they are rows like any other in every token-local op, never keys of self-attention (the key ranges
+        # below end at L), and the head gather drops them
+        Lp = -(-L // sp) * sp
+        lc = Lp // sp
         tok0 = rank * lc
+        if Lp > L and cd["cos"].shape[0] < Lp:             # RoPE rows of the pad tokens: the identity, like every token beyond the grid
+            extra = Lp - cd["cos"].shape[0]
+            cd["cos"] = torch.cat([cd["cos"], torch.ones(extra, cd["cos"].shape[1], device=dev)])
+            cd["sin"] = torch.cat([cd["sin"], torch.zeros(extra, cd["sin"].shape[1], device=dev)])
         ws = self._workspace(B, lc)
         xres, hbuf, qkv, ao, ffn, head = ws["x"], ws["h"], ws["qkv"], ws["ao"], ws["ffn"], ws["head"]
         xr = xres.view(B, lc, d)
 
         # ---- stem: patch embedding of the noisy latent (+ cached static channels), ref tokens
         bx = x.shape[0]
-        full = torch.empty(L, d, device=dev, dtype=F32) if sp > 1 else None
+        full = torch.empty(Lp, d, device=dev, dtype=F32) if sp > 1 else None
+        if Lp > L:
+            full[L:].zero_()
         for b in range(bx):
             pa = cd["patch_a"][b if cd["nb"] > 1 else 0]
             hip.patchify(x[b].to(dev).contiguous(), pa, col0=0)
             dst = full if sp > 1 else xr[b]
-            hip.gemm(pa, self.pe_w, self.pe_b, out=dst[ref_len:], out_dtype=F32)
+            hip.gemm(pa, self.pe_w, self.pe_b, out=dst[ref_len:L], out_dtype=F32)
             if ref_len:
                 dst[:ref_len].copy_(cd["ref_tok"][b if cd["nb"] > 1 else 0])
             if sp > 1:
@@ -597,10 +614,10 @@ class DiTEngine:
         # itself, a caller's re-bound forward finds group / rank / token offset / RoPE tables in flexam_amd.dist.current_sp_context()
         from .dist import sequence_parallel_context
         sp = self.sp_size
-        seq_lens = torch.tensor([lc * sp] * B, dtype=torch.long)
+        seq_lens = torch.tensor([cd["L"]] * B, dtype=torch.long)      # the REAL lengths (FX.py:917): under sequence parallelism lc * sp may be padded
         x3 = xres.view(B, lc, d)
         ctx = cd["ctx"][rsel]
-        with sequence_parallel_context(self.sp_group, self.sp_rank, sp, self.sp_rank * lc, lc * sp, cd["cos"], cd["sin"]) if sp > 1 else nullcontext():
+        with sequence_parallel_context(self.sp_group, self.sp_rank, sp, self.sp_rank * lc, cd["L"], cd["cos"], cd["sin"]) if sp > 1 else nullcontext():
             for blk in self.block_modules:
                 out = blk(x3, e=e_full, density_emb=dens0, seq_lens=seq_lens, grid_sizes=grid_sizes, freqs=self.model.freqs, context=ctx,
                           context_lens=None, dtype=BF16, t=t_rows)
@@ -664,6 +681,7 @@ class DiTEngine:
         send, recv, out, recv2 = ws["a2a_send"], ws["a2a_recv"], ws["a2a_out"], ws["a2a_recv2"]
         full = recv.view(B, sp * lc, 3, hg, hd)
         chunks = out.view(B, sp, lc, G)
+        nk = cd["L"]                                   # keys: the real tokens (rows nk .. sp*lc - 1 are the reference's zero pads, FX.py:919-925)
 
         def project_and_pack(rows, b0, nb):          # samples b0 .. b0 + nb - 1: rows of h -> q|k|v -> normed / rotated send blocks
             a8 = a8sa and (a8sa[0][rows], a8sa[1][rows])
@@ -677,7 +695,7 @@ class DiTEngine:
             project_and_pack(slice(None), 0, B)
             for b in range(B):
                 all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group)
-            hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=out, prescaled=True)
+            hip.attn_fwd(full[:, :, 0], full[:, :nk, 1], full[:, :nk, 2], out=out, prescaled=True)
             for b in range(B):
                 all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group)
             return recv2.view(sp * B * lc, G), ws["a2a_koff"]
@@ -689,7 +707,7 @@ class DiTEngine:
             for w in there:
                 if w is not None:
                     w.wait()
-            hip.attn_fwd(full[:, :, 0], full[:, :, 1], full[:, :, 2], out=out, prescaled=True)
+            hip.attn_fwd(full[:, :, 0], full[:, :nk, 1], full[:, :nk, 2], out=out, prescaled=True)
             back = [all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True)
                     for b in range(B)]
             for w in back:
@@ -699,7 +717,7 @@ class DiTEngine:
         for b in range(B):
             if there[b] is not None:
                 there[b].wait()
-            hip.attn_fwd(full[b:b + 1, :, 0], full[b:b + 1, :, 1], full[b:b + 1, :, 2], out=out[b:b + 1], prescaled=True)
+            hip.attn_fwd(full[b:b + 1, :, 0], full[b:b + 1, :nk, 1], full[b:b + 1, :nk, 2], out=out[b:b + 1], prescaled=True)
             back.append(all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True))
         for w in back:
             if w is not None:
@@ -739,14 +757,16 @@ class DiTEngine:
         from .dist import all_gather_into_tensor, group_backend
         sp, nh, hd, d, dev = self.sp_size, self.nh, self.hd, self.dim, self.device
         ws = self._ws[(B, lc)]
-        L = sp * lc
+        L = sp * lc                                    # rows of the gathered buffer (the padded sequence)
+        Lr = self.cond["L"]                            # keys: the real tokens; rows Lr .. L - 1 are zero pads (FX.py:919-925) and end every key range
+        n_loc = max(0, min(lc, Lr - tok0))             # real tokens of the local chunk
         G = self.sp_pieces
         cb, hg = d // G, nh // G
         if "kv_send" not in ws:
             ws["kv_send"] = torch.empty(G, B, lc, 2 * cb, device=dev, dtype=BF16)
             ws["kv_cat"] = torch.empty(G, B, L, 2 * cb, device=dev, dtype=BF16)
             units = B * hg * ((lc + 255) // 256)
-            ranges = [lc, tok0, L - tok0 - lc]                                            # local, before, after
+            ranges = [n_loc, min(tok0, Lr), max(0, Lr - tok0 - lc)]                      # local, before, after
             ws["kv_splits"] = [self._splits_for(units, (n + 63) // 64) if n else 0 for n in ranges]
             ws["kv_part"] = hip.attn_partial_workspace(B, hg, lc, sum(hip.attn_effective_splits(n, s) for n, s in zip(ranges, ws["kv_splits"]) if n), dev)
         cd = self.cond
@@ -772,17 +792,19 @@ class DiTEngine:
                 for w in works[g]:
                     if w is not None:
                         w.wait()
-                hip.attn_fwd(qg, heads(kc), heads(vc), out=og, prescaled=True)
+                hip.attn_fwd(qg, heads(kc[:, :Lr]), heads(vc[:, :Lr]), out=og, prescaled=True)
                 continue
             s_loc, s_before, s_after = ws["kv_splits"]
-            n = hip.attn_fwd_partial(qg, heads(send[0, :, :, 0:cb]), heads(send[0, :, :, cb:]), ws["kv_part"], 0, s_loc, prescaled=True)
+            n = 0
+            if n_loc > 0:
+                n = hip.attn_fwd_partial(qg, heads(send[0, :, :n_loc, 0:cb]), heads(send[0, :, :n_loc, cb:]), ws["kv_part"], 0, s_loc, prescaled=True)
             for w in works[0]:
                 if w is not None:
                     w.wait()
             if tok0 > 0:
-                n += hip.attn_fwd_partial(qg, heads(kc[:, :tok0]), heads(vc[:, :tok0]), ws["kv_part"], n, s_before, prescaled=True)
-            if tok0 + lc < L:
-                n += hip.attn_fwd_partial(qg, heads(kc[:, tok0 + lc:]), heads(vc[:, tok0 + lc:]), ws["kv_part"], n, s_after, prescaled=True)
+                n += hip.attn_fwd_partial(qg, heads(kc[:, :min(tok0, Lr)]), heads(vc[:, :min(tok0, Lr)]), ws["kv_part"], n, s_before, prescaled=True)
+            if tok0 + lc < Lr:
+                n += hip.attn_fwd_partial(qg, heads(kc[:, tok0 + lc:Lr]), heads(vc[:, tok0 + lc:Lr]), ws["kv_part"], n, s_after, prescaled=True)
             hip.attn_merge(og, ws["kv_part"], n, prescaled=True)
 
     def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
@@ -791,8 +813,9 @@ class DiTEngine:
         if self.world_size == 1:
             return head_local
         from .dist import all_gather_seq
+        Lr = self.cond["L"]                            # the pad tokens of a sequence that does not divide over the ranks end here
         if self.cfg_size == 1:
-            return all_gather_seq(head_local, self.sp_group)
+            return all_gather_seq(head_local, self.sp_group)[:, :Lr]
         # world rank = cfg_row * sp + sp_rank, one local row each: the rank-major gather IS [2, sp, Lc, n]
         from .dist import all_gather_into_tensor
         bl, lc, n = head_local.shape
@@ -800,4 +823,4 @@ class DiTEngine:
             raise RuntimeError("cfg-parallel ranks carry exactly one CFG row")
         out = torch.empty(self.world_size * lc, n, device=head_local.device, dtype=head_local.dtype)   # rank-major concat
         all_gather_into_tensor(out, head_local.reshape(lc, n).contiguous(), group=self.world_group)
-        return out.view(self.cfg_size, self.sp_size * lc, n)
+        return out.view(self.cfg_size, self.sp_size * lc, n)[:, :Lr]

@@ -100,6 +100,24 @@ def _holder(n_out: int, n_in: int) -> nn.Linear:
     return HipLinear(n_in, n_out)
 
 
+def _fp8_weight(pk: dict, name: str):
+    """(e4m3 bytes, per-output-channel scales) of pack entry `name`, quantised once per pack (the pack is rebuilt when a parameter changes)."""
+    from . import hip
+    key = "_f8_" + name
+    if key not in pk:
+        pk[key] = hip.quantize_rows_fp8(pk[name])
+    return pk[key]
+
+
+def _proj_fp8(h: torch.Tensor, pk: dict, wname: str, bias, epilogue: int = 0) -> torch.Tensor:
+    """h [M, K] bf16 -> bf16 [M, N] on the fp8 (OCP e4m3) MFMA path: rows of h quantised per call (absmax / 448), weights per output channel,
+    fp32 accumulation, scales / bias / activation in the epilogue (csrc/gemm_fp8.hip) -- the module-seam form of DiTEngine.enable_fp8."""
+    from . import hip
+    a8, sa = hip.quantize_rows_fp8(h)
+    w8, sw = _fp8_weight(pk, wname)
+    return hip.gemm_fp8(a8, sa, w8, sw, bias, epilogue=epilogue)
+
+
 class _Norm(nn.Module):
     """WanRMSNorm (wan_transformer3d_FlexAM.py:173-189; weight only) or the affine WanLayerNorm `norm3` (:192-202)."""
 
@@ -132,6 +150,7 @@ class _Attn(nn.Module):
         self.q, self.k, self.v, self.o = (_holder(dim, dim) for _ in range(4))
         self.norm_q, self.norm_k = _Norm(dim, eps=eps), _Norm(dim, eps=eps)
         self._pk = None
+        self._fp8 = False                                      # q|k|v (self-attention) / q (cross-attention) projection on the fp8 MFMA path (model.enable_fp8_gemm)
 
     def _sig(self):
         return tuple(_param_sig(m) for m in (self.q, self.k, self.v, self.o, self.norm_q, self.norm_k))
@@ -199,7 +218,7 @@ class _SelfAttn(_Attn):
             n_keys = lens[0]
         pk = self.packed()
         h = x.reshape(b * l, c).to(BF16).contiguous()
-        qkv = hip.gemm(h, pk["wqkv"], pk["bqkv"])
+        qkv = _proj_fp8(h, pk, "wqkv", pk["bqkv"]) if self._fp8 else hip.gemm(h, pk["wqkv"], pk["bqkv"])
         cos, sin = self._rope(grid_sizes, l, freqs, x.device)
         hip.rmsnorm_rope(qkv[:, 0:c], pk["nq"], qkv[:, c:2 * c], pk["nk"], eps=self.eps, rope_cos=cos, rope_sin=sin,
                          tokens_per_batch=l, token_offset=0, head_dim=hd)
@@ -225,16 +244,19 @@ class _SelfAttn(_Attn):
         from .dist import all_gather_seq
         b, lc, c = x.shape
         nh, hd = self.num_heads, self.head_dim
-        L = sp["seq_len"]
-        if lc * sp["size"] != L or (seq_lens is not None and any(int(v) != L for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens))):
-            raise NotImplementedError(f"flexam_amd: a sequence-parallel chunk of {lc} tokens x {sp['size']} ranks does not tile seq_lens / L = {L}")
+        L = sp["seq_len"]                                                           # the REAL length; lc * size is the padded one
+        Lp = lc * sp["size"]
+        if not (L <= Lp < L + sp["size"]) or (seq_lens is not None and any(int(v) != L for v in (seq_lens.tolist() if torch.is_tensor(seq_lens) else seq_lens))):
+            raise NotImplementedError(f"flexam_amd: a sequence-parallel chunk of {lc} tokens x {sp['size']} ranks is not the padded form of seq_lens / L = {L} "
+                                      "(ceil(L / ranks) * ranks rows, FX.py:919-920)")
         pk = self.packed()
-        qkv = hip.gemm(x.reshape(b * lc, c).to(BF16).contiguous(), pk["wqkv"], pk["bqkv"])
+        h = x.reshape(b * lc, c).to(BF16).contiguous()
+        qkv = _proj_fp8(h, pk, "wqkv", pk["bqkv"]) if self._fp8 else hip.gemm(h, pk["wqkv"], pk["bqkv"])
         hip.rmsnorm_rope(qkv[:, 0:c], pk["nq"], qkv[:, c:2 * c], pk["nk"], eps=self.eps, rope_cos=sp["rope_cos"], rope_sin=sp["rope_sin"],
                          tokens_per_batch=lc, token_offset=sp["token_offset"], head_dim=hd)
         q3 = qkv.view(b, lc, 3 * c)
-        kv = all_gather_seq(q3[:, :, c:].contiguous(), sp["group"])                  # [B, L, 2C]
-        ao = hip.attn_fwd(q3[:, :, 0:c].unflatten(2, (nh, hd)), kv[:, :, 0:c].unflatten(2, (nh, hd)), kv[:, :, c:].unflatten(2, (nh, hd)),
+        kv = all_gather_seq(q3[:, :, c:].contiguous(), sp["group"])                  # [B, Lp, 2C]; rows L .. Lp - 1 are the zero pad tokens:
+        ao = hip.attn_fwd(q3[:, :, 0:c].unflatten(2, (nh, hd)), kv[:, :L, 0:c].unflatten(2, (nh, hd)), kv[:, :L, c:].unflatten(2, (nh, hd)),   # no keys (k_lens, FX.py:251-256)
                           prescaled=True)
         return hip.gemm(ao.view(b * lc, c), pk["wo"], pk["bo"]).view(b, lc, c)
 
@@ -269,7 +291,8 @@ class _CrossAttn(_Attn):
         nh, hd = self.num_heads, self.head_dim
         tl = context.shape[1]
         pk = self.packed()
-        q = hip.gemm(x.reshape(b * l, c).to(BF16).contiguous(), pk["cwq"], pk["cbq"])
+        h = x.reshape(b * l, c).to(BF16).contiguous()
+        q = _proj_fp8(h, pk, "cwq", pk["cbq"]) if self._fp8 else hip.gemm(h, pk["cwq"], pk["cbq"])
         hip.rmsnorm_rope(q, pk["cnq"], eps=self.eps)
         kv = self.context_kv(context.reshape(b * tl, c).to(BF16).contiguous()).view(b, tl, 2 * c)
         q4 = q.view(b, l, nh, hd)
@@ -315,6 +338,13 @@ class _Block(nn.Module):
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
         self.modulation_density = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
         self._pk = None
+        self._fp8 = False                                      # FFN on the fp8 MFMA path when the block is called as a module (set_fp8)
+
+    def set_fp8(self, on: bool):
+        """BASELINE configs[4] through the block-level seam: the same GEMMs DiTEngine.enable_fp8 moves to the fp8 pipe -- self-attention
+        q|k|v, cross-attention q, FFN1 (+ GELU), FFN2 (+ gated residual) -- when this block runs as a module (replaced / wrapped /
+        re-bound blocks: comfyui/comfyui_nodes.py:67-71, wan_transformer3d_FlexAM.py:807-815).  Activations: absmax rows per call."""
+        self._fp8 = self.self_attn._fp8 = self.cross_attn._fp8 = bool(on)
 
     def pristine(self) -> bool:
         """No instance-level `forward` on the block or its attention modules (what types.MethodType re-binding creates)."""
@@ -355,8 +385,14 @@ class _Block(nn.Module):
         y = self.cross_attn(hbuf.view(b, l, c), context, context_lens, dtype, t=t)
         hip.gate_residual(xres, y.reshape(b * l, c).to(BF16).contiguous())
         hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=idx, rows_per_batch=l)
-        mid = hip.gemm(hbuf, pk["w1"], pk["b1"], epilogue=hip.EPI_GELU_TANH)
-        hip.gemm_gate_residual(mid, pk["w2"], pk["b2"], xres, gate=T[:, 5], gate_row=idx, rows_per_batch=l)
+        if self._fp8:
+            mid = _proj_fp8(hbuf, pk, "w1", pk["b1"], epilogue=hip.EPI_GELU_TANH)
+            a8, sa = hip.quantize_rows_fp8(mid)
+            w8, sw = _fp8_weight(pk, "w2")
+            hip.gemm_fp8_gate_residual(a8, sa, w8, sw, pk["b2"], xres, gate=T[:, 5], gate_row=idx, rows_per_batch=l)
+        else:
+            mid = hip.gemm(hbuf, pk["w1"], pk["b1"], epilogue=hip.EPI_GELU_TANH)
+            hip.gemm_gate_residual(mid, pk["w2"], pk["b2"], xres, gate=T[:, 5], gate_row=idx, rows_per_batch=l)
         return xres.view(b, l, c)
 
 
@@ -595,6 +631,9 @@ class WanTransformer3DModel_FlexAM(nn.Module):
         """This build's extension (BASELINE.json configs[4]): QKV and FFN projections on fp8 (OCP e4m3) MFMA with per-row /
         per-channel scales; see DiTEngine.enable_fp8.  Off by default; parity tolerance is the fp8 one (tests/test_fp8_gpu.py)."""
         self._fp8 = bool(on)
+        for mod in self.modules():                 # every native block, also those inside a caller's wrapper modules (blocks[i] = wrapper(block))
+            if isinstance(mod, _Block):
+                mod.set_fp8(self._fp8)
         if self._engine is not None:
             self._engine.enable_fp8(self._fp8)
 

@@ -107,11 +107,17 @@ def test_sequence_parallel_attention_matches_single_process():
     assert max(errs) < 5e-5, errs
 
 
-def test_chunk_bounds_requires_even_split():
-    from flexam_amd.dist import chunk_bounds
-    assert chunk_bounds(11648, 7, 8) == (10192, 11648)
-    with pytest.raises(ValueError):
-        chunk_bounds(11648, 0, 5)
+def test_chunk_bounds_pad_like_the_reference():
+    """Equal chunks of the sequence padded to a multiple of the ranks (wan_transformer3d_FlexAM.py:919-920); the pads sit at the end."""
+    from flexam_amd.dist import chunk_bounds, padded_len, real_tokens, shard_rows
+    assert chunk_bounds(11648, 7, 8) == (10192, 11648) and padded_len(11648, 8) == 11648 and real_tokens(11648, 7, 8) == 1456
+    assert padded_len(11648, 3) == 11649 and padded_len(11648, 5) == 11650
+    assert [chunk_bounds(11648, r, 3) for r in range(3)] == [(0, 3883), (3883, 7766), (7766, 11649)]
+    assert [real_tokens(11648, r, 3) for r in range(3)] == [3883, 3883, 3882]
+    assert [real_tokens(5, r, 4) for r in range(4)] == [2, 2, 1, 0]                  # a rank may hold pads only
+    idx = torch.arange(2 * 7, dtype=torch.int32)                                     # B = 2, L = 7, three ranks: chunks of 3, the last 1 real + 2 pads
+    assert shard_rows(idx, 2, 7, 0, 3).tolist() == [0, 1, 2, 7, 8, 9]
+    assert shard_rows(idx, 2, 7, 2, 3).tolist() == [6, 6, 6, 13, 13, 13]             # pads repeat the last real token's entry (FX.py:930-934)
 
 
 def _async_gather(rank, world):

