@@ -349,14 +349,15 @@ class DiTEngine:
                                      a8d=torch.empty(m, d, device=dev, dtype=torch.uint8), so=torch.empty(m, device=dev, dtype=F32))
         return self._ws[key]
 
-    def _attn8_buffers(self, nb, lc):
-        """MXFP8 operand buffers of the quantised self-attention (one set per (samples, tokens) shape, reused by every block)."""
+    def _attn8_buffers(self, nb, lc, heads=None):
+        """MXFP8 operand buffers of the quantised self-attention (one set per (samples, tokens, heads) shape, reused by every block)."""
         cache = self.__dict__.setdefault("_attn8", {})
-        if (nb, lc) not in cache:
-            if any(k[1] != lc for k in cache):          # another token count: drop the old sets (as _workspace does)
+        heads = self.nh if heads is None else heads
+        if (nb, lc, heads) not in cache:
+            if any(k[1:] != (lc, heads) for k in cache):          # another token / head count: drop the old sets (as _workspace does)
                 cache.clear()
-            cache[(nb, lc)] = hip.attn_fp8_buffers(nb, self.nh, lc, self.device)      # (block 0 may run one sample: its own set, not a re-allocation per step)
-        return cache[(nb, lc)]
+            cache[(nb, lc, heads)] = hip.attn_fp8_buffers(nb, heads, lc, self.device)      # (block 0 may run one sample: its own set, not a re-allocation per step)
+        return cache[(nb, lc, heads)]
 
     # ------------------------------------------------------------------ per-step
     def embed_time(self, t_rows: torch.Tensor):
@@ -461,14 +462,18 @@ class DiTEngine:
         nh, hdim = self.nh, self.hd
         # the reference reads the switch at every attention call (attention_utils.py:195); quantised self-attention on one rank only
         sage_asked = os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION"
-        sage = sp == 1 and sage_asked
+        # one rank: the fused producer (RMSNorm + RoPE write the MXFP8 operands).  Sequence parallel with the all-to-all over heads: every
+        # rank ends up with ALL tokens of its heads in bf16, packs them and runs the MXFP8 kernel on them (r6).  The K|V all-gather keeps
+        # the bf16 kernel: its key tiles (64 keys, one record each) do not line up with the ranks' token chunks, so MXFP8 records cannot
+        # be gathered and re-packing ALL keys on every rank costs more than the kernel saves -- said once per process
+        sage = sage_asked and self.fused and (sp == 1 or (self.sp_mode == "ulysses" and Lp == L))
         self.sage_taken = bool(sage)                       # what this forward DID (bench.py labels its line from it, like share0_taken)
         if sage_asked and not sage and not DiTEngine._sage_warned:
             DiTEngine._sage_warned = True
             import warnings
             warnings.warn("flexam_amd: VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION is ignored " +
-                          "under sequence parallelism (the K|V exchange carries bf16 rows): self-attention runs the bf16 kernel",
-                          RuntimeWarning, stacklevel=2)
+                          "under sequence parallelism with the K|V all-gather (or a padded sequence): self-attention runs the bf16 kernel; "
+                          "FLEXAM_SP_MODE=ulysses keeps the MXFP8 kernel", RuntimeWarning, stacklevel=2)
         fp8_oproj = self.fp8 and os.environ.get("FLEXAM_FP8_OPROJ", "0") == "1"
         q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hdim))
         k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hdim))
@@ -503,7 +508,7 @@ class DiTEngine:
             if sp > 1 and self.sp_mode == "ulysses":
                 # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
                 # returned blocks in place (flexam_amd/dist.py)
-                a_o, koff_o = self._ulysses_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, B, lc, tok0)
+                a_o, koff_o = self._ulysses_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, B, lc, tok0, sage=sage)
                 hip.gemm_gate_residual(a_o, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb, a_koff=koff_o)
             elif sp > 1:
                 # K|V projection + K norm/RoPE first, written straight into the send buffer; their all-gather (RCCL over xGMI)
@@ -651,7 +656,7 @@ class DiTEngine:
         return calc
 
     # ------------------------------------------------------------------ sequence parallel
-    def _ulysses_attention(self, qkv, hbuf, a8sa, layer, p, B, lc, tok0):
+    def _ulysses_attention(self, qkv, hbuf, a8sa, layer, p, B, lc, tok0, sage=False):
         """h [B*lc, C] (LayerNorm output of this rank's tokens) -> q|k|v projection -> exchange -> attention -> exchange back ->
         (A base view, per-K-block A offsets) of the attention output for the o-projection.  Head group j = heads j*H/sp .. goes
         to rank j.
@@ -683,6 +688,17 @@ class DiTEngine:
         chunks = out.view(B, sp, lc, G)
         nk = cd["L"]                                   # keys: the real tokens (rows nk .. sp*lc - 1 are the reference's zero pads, FX.py:919-925)
 
+        def attend(b0, nb):
+            """Attention of samples b0 .. b0 + nb - 1 on this rank's heads over all tokens; SAGE_ATTENTION: the received bf16 q|k|v are
+            packed into MXFP8 operands first (flexam_attn_fp8_pack) and the quantised kernel runs (run() only asks for it when nk = sp * lc)."""
+            q_, k_, v_ = full[b0:b0 + nb, :, 0], full[b0:b0 + nb, :nk, 1], full[b0:b0 + nb, :nk, 2]
+            if sage:
+                bufs = self._attn8_buffers(nb, sp * lc, hg)
+                hip.attn_fp8_pack(q_, k_, v_, bufs)
+                hip.attn_fwd_fp8(bufs, sp * lc, out=out[b0:b0 + nb])
+            else:
+                hip.attn_fwd(q_, k_, v_, out=out[b0:b0 + nb], prescaled=True)
+
         def project_and_pack(rows, b0, nb):          # samples b0 .. b0 + nb - 1: rows of h -> q|k|v -> normed / rotated send blocks
             a8 = a8sa and (a8sa[0][rows], a8sa[1][rows])
             self._proj(hbuf[rows], a8, layer, p, "wqkv", "bqkv", slice(None), qkv[rows])
@@ -695,7 +711,7 @@ class DiTEngine:
             project_and_pack(slice(None), 0, B)
             for b in range(B):
                 all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group)
-            hip.attn_fwd(full[:, :, 0], full[:, :nk, 1], full[:, :nk, 2], out=out, prescaled=True)
+            attend(0, B)
             for b in range(B):
                 all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group)
             return recv2.view(sp * B * lc, G), ws["a2a_koff"]
@@ -707,7 +723,7 @@ class DiTEngine:
             for w in there:
                 if w is not None:
                     w.wait()
-            hip.attn_fwd(full[:, :, 0], full[:, :nk, 1], full[:, :nk, 2], out=out, prescaled=True)
+            attend(0, B)
             back = [all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True)
                     for b in range(B)]
             for w in back:
@@ -717,7 +733,7 @@ class DiTEngine:
         for b in range(B):
             if there[b] is not None:
                 there[b].wait()
-            hip.attn_fwd(full[b:b + 1, :, 0], full[b:b + 1, :nk, 1], full[b:b + 1, :nk, 2], out=out[b:b + 1], prescaled=True)
+            attend(b, 1)
             back.append(all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True))
         for w in back:
             if w is not None:
