@@ -42,17 +42,19 @@ def measure_rank_step(step, sync, steps: int, warmup: int):
 
 
 def layouts(world: int, num_heads: int):
-    """(name, FLEXAM_SP_MODE, cfg_parallel, pieces): the layouts the N-rank run chooses between (benchlib/probe.candidates), without
-    the overlap variants that only differ in what travels under what."""
+    """(name, FLEXAM_SP_MODE, cfg_parallel, pieces, FLEXAM_SP_OVERLAP or None = the engine's default): the layouts the N-rank run chooses
+    between (benchlib/probe.candidates).  The first row is the default layout."""
     out = []
     if world % 2 == 0:
-        out.append((f"cfg2 x sp{world // 2}, K|V all-gather (default)", "allgather", True, None))
+        out.append((f"cfg2 x sp{world // 2}, K|V all-gather (default)", "allgather", True, None, None))
     if world >= 4 and num_heads % world == 0:
-        out.append((f"cfg1 x sp{world}, all-to-all over heads", "ulysses", False, None))
+        out.append((f"cfg1 x sp{world}, all-to-all over heads", "ulysses", False, None, None))
     if world >= 4 and world % 2 == 0 and num_heads % (world // 2) == 0:
-        out.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, None))
+        out.append((f"cfg2 x sp{world // 2}, all-to-all over heads", "ulysses", True, None, None))
     if world % 2 or world == 2:
-        out.append((f"cfg1 x sp{world}, K|V all-gather", "allgather", False, None))
+        out.append((f"cfg1 x sp{world}, K|V all-gather", "allgather", False, None, None))
+    if world >= 4 and world % 2 == 0:
+        out.append((f"cfg2 x sp{world // 2}, K|V all-gather with local-chunk-first attention under it (FLEXAM_SP_OVERLAP=1)", "allgather", True, None, "1"))
     return out
 
 
@@ -75,13 +77,16 @@ def emulate(model, make_pipe, inp, cond, world: int, steps: int, warmup: int, to
     saved = {k: os.environ.get(k) for k in ("FLEXAM_SP_MODE", "FLEXAM_SP_PIECES", "FLEXAM_SP_OVERLAP")}
     rows = []
     try:
-        for name, mode, cfgp, pieces in layouts(world, model.num_heads):
+        for name, mode, cfgp, pieces, overlap in layouts(world, model.num_heads):
             sp = world // 2 if cfgp else world
             r = rank if rank is not None else (sp // 2 if sp > 2 else 0)
             os.environ["FLEXAM_SP_MODE"] = mode
             os.environ.pop("FLEXAM_SP_PIECES", None)
+            os.environ.pop("FLEXAM_SP_OVERLAP", None)
             if pieces is not None:
                 os.environ["FLEXAM_SP_PIECES"] = str(pieces)
+            if overlap is not None:
+                os.environ["FLEXAM_SP_OVERLAP"] = str(overlap)
             set_emulated_layout(model, world, cfgp, r)
             pipe = make_pipe()
             pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)

@@ -10,12 +10,13 @@ PROBE_ENV = ("FLEXAM_SP_MODE", "FLEXAM_CFG_PARALLEL", "FLEXAM_SP_OVERLAP", "FLEX
 
 
 def candidates(world: int, num_heads: int):
-    cands = [(f"cfg2 x sp{world // 2}, K|V all-gather", "allgather", True, "1", None)]
+    """(name, FLEXAM_SP_MODE, cfg_parallel, FLEXAM_SP_OVERLAP, FLEXAM_SP_PIECES).  The first one is the default layout (what runs when
+    nothing is measured): one K|V gather per block, waited for, ONE attention call -- the fastest form on compute (r5: 41.4 against 48.1
+    ms per rank step at 8 GPUs for the overlapped form, whose partial-softmax machinery pays only on slow links: measured here)."""
+    cands = [(f"cfg2 x sp{world // 2}, K|V all-gather in one piece, waited for (default)", "allgather", True, "0", "1"),
+             (f"cfg2 x sp{world // 2}, K|V all-gather, local-chunk-first attention under the gather", "allgather", True, "1", None)]
     if world // 2 >= 4:
-        cands.append((f"cfg2 x sp{world // 2}, K|V all-gather in one piece", "allgather", True, "1", "1"))
-    # one gather per block, waited for, then ONE attention call: no partial softmaxes, no merges -- 41.4 against 48.1 ms of compute per
-    # rank step at 8 GPUs; it wins where a link moves a rank's 36 MB per block faster than that saving
-    cands.append((f"cfg2 x sp{world // 2}, K|V all-gather in one piece, waited for", "allgather", True, "0", "1"))
+        cands.append((f"cfg2 x sp{world // 2}, K|V all-gather in one piece, local-chunk-first attention under it", "allgather", True, "1", "1"))
     if num_heads % world == 0:
         cands.append((f"cfg1 x sp{world}, all-to-all over heads, a sample's blocks leave under the other's projection", "ulysses", False, "1", None))
         cands.append((f"cfg1 x sp{world}, all-to-all over heads, samples fully pipelined (attention per sample)", "ulysses", False, "2", None))
@@ -120,10 +121,7 @@ def probe_layouts(model, pipe, inp, cond, cfg, world, device, total_steps):
             best = probe["candidates"][int(os.environ["FLEXAM_BENCH_LAYOUT_FORCE"])]
         probe["chosen"] = best["layout"]
         os.environ["FLEXAM_SP_MODE"] = best["mode"]
-        if best["overlap"] == "1":
-            os.environ.pop("FLEXAM_SP_OVERLAP", None)      # the default; left unset so that a failed self-check can still fall back to 0
-        else:
-            os.environ["FLEXAM_SP_OVERLAP"] = best["overlap"]
+        os.environ["FLEXAM_SP_OVERLAP"] = best["overlap"]  # always pinned: the engine's default differs per exchange (gather 0, all-to-all 1)
         os.environ.pop("FLEXAM_SP_PIECES", None)
         if best["pieces"] is not None:
             os.environ["FLEXAM_SP_PIECES"] = best["pieces"]

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflexam_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attn.hip", "dit_elementwise.hip", "conv_cl.hip", "vae.hip", "text_encoder.hip", "raster.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_fp8.hip", "attn.hip", "dit_elementwise.hip", "conv_cl.hip", "vae.hip", "text_encoder.hip", "raster.hip", "replay.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
          "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
 
@@ -26,6 +26,9 @@ def _stale(obj, src):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    from . import gen_replay
+    if gen_replay.write() and verbose:                 # csrc/replay_table.inc follows include/flexam_hip.h (committed; rewritten only when the header moved)
+        print("regenerated", gen_replay.OUT, flush=True)
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     objs, procs = [], []

@@ -99,6 +99,7 @@ class DiTEngine:
         self.world_group, self.world_size = None, 1
         self.cfg_size, self.cfg_row = 1, 0          # cfg_size 2: this rank computes only CFG row `cfg_row`
         self._ws = {}
+        self._ws_gen = 0                            # bumped whenever the activation buffers are dropped: recorded launch plans name their addresses
         self._angles = None
         self.cond = None
         self.n_conditioning = 0                     # set_conditioning runs so far (tests: the per-clip work is hoisted)
@@ -163,16 +164,25 @@ class DiTEngine:
         if mode not in ("ulysses", "allgather"):
             raise ValueError(f"FLEXAM_SP_MODE={mode!r}: expected 'ulysses' or 'allgather'")
         self.sp_mode = mode if (mode == "allgather" or self.nh % max(sp_size, 1) == 0) else "allgather"
-        # local-chunk-first attention under the K|V all-gather (0: wait for the gather, then one attention call)
-        ov = os.environ.get("FLEXAM_SP_OVERLAP", "1").strip().lower()              # "0" / "off" / "false": off; "2": the pipelined all-to-all form;
+        # FLEXAM_SP_OVERLAP.  K|V all-gather: 0 (default since r6) = ONE gather per block and CFG row, waited for, then ONE ordinary
+        # attention call; 1 = head-group pieces with local-chunk-first partial attention + merge underneath them.  r5 measured the
+        # overlap machinery at 6.7 ms of a 48 ms rank step at 8 GPUs (three partial calls parking 17 fp32 slots for a merge: 605 us of
+        # attention per block against 342 for the one call; profiles/r5o_*): it pays only on links slow enough that hiding ~0.3 ms of
+        # a block's gather is worth 0.22 ms of compute, which bench.py's layout probe measures per node -- the default is the form
+        # that is fastest on compute.  All-to-all over heads: 1 (default) = a sample's blocks leave under the other sample's projection,
+        # 2 = attention per sample as well, 0 = one exchange for the pair.
+        ov = os.environ.get("FLEXAM_SP_OVERLAP")
+        ov = ("1" if self.sp_mode == "ulysses" else "0") if ov is None else ov.strip().lower()
         self.sp_overlap_level = 0 if ov in ("0", "off", "false", "no", "") else (2 if ov == "2" else 1)      # anything else: on (1)
         self.sp_overlap = self.sp_overlap_level != 0
-        # the K|V gather is cut into `sp_pieces` groups of heads, one collective each: the attention of a group starts when ITS
-        # piece has landed, the later pieces travel underneath it (1: one gather per block and CFG row)
-        # Default: 2 pieces from 4 chunks on (3+ peers: the gather outlasts the Q projection + local-chunk attention it hides under),
-        # 1 below (two chunks: one peer's 36 MB arrive within that window anyway, and a piece costs 3-4 more launches per block)
+        # with the overlap on, the K|V gather is cut into `sp_pieces` groups of heads, one collective each: the attention of a group starts
+        # when ITS piece has landed, the later pieces travel underneath it.  Default: 2 pieces from 4 chunks on (3+ peers: the gather
+        # outlasts the local-chunk attention it hides under), 1 below and whenever the gather is waited for (two attention calls on half
+        # the heads each fill 256 CUs worse than one: 44.2 against 41.4 ms per rank step, profiles/r5o_*)
         env = os.environ.get("FLEXAM_SP_PIECES")
-        pieces = int(env) if env is not None else (2 if sp_size >= 4 and self.nh % 2 == 0 else 1)
+        pieces = int(env) if env is not None else (2 if (sp_size >= 4 and self.nh % 2 == 0 and self.sp_overlap and self.sp_mode == "allgather") else 1)
+        if self.sp_mode != "allgather":
+            pieces = 1                              # (head-group pieces belong to the gather)
         if pieces < 1 or self.nh % pieces:
             raise ValueError(f"FLEXAM_SP_PIECES={pieces}: must divide the {self.nh} heads")
         self.sp_pieces = pieces if sp_size > 1 else 1
@@ -181,6 +191,7 @@ class DiTEngine:
         self.world_size = world_size if world_size is not None else sp_size
         self.cfg_size, self.cfg_row = cfg_size, cfg_row
         self._ws.clear()
+        self._ws_gen += 1
 
     def enable_fp8(self, on: bool = True):
         """QKV (self-attention q|k|v, cross-attention q) and FFN projections on the fp8 (OCP e4m3) MFMA path: weights quantised once per output channel, activations per
@@ -215,6 +226,7 @@ class DiTEngine:
                 self._fp8_w.append(q)
         self.fp8 = bool(on)
         self._ws.clear()
+        self._ws_gen += 1
 
     def _ln_fp8(self, xres, ws, hbuf, nxt=None, **kw):
         """LN + modulate as the fp8 GEMMs' A operand: one launch at widths the wave-per-row kernel covers (multiples of 512, the 5B
@@ -339,6 +351,7 @@ class DiTEngine:
         if key not in self._ws:
             dev, d, m = self.device, self.dim, B * lc
             self._ws = {}
+            self._ws_gen += 1
             self._ws[key] = dict(
                 x=torch.empty(m, d, device=dev, dtype=F32), h=torch.empty(m, d, device=dev, dtype=BF16),
                 qkv=torch.empty(m, 3 * d, device=dev, dtype=BF16), ao=torch.empty(m, d, device=dev, dtype=BF16),
@@ -440,13 +453,18 @@ class DiTEngine:
             e, e0 = self.embed_time(t_rows)
         per_layer = (not self.fused) or self.nl * R * 6 * d * 4 > self.table_limit
         dens0c = dens0.contiguous() if dens0 is not None else None
+        # the tables live in the workspace (one set per row count): the blocks' launches name their addresses, and a recorded launch plan
+        # (below) is only valid while they stay put
+        tabs = ws.setdefault(("tabs", R, per_layer), {})
+        if not tabs:
+            tabs["blk"] = torch.empty(1 if per_layer else self.nl, R, 6, d, device=dev, dtype=F32)
+            tabs["head"] = torch.empty(1, R, 2, d, device=dev, dtype=F32)
         if per_layer:
-            tab = None
-            tab1 = torch.empty(1, R, 6, d, device=dev, dtype=F32)
+            tab, tab1 = None, tabs["blk"]
         else:
-            tab = torch.empty(self.nl, R, 6, d, device=dev, dtype=F32)
+            tab = tabs["blk"]
             hip.mod_table(self.mod, e0, tab, rows_per_batch, 0b010010, self.mdens, dens0c, 0xFF1FF0 if dens0 is not None else -1)
-        htab = torch.empty(1, R, 2, d, device=dev, dtype=F32)
+        htab = tabs["head"]
         e2 = e.unsqueeze(1).expand(R, 2, d).contiguous()
         hd_dens = dens_emb.reshape(B, 1, d).contiguous() if dens_emb is not None else None
         hip.mod_table(self.hmod, e2, htab, rows_per_batch, 0b10, self.hmdens if hd_dens is not None else None, hd_dens,
@@ -454,9 +472,18 @@ class DiTEngine:
         calc = True
         if teacache is not None:
             calc = self._teacache_decide(teacache, e0, row_index, B, L, cond_flag)
-        if row_index is not None and sp > 1:
-            from .dist import shard_rows
-            row_index = shard_rows(row_index, B, L, rank, sp)
+        if row_index is not None:
+            # the per-token row index of THIS rank's rows, copied (47 KB) into a buffer of the workspace: the blocks' launches then see ONE
+            # address from step to step whoever built the index (the sampler keeps one tensor per clip, the reference-style forward()
+            # builds a new one per call) -- what a recorded launch plan (below) needs
+            if sp > 1:
+                from .dist import shard_rows
+                row_index = shard_rows(row_index, B, L, rank, sp)
+            buf = ws.get("row_index_buf")
+            if buf is None or buf.numel() != row_index.numel():
+                buf = ws["row_index_buf"] = torch.empty(row_index.numel(), device=dev, dtype=I32)
+            buf.copy_(row_index.reshape(-1))
+            row_index = buf
         rpb = lc                                   # used only when row_index is None: row = m // lc = b
 
         nh, hdim = self.nh, self.hd
@@ -490,114 +517,148 @@ class DiTEngine:
                 ori = xres.clone()
         if calc and not self.fused:
             self._run_block_modules(xres, B, lc, e0, row_index, rows_per_batch, dens0, t_rows, rsel)
-        for i, p in enumerate(self.blocks if (calc and self.fused) else ()):
-            if per_layer:                                  # one table, rebuilt per layer (bounded memory, see table_limit)
-                hip.mod_table(self.mod[i:i + 1], e0, tab1, rows_per_batch, 0b010010, self.mdens[i:i + 1], dens0c,
-                              0xFF1FF0 if dens0 is not None else -1)
-                T = tab1[0]
-            else:
-                T = tab[i]
-            fp8_here = self.fp8
-            nb = 1 if (share0 and i == 0) else B               # samples that run the self-attention half of this block (share0: above)
-            mb = nb * lc
-            ri = row_index[:mb] if row_index is not None else None
-            if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
-                a8, sa, _ = self._ln_fp8(xres[:mb], ws, hbuf[:mb], shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
-            else:
-                hip.ln_modulate(xres[:mb], out=hbuf[:mb], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
-            if sp > 1 and self.sp_mode == "ulysses":
-                # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
-                # returned blocks in place (flexam_amd/dist.py)
-                a_o, koff_o = self._ulysses_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, B, lc, tok0, sage=sage)
-                hip.gemm_gate_residual(a_o, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb, a_koff=koff_o)
-            elif sp > 1:
-                # K|V projection + K norm/RoPE first, written straight into the send buffer; their all-gather (RCCL over xGMI)
-                # runs under the Q projection, the Q norm/RoPE and the attention to the LOCAL chunk
-                # (FLEXAM_SP_FUSED_QKV=1, default: ONE q|k|v launch instead -- at a rank's few thousand rows two launches of 24 and 12 tile
-                #  columns quantise worse on 256 CUs than one of 36 (emulated rank of 8, profiles/r5*: 119 + 80 us against ~135), and the
-                #  gather starts ~15 us later, not ~80)
-                fused_qkv = self.sp_fused_qkv
-                self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None) if fused_qkv else slice(d, None), qkv if fused_qkv else qkv[:, d:])
-                self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0, q_done=fused_qkv)
-                hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
-            else:
-                a8sa = fp8_here and (a8[:mb], sa[:mb])
-                self._proj(hbuf[:mb], a8sa, i, p, "wqkv", "bqkv", slice(None), qkv[:mb])
-                if sage and nh == 24 and hdim == 128 and os.environ.get("FLEXAM_SAGE_FUSED", "1") != "0":   # SAGE_ATTENTION: MXFP8 operands (csrc/attn_fp8.inc);
-                    bufs = self._attn8_buffers(nb, lc)     # RMSNorm + RoPE write Q and K as operands directly, V is packed on its own
-                    hip.rmsnorm_rope_mx(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], bufs, cd["cos"], cd["sin"], lc, tok0, eps=self.eps)
-                    hip.attn_fp8_pack(None, None, v4[:nb], bufs)
-                    hip.attn_fwd_fp8(bufs, lc, out=ao4[:nb])
+
+        def run_blocks():
+            for i, p in enumerate(self.blocks if (calc and self.fused) else ()):
+                if per_layer:                                  # one table, rebuilt per layer (bounded memory, see table_limit)
+                    hip.mod_table(self.mod[i:i + 1], e0, tab1, rows_per_batch, 0b010010, self.mdens[i:i + 1], dens0c,
+                                  0xFF1FF0 if dens0 is not None else -1)
+                    T = tab1[0]
                 else:
-                    hip.rmsnorm_rope(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
-                                     tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
-                    if sage:
-                        bufs = self._attn8_buffers(nb, lc)
-                        hip.attn_fp8_pack(q4[:nb], k4[:nb], v4[:nb], bufs)
+                    T = tab[i]
+                fp8_here = self.fp8
+                nb = 1 if (share0 and i == 0) else B               # samples that run the self-attention half of this block (share0: above)
+                mb = nb * lc
+                ri = row_index[:mb] if row_index is not None else None
+                if fp8_here:                                   # LN + modulate written as e4m3 + row scales: the fp8 QKV GEMM's A operand
+                    a8, sa, _ = self._ln_fp8(xres[:mb], ws, hbuf[:mb], shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
+                else:
+                    hip.ln_modulate(xres[:mb], out=hbuf[:mb], eps=self.eps, shift=T[:, 0], scale=T[:, 1], row_index=ri, rows_per_batch=rpb)
+                if sp > 1 and self.sp_mode == "ulysses":
+                    # all tokens of H/sp heads per rank: q|k|v all-to-all -> attention -> all-to-all back; the o-projection reads the
+                    # returned blocks in place (flexam_amd/dist.py)
+                    a_o, koff_o = self._ulysses_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, B, lc, tok0, sage=sage)
+                    hip.gemm_gate_residual(a_o, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb, a_koff=koff_o)
+                elif sp > 1:
+                    # K|V projection + K norm/RoPE first, written straight into the send buffer; their all-gather (RCCL over xGMI)
+                    # runs under the Q projection, the Q norm/RoPE and the attention to the LOCAL chunk
+                    # (FLEXAM_SP_FUSED_QKV=1, default: ONE q|k|v launch instead -- at a rank's few thousand rows two launches of 24 and 12 tile
+                    #  columns quantise worse on 256 CUs than one of 36 (emulated rank of 8, profiles/r5*: 119 + 80 us against ~135), and the
+                    #  gather starts ~15 us later, not ~80)
+                    fused_qkv = self.sp_fused_qkv
+                    self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None) if fused_qkv else slice(d, None), qkv if fused_qkv else qkv[:, d:])
+                    self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0, q_done=fused_qkv)
+                    hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
+                else:
+                    a8sa = fp8_here and (a8[:mb], sa[:mb])
+                    self._proj(hbuf[:mb], a8sa, i, p, "wqkv", "bqkv", slice(None), qkv[:mb])
+                    if sage and nh == 24 and hdim == 128 and os.environ.get("FLEXAM_SAGE_FUSED", "1") != "0":   # SAGE_ATTENTION: MXFP8 operands (csrc/attn_fp8.inc);
+                        bufs = self._attn8_buffers(nb, lc)     # RMSNorm + RoPE write Q and K as operands directly, V is packed on its own
+                        hip.rmsnorm_rope_mx(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], bufs, cd["cos"], cd["sin"], lc, tok0, eps=self.eps)
+                        hip.attn_fp8_pack(None, None, v4[:nb], bufs)
                         hip.attn_fwd_fp8(bufs, lc, out=ao4[:nb])
                     else:
-                        hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
-                if fp8_here and fp8_oproj:
-                    a8o, sao = hip.quantize_rows_fp8(ao[:mb], ws["a8d"][:mb], ws["sa"][:mb])
-                    hip.gemm_fp8_gate_residual(a8o, sao, self._fp8_w[i]["wo"], self._fp8_w[i]["s_wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri,
-                                               rows_per_batch=rpb)
+                        hip.rmsnorm_rope(qkv[:mb, 0:d], p["nq"], qkv[:mb, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                                         tokens_per_batch=lc, token_offset=tok0, head_dim=hdim)
+                        if sage:
+                            bufs = self._attn8_buffers(nb, lc)
+                            hip.attn_fp8_pack(q4[:nb], k4[:nb], v4[:nb], bufs)
+                            hip.attn_fwd_fp8(bufs, lc, out=ao4[:nb])
+                        else:
+                            hip.attn_fwd(q4[:nb], k4[:nb], v4[:nb], out=ao4[:nb], prescaled=True)
+                    if fp8_here and fp8_oproj:
+                        a8o, sao = hip.quantize_rows_fp8(ao[:mb], ws["a8d"][:mb], ws["sa"][:mb])
+                        hip.gemm_fp8_gate_residual(a8o, sao, self._fp8_w[i]["wo"], self._fp8_w[i]["s_wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri,
+                                                   rows_per_batch=rpb)
+                    else:
+                        hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
+                    if nb < B:
+                        hip.host_op(lambda: xr[1].copy_(xr[0]))         # (a torch copy, not a library call: a host step of a recorded plan)
+                # cross-attention on the text context (K/V precomputed per clip)
+                qc = qkv[:, 0:d]
+                if self.fp8:                                   # the Q projection of cross-attention on the fp8 pipe as well (its K|V are per clip)
+                    a8, sa, _ = self._ln_fp8(xres, ws, hbuf, ln_w=p["n3w"], ln_b=p["n3b"])
+                    hip.gemm_fp8(a8, sa, self._fp8_w[i]["cwq"], self._fp8_w[i]["s_cwq"], p["cbq"], out=qc)
                 else:
-                    hip.gemm_gate_residual(ao[:mb], p["wo"], p["bo"], xres[:mb], gate=T[:, 2], gate_row=ri, rows_per_batch=rpb)
-                if nb < B:
-                    xr[1].copy_(xr[0])
-            # cross-attention on the text context (K/V precomputed per clip)
-            qc = qkv[:, 0:d]
-            if self.fp8:                                   # the Q projection of cross-attention on the fp8 pipe as well (its K|V are per clip)
-                a8, sa, _ = self._ln_fp8(xres, ws, hbuf, ln_w=p["n3w"], ln_b=p["n3b"])
-                hip.gemm_fp8(a8, sa, self._fp8_w[i]["cwq"], self._fp8_w[i]["s_cwq"], p["cbq"], out=qc)
+                    hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
+                    hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
+                hip.rmsnorm_rope(qc, p["cnq"], eps=self.eps)
+                kv = cd["cross_kv"][i][rsel]
+                if cd.get("cross_lk"):                          # the identical padded text rows as ONE weighted key
+                    lk = cd["cross_lk"]
+                    hip.attn_fwd_lastkey(q4, kv[:, :lk, 0:d].unflatten(2, (nh, hdim)), kv[:, :lk, d:].unflatten(2, (nh, hdim)), cd["cross_mult"],
+                                         out=ao4, prescaled=True)
+                else:
+                    hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
+                if self.fp8 and fp8_oproj:
+                    a8o, sao = hip.quantize_rows_fp8(ao, ws["a8d"], ws["sa"])
+                    hip.gemm_fp8_gate_residual(a8o, sao, self._fp8_w[i]["cwo"], self._fp8_w[i]["s_cwo"], p["cbo"], xres)
+                else:
+                    hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
+                # FFN
+                if self.fp8:
+                    w8 = self._fp8_w[i]
+                    # FFN1 writes FFN2's e4m3 operand itself: its output row scales are known before it runs (a bound from the row's L2
+                    # norm, written by the LN launch), so there is no absmax / quantise pass over the [M, 14336] intermediate
+                    # (FLEXAM_FP8_FFN_APRIORI=0: the earlier form -- bf16 intermediate + an absmax row quantiser pass -- for checkpoints whose w1
+                    #  has a few very large rows: the bound is set by the LARGEST row norm, so every ordinary row's outputs then sit lower in
+                    #  e4m3's range.  One scale per output row has to cover all 14336 columns, so a per-tile bound cannot be used by FFN2.)
+                    apriori = os.environ.get("FLEXAM_FP8_FFN_APRIORI", "1") != "0"
+                    a8, sa, bound = self._ln_fp8(xres, ws, hbuf, nxt=(w8["w1_norm"], w8["b1_max"]) if apriori else None, shift=T[:, 3], scale=T[:, 4],
+                                                 row_index=row_index, rows_per_batch=rpb)
+                    if bound:
+                        hip.gemm_fp8_gelu_q(a8, sa, w8["w1"], w8["s_w1"], p["b1"], ws["so"], ws["a8"])
+                        a8, sa = ws["a8"], ws["so"]
+                    else:                                      # widths the fused LN launch does not cover: bf16 intermediate + row quantiser
+                        hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
+                        a8, sa = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
+                    hip.gemm_fp8_gate_residual(a8, sa, w8["w2"], w8["s_w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
+                else:
+                    hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
+                    # (FFN1 -> FFN2 per row chunk, so that the [M, 14336] intermediate stays in the Infinity Cache: the clock rises with the
+                    #  saved HBM traffic, but tile quantisation and launch ramps cost more: +0.5 / +1.6 / +7.1 % of a step at 2 / 4 / 7 chunks,
+                    #  profiles/r4p_ffn_row_chunks.txt)
+                    hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
+                    hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
+        def run_head():
+            H = htab[0]
+            hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=H[:, 0], scale=H[:, 1], row_index=row_index, rows_per_batch=rpb)
+            hip.gemm(hbuf, self.head_w, self.head_b, out=head)
+
+        # ---- launch plan: the blocks and the head issue the same ~420 launches on the same buffers every step (only buffer CONTENTS
+        # change), so the first step records them (hip.record: executed and appended to command lists) and every later step re-issues
+        # the lists from C (flexam_replay, csrc/replay.hip: ~1 us per launch instead of 20-30 us of Python + ctypes).  Collectives,
+        # waits and torch copies between them are host steps of the plan (hip.host_op).  The key names everything the recorded launches
+        # depend on besides buffer contents; plans live in the per-clip state (new conditioning = new plans) and hold references to every
+        # tensor whose address they carry.  Not with TeaCache (data-dependent skipping), per-layer tables or blocks called as modules.
+        use_plan = (calc and self.fused and teacache is None and not per_layer and os.environ.get("FLEXAM_REPLAY", "1") != "0")
+        self.replay_taken = False
+        if use_plan:
+            pkey = (self._ws_gen, B, lc, only_row, bool(share0), bool(sage), self.fp8, fp8_oproj, R, rows_per_batch,
+                    row_index.data_ptr() if row_index is not None else 0, tabs["blk"].data_ptr(), cd["cos"].data_ptr(),
+                    torch.cuda.current_stream().cuda_stream, os.environ.get("FLEXAM_SAGE_FUSED", "1"), os.environ.get("FLEXAM_FP8_FFN_APRIORI", "1"),
+                    sp, rank, getattr(self, "sp_mode", None), getattr(self, "sp_pieces", 1), getattr(self, "sp_overlap_level", 0),
+                    getattr(self, "sp_fused_qkv", True), id(self.sp_group))
+            plans = cd.setdefault("_plans", {})
+            plan = plans.get(pkey)
+            if plan is None:
+                with hip.record() as plan:
+                    run_blocks()
+                    run_head()
+                while len(plans) >= 6:                     # (cond / uncond rows of cfg_skip, the shared-block-0 form, ...: a handful per clip)
+                    plans.pop(next(iter(plans)))
+                plans[pkey] = plan
             else:
-                hip.ln_modulate(xres, out=hbuf, eps=self.eps, ln_w=p["n3w"], ln_b=p["n3b"])
-                hip.gemm(hbuf, p["cwq"], p["cbq"], out=qc)
-            hip.rmsnorm_rope(qc, p["cnq"], eps=self.eps)
-            kv = cd["cross_kv"][i][rsel]
-            if cd.get("cross_lk"):                          # the identical padded text rows as ONE weighted key
-                lk = cd["cross_lk"]
-                hip.attn_fwd_lastkey(q4, kv[:, :lk, 0:d].unflatten(2, (nh, hdim)), kv[:, :lk, d:].unflatten(2, (nh, hdim)), cd["cross_mult"],
-                                     out=ao4, prescaled=True)
-            else:
-                hip.attn_fwd(q4, kv[:, :, 0:d].unflatten(2, (nh, hdim)), kv[:, :, d:].unflatten(2, (nh, hdim)), out=ao4, prescaled=True)
-            if self.fp8 and fp8_oproj:
-                a8o, sao = hip.quantize_rows_fp8(ao, ws["a8d"], ws["sa"])
-                hip.gemm_fp8_gate_residual(a8o, sao, self._fp8_w[i]["cwo"], self._fp8_w[i]["s_cwo"], p["cbo"], xres)
-            else:
-                hip.gemm_gate_residual(ao, p["cwo"], p["cbo"], xres)
-            # FFN
-            if self.fp8:
-                w8 = self._fp8_w[i]
-                # FFN1 writes FFN2's e4m3 operand itself: its output row scales are known before it runs (a bound from the row's L2
-                # norm, written by the LN launch), so there is no absmax / quantise pass over the [M, 14336] intermediate
-                # (FLEXAM_FP8_FFN_APRIORI=0: the earlier form -- bf16 intermediate + an absmax row quantiser pass -- for checkpoints whose w1
-                #  has a few very large rows: the bound is set by the LARGEST row norm, so every ordinary row's outputs then sit lower in
-                #  e4m3's range.  One scale per output row has to cover all 14336 columns, so a per-tile bound cannot be used by FFN2.)
-                apriori = os.environ.get("FLEXAM_FP8_FFN_APRIORI", "1") != "0"
-                a8, sa, bound = self._ln_fp8(xres, ws, hbuf, nxt=(w8["w1_norm"], w8["b1_max"]) if apriori else None, shift=T[:, 3], scale=T[:, 4],
-                                             row_index=row_index, rows_per_batch=rpb)
-                if bound:
-                    hip.gemm_fp8_gelu_q(a8, sa, w8["w1"], w8["s_w1"], p["b1"], ws["so"], ws["a8"])
-                    a8, sa = ws["a8"], ws["so"]
-                else:                                      # widths the fused LN launch does not cover: bf16 intermediate + row quantiser
-                    hip.gemm_fp8(a8, sa, w8["w1"], w8["s_w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
-                    a8, sa = hip.quantize_rows_fp8(ffn, ws["a8"], ws["sa"])
-                hip.gemm_fp8_gate_residual(a8, sa, w8["w2"], w8["s_w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
-            else:
-                hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=T[:, 3], scale=T[:, 4], row_index=row_index, rows_per_batch=rpb)
-                # (FFN1 -> FFN2 per row chunk, so that the [M, 14336] intermediate stays in the Infinity Cache: the clock rises with the
-                #  saved HBM traffic, but tile quantisation and launch ramps cost more: +0.5 / +1.6 / +7.1 % of a step at 2 / 4 / 7 chunks,
-                #  profiles/r4p_ffn_row_chunks.txt)
-                hip.gemm(hbuf, p["w1"], p["b1"], out=ffn, epilogue=hip.EPI_GELU_TANH)
-                hip.gemm_gate_residual(ffn, p["w2"], p["b2"], xres, gate=T[:, 5], gate_row=row_index, rows_per_batch=rpb)
+                plan.run()
+                self.replay_taken = True
+            self.plan_launches = plan.launches
+        else:
+            run_blocks()
         if teacache is not None and calc:                  # residual = x_after_blocks - x_before (FX.py:1048-1051), kept on the GPU
             hip.axpby(ori, 1.0, xres, -1.0)
             setattr(teacache, key, ori)
-        # ---- head
-        H = htab[0]
-        hip.ln_modulate(xres, out=hbuf, eps=self.eps, shift=H[:, 0], scale=H[:, 1], row_index=row_index, rows_per_batch=rpb)
-        hip.gemm(hbuf, self.head_w, self.head_b, out=head)
+        if not use_plan:
+            run_head()
         return head.view(B, lc, -1)
 
     # ------------------------------------------------------------------ block-level seam
@@ -707,37 +768,39 @@ class DiTEngine:
                                      ld_out=W, out_bs=sp * lc * W, col_block=G, block_stride=lc * W, eps=self.eps, rope_cos=cd["cos"],
                                      rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
 
+        # the exchanges and their waits are host steps (hip.host_op): run here, and again at this place by every replay of a recorded
+        # launch plan; `st` carries the Work handles from the step that issues to the step that waits
+        st = {"there": [None] * B, "back": [None] * B}
+
+        def go_there(b, async_op):
+            st["there"][b] = all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group, async_op=async_op)
+
+        def go_back(b, async_op):
+            st["back"][b] = all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=async_op)
+
+        def wait(which, bs):
+            for b in bs:
+                if st[which][b] is not None:
+                    st[which][b].wait()
         if B == 1 or not self.sp_overlap:
             project_and_pack(slice(None), 0, B)
-            for b in range(B):
-                all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group)
+            hip.host_op(lambda: [go_there(b, False) for b in range(B)])
             attend(0, B)
-            for b in range(B):
-                all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group)
+            hip.host_op(lambda: [go_back(b, False) for b in range(B)])
             return recv2.view(sp * B * lc, G), ws["a2a_koff"]
-        there, back = [], []
         for b in range(B):
             project_and_pack(slice(b * lc, (b + 1) * lc), b, 1)
-            there.append(all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group, async_op=True))
+            hip.host_op(lambda b=b: go_there(b, True))
         if self.sp_overlap_level < 2:
-            for w in there:
-                if w is not None:
-                    w.wait()
+            hip.host_op(lambda: wait("there", range(B)))
             attend(0, B)
-            back = [all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True)
-                    for b in range(B)]
-            for w in back:
-                if w is not None:
-                    w.wait()
+            hip.host_op(lambda: ([go_back(b, True) for b in range(B)], wait("back", range(B))))
             return recv2.view(sp * B * lc, G), ws["a2a_koff"]
         for b in range(B):
-            if there[b] is not None:
-                there[b].wait()
+            hip.host_op(lambda b=b: wait("there", [b]))
             attend(b, 1)
-            back.append(all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=True))
-        for w in back:
-            if w is not None:
-                w.wait()
+            hip.host_op(lambda b=b: go_back(b, True))
+        hip.host_op(lambda: wait("back", range(B)))
         return recv2.view(sp * B * lc, G), ws["a2a_koff"]
 
     @staticmethod
@@ -795,7 +858,17 @@ class DiTEngine:
         # test runs (gloo) execute several in-flight collectives of one group on concurrent worker threads, which is not what is being
         # modelled (and delivered wrong chunks intermittently with 8 ranks on one device): there each gather completes before the next.
         overlapped = group_backend(self.sp_group) in ("nccl", "loopback")
-        works = [[all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=overlapped) for b in range(B)] for g in range(G)]
+        # collectives and waits are host steps (hip.host_op): run here, and again at this place by every replay of a recorded launch plan
+        st = {}
+
+        def issue():
+            st["works"] = [[all_gather_into_tensor(cat[g, b], send[g, b], group=self.sp_group, async_op=overlapped) for b in range(B)] for g in range(G)]
+
+        def wait(g):
+            for w in st["works"][g]:
+                if w is not None:
+                    w.wait()
+        hip.host_op(issue)
         if not q_done:
             self._proj(hbuf, a8sa, layer, p, "wqkv", "bqkv", slice(0, d), qkv[:, 0:d])
         hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"], tokens_per_batch=lc, token_offset=tok0,
@@ -805,18 +878,14 @@ class DiTEngine:
             qg, og = q4[:, :, g * hg:(g + 1) * hg], ao4[:, :, g * hg:(g + 1) * hg]
             kc, vc = cat[g, :, :, 0:cb], cat[g, :, :, cb:]
             if g > 0 or not self.sp_overlap:
-                for w in works[g]:
-                    if w is not None:
-                        w.wait()
+                hip.host_op(lambda g=g: wait(g))
                 hip.attn_fwd(qg, heads(kc[:, :Lr]), heads(vc[:, :Lr]), out=og, prescaled=True)
                 continue
             s_loc, s_before, s_after = ws["kv_splits"]
             n = 0
             if n_loc > 0:
                 n = hip.attn_fwd_partial(qg, heads(send[0, :, :n_loc, 0:cb]), heads(send[0, :, :n_loc, cb:]), ws["kv_part"], 0, s_loc, prescaled=True)
-            for w in works[0]:
-                if w is not None:
-                    w.wait()
+            hip.host_op(lambda: wait(0))
             if tok0 > 0:
                 n += hip.attn_fwd_partial(qg, heads(kc[:, :min(tok0, Lr)]), heads(vc[:, :min(tok0, Lr)]), ws["kv_part"], n, s_before, prescaled=True)
             if tok0 + lc < Lr:

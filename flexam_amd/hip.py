@@ -74,6 +74,10 @@ _SIGNATURES = {
     "flexam_vae_patchify_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_space_to_depth_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_avgdown_add_cl": ([_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P], c_int),
+    "flexam_fn_id": ([c_char_p], c_int),
+    "flexam_fn_count": ([], c_int),
+    "flexam_fn_name": ([_I], c_char_p),
+    "flexam_replay": ([_P, _L, _P, _P], c_int),
 }
 
 _lib = None
@@ -98,8 +102,145 @@ def load_library(path: str = None) -> ctypes.CDLL:
     return lib
 
 
-def lib() -> ctypes.CDLL:
+def lib():
+    """The library -- or, while a command list is being recorded (`record()`), the recorder in front of it."""
+    if _rec is not None:
+        return _rec
     return _lib if _lib is not None else load_library()
+
+
+# ----------------------------------------------------------------------------- command lists (csrc/replay.hip)
+REPLAY_MAX_ARGS = 26
+
+
+class _Arg(ctypes.Union):
+    _fields_ = [("i", c_int64), ("f", ctypes.c_double), ("p", c_void_p)]
+
+
+class _Cmd(ctypes.Structure):
+    _fields_ = [("fn", ctypes.c_int32), ("nargs", ctypes.c_int32), ("a", _Arg * REPLAY_MAX_ARGS)]
+
+
+# entry points that read HOST arrays during the call (flexam_hip.h): a recorded pointer to a temporary host array would dangle
+_NOT_RECORDABLE = ("flexam_lincomb_f32",)
+_rec = None              # the active _Recorder (one at a time, per process: recording happens on the thread that drives the engine)
+_FN_IDS = {}
+
+
+def _fn_id(name: str) -> int:
+    if name not in _FN_IDS:
+        real = _lib if _lib is not None else load_library()
+        _FN_IDS[name] = int(real.flexam_fn_id(name.encode()))
+    return _FN_IDS[name]
+
+
+class Plan:
+    """A recorded stretch of the engine's work: C segments (arrays of flexam_cmd, each re-issued by ONE flexam_replay call) interleaved
+    with host operations (Python callables: collectives, waits, torch copies -- whatever the engine wrapped in `host_op`).  `keep` holds
+    every tensor whose pointer sits in a command, so no recorded address can be handed to anybody else while the plan lives."""
+
+    def __init__(self):
+        self.items, self.keep, self.launches = [], [], 0
+
+    def run(self):
+        real = _lib if _lib is not None else load_library()
+        st = _stream()
+        failed = c_int64(-1)
+        for kind, a, b in self.items:
+            if kind == "c":
+                rc = real.flexam_replay(a, b, ctypes.byref(failed), st)
+                if rc != 0:
+                    name = real.flexam_fn_name(a[failed.value].fn) if failed.value >= 0 else b"?"
+                    raise RuntimeError(f"flexam_replay: command {failed.value} ({(name or b'?').decode()}) failed with code {rc}: "
+                                       f"{real.flexam_last_error().decode()}")
+            else:
+                a()
+
+
+class _Recorder:
+    """Stands in for the library while a plan is recorded: every stream-ordered entry point is CALLED (the recording step is a real
+    step) and appended to the open C segment as (function id, argument words); anything else (queries, flexam_last_error) passes
+    through.  The stream argument is not recorded: a replay runs on the stream it is issued on."""
+
+    def __init__(self, plan: Plan):
+        self.plan, self.seg = plan, []
+        self._wrapped = {}
+
+    def __getattr__(self, name):
+        real = _lib if _lib is not None else load_library()
+        fn = getattr(real, name)
+        fid = _fn_id(name) if name.startswith("flexam_") and name not in ("flexam_fn_id", "flexam_fn_name", "flexam_fn_count", "flexam_replay") else -1
+        if fid < 0:
+            return fn
+        if name in _NOT_RECORDABLE:
+            raise RuntimeError(f"{name} takes host arrays and cannot be part of a recorded launch plan")
+        w = self._wrapped.get(name)
+        if w is None:
+            kinds = _SIGNATURES[name][0][:-1]
+
+            def w(*args, _fn=fn, _fid=fid, _kinds=kinds, _name=name):
+                rc = _fn(*args)
+                if rc == 0:
+                    if len(args) != len(_kinds) + 1:
+                        raise RuntimeError(f"{_name}: {len(args)} arguments recorded, the signature has {len(_kinds) + 1}")
+                    self.seg.append((_fid, _kinds, args[:-1]))
+                return rc
+            self._wrapped[name] = w
+        return w
+
+    def flush(self):
+        if not self.seg:
+            return
+        arr = (_Cmd * len(self.seg))()
+        for c, (fid, kinds, args) in zip(arr, self.seg):
+            c.fn, c.nargs = fid, len(args)
+            for j, (k, v) in enumerate(zip(kinds, args)):
+                if k is _P:
+                    c.a[j].p = v
+                elif k is _F:
+                    c.a[j].f = float(v)
+                else:
+                    c.a[j].i = int(v)
+        self.plan.items.append(("c", arr, len(self.seg)))
+        self.plan.launches += len(self.seg)
+        self.seg = []
+
+
+class record:
+    """`with hip.record() as plan:` -- everything the block of code launches through this module is executed AND recorded into `plan`
+    (Plan.run() re-issues it).  Valid for code whose launches depend only on things that do not change between runs: buffer addresses,
+    shapes, scalars (the caller's business: DiTEngine keys its plans on all of them).  Host-side work in between goes through
+    `host_op`."""
+
+    def __init__(self):
+        self.plan = Plan()
+
+    def __enter__(self):
+        global _rec
+        if _rec is not None:
+            raise RuntimeError("flexam_amd.hip.record: already recording")
+        _rec = _Recorder(self.plan)
+        return self.plan
+
+    def __exit__(self, et, ev, tb):
+        global _rec
+        rec, _rec = _rec, None
+        if et is None:
+            rec.flush()
+        return False
+
+
+def host_op(fn):
+    """Runs `fn()` now; while a plan is recorded it also closes the open C segment and becomes a host step of the plan (run again, in
+    this place, by every Plan.run()).  For what is not a call into the library: collectives, Work.wait(), torch copies."""
+    if _rec is not None:
+        _rec.flush()
+        _rec.plan.items.append(("py", fn, None))
+    return fn()
+
+
+def recording() -> bool:
+    return _rec is not None
 
 
 def _check(rc: int, what: str):
@@ -119,6 +260,15 @@ def _ptr(t, dtype=None):
         raise RuntimeError("flexam_amd.hip: tensor is not on a GPU (there is no CPU path)")
     if dtype is not None and t.dtype != dtype:
         raise RuntimeError(f"flexam_amd.hip: expected {dtype}, got {t.dtype}")
+    if _rec is not None:
+        _rec.plan.keep.append(t)                   # a recorded address stays this tensor's for as long as the plan lives
+    return t.data_ptr()
+
+
+def _raw(t):
+    """data_ptr() of scratch the wrappers pass without a dtype check (workspaces, byte images); kept alive by a plan being recorded."""
+    if _rec is not None:
+        _rec.plan.keep.append(t)
     return t.data_ptr()
 
 
@@ -185,7 +335,7 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, out_dtype=BF16, a_koff=No
     st = _stream()
     ws = _gemm_workspace(a.device, st)
     _check(lib().flexam_gemm_bf16(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(out), ldc, M, wn, K, epilogue,
-                                  1 if out.dtype == F32 else 0, _ptr(a_koff, I64), ws.data_ptr(), ws.numel(), st), "flexam_gemm_bf16")
+                                  1 if out.dtype == F32 else 0, _ptr(a_koff, I64), _raw(ws), ws.numel(), st), "flexam_gemm_bf16")
     return out
 
 
@@ -202,7 +352,7 @@ def gemm_gate_residual(a, w, bias, x, gate=None, gate_row=None, rows_per_batch=0
     ws = _gemm_workspace(a.device, st)
     _check(lib().flexam_gemm_bf16_gate_residual(_ptr(a, BF16), lda, _ptr(w, BF16), ldw, _ptr(bias, F32), _ptr(x, F32), ldx,
                                                 _ptr(gate, F32), gate_ld, _ptr(gate_row, I32), rows_per_batch, M, N, K,
-                                                _ptr(a_koff, I64), ws.data_ptr(), ws.numel(), st), "flexam_gemm_bf16_gate_residual")
+                                                _ptr(a_koff, I64), _raw(ws), ws.numel(), st), "flexam_gemm_bf16_gate_residual")
     return x
 
 
@@ -430,7 +580,7 @@ def attn_fp8_pack(q, k, v, bufs=None):
     q8, qs, kv8 = bufs
     qk = (lambda t: (t.stride(0), t.stride(1))) if q is not None else (lambda t: (0, 0))
     _check(lib().flexam_attn_fp8_pack(_ptr(q, BF16), *qk(q), _ptr(k, BF16), *qk(k), _ptr(v, BF16),
-                                      v.stride(0), v.stride(1), q8.data_ptr(), qs.data_ptr(), kv8.data_ptr(), B, H, L, D, _stream()),
+                                      v.stride(0), v.stride(1), _raw(q8), _raw(qs), _raw(kv8), B, H, L, D, _stream()),
            "flexam_attn_fp8_pack")
     return bufs
 
@@ -443,8 +593,8 @@ def rmsnorm_rope_mx(q, wq, k, wk, bufs, rope_cos, rope_sin, tokens_per_batch, to
         raise RuntimeError(f"rmsnorm_rope_mx: {M} rows of {C} columns do not tile batches of {tokens_per_batch} tokens x {heads} heads x 128")
     _check_fp8_bufs(bufs, M // tokens_per_batch, heads, tokens_per_batch, q.device, "rmsnorm_rope_mx")
     q8, qs, kv8 = bufs
-    _check(lib().flexam_rmsnorm_rope_mx(_ptr(q, BF16), ldq, _ptr(wq, F32), _ptr(k, BF16), k.stride(0), _ptr(wk, F32), q8.data_ptr(),
-                                        qs.data_ptr(), kv8.data_ptr(), M, C, eps, _ptr(rope_cos, F32), _ptr(rope_sin, F32),
+    _check(lib().flexam_rmsnorm_rope_mx(_ptr(q, BF16), ldq, _ptr(wq, F32), _ptr(k, BF16), k.stride(0), _ptr(wk, F32), _raw(q8),
+                                        _raw(qs), _raw(kv8), M, C, eps, _ptr(rope_cos, F32), _ptr(rope_sin, F32),
                                         tokens_per_batch, token_offset, heads, 128, _stream()), "flexam_rmsnorm_rope_mx")
     return bufs
 
@@ -473,7 +623,7 @@ def attn_fwd_fp8(bufs, L, out=None, kv_splits=None, split_from_unit=None):
             _ws_slot(_ATTN_WS, slot, lambda: (key, torch.empty(S, n, 256, D, device=q8.device, dtype=F32),
                                               torch.empty(S, n, 256, 2, device=q8.device, dtype=F32)))
         _, ws_o, ws_ml = _ws_slot(_ATTN_WS, slot, None)
-    _check(lib().flexam_attn_fwd_fp8(q8.data_ptr(), qs.data_ptr(), kv8.data_ptr(), _ptr(out, BF16), out.stride(0), out.stride(1), B, H, L, D,
+    _check(lib().flexam_attn_fwd_fp8(_raw(q8), _raw(qs), _raw(kv8), _ptr(out, BF16), out.stride(0), out.stride(1), B, H, L, D,
                                      max(S, 1), from_unit if S > 1 else 0, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()), "flexam_attn_fwd_fp8")
     return out
 

@@ -358,6 +358,22 @@ int flexam_raster_keys(const float* points, const unsigned char* visible, int T,
 int flexam_raster_resolve(const unsigned long long* keys, const unsigned char* colors, int64_t color_frame_stride, int N, int T, int H, int W,
                           unsigned char* out_u8, float* out_f32, void* stream);
 
+/* Command lists: a recorded sequence of this library's stream-ordered calls re-issued from ONE call (csrc/replay.hip).  The reference
+ * has no counterpart -- its step loop is Python over PyTorch ops (pipeline_wan2_2_fun_control_FlexAM.py:844-949, one Python frame per
+ * nn.Module call of wan_transformer3d_FlexAM.py:1053-1089); this is what replaces that per-op host cost when one rank of eight has
+ * ~40 ms per step for ~450 launches.  A command = the id of an entry point of THIS header whose last parameter is `void* stream`
+ * (flexam_fn_id(name); ids are positions in the header, never hard-coded) + its arguments without the stream as 8-byte words in
+ * declaration order: pointers -> p, float -> f (as double), integers -> i.  flexam_replay calls them in order on `stream`; every call
+ * checks its own arguments as usual; it stops at the first failure (its code returned, its message in flexam_last_error(),
+ * *failed_at = index; -1 = none).  The list is HOST memory of the caller, read during the call only. */
+#define FLEXAM_REPLAY_MAX_ARGS 26
+typedef union { int64_t i; double f; void* p; } flexam_arg;
+typedef struct { int32_t fn; int32_t nargs; flexam_arg a[FLEXAM_REPLAY_MAX_ARGS]; } flexam_cmd;
+int flexam_fn_id(const char* name);            /* -1: not a replayable entry point */
+int flexam_fn_count(void);
+const char* flexam_fn_name(int id);
+int flexam_replay(const flexam_cmd* cmds, int64_t n, int64_t* failed_at, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,7 +57,7 @@ def test_bench_spawns_its_own_ranks_and_validates_the_exchange(world, env):
 def test_launcher_falls_back_to_the_conservative_exchange_when_the_check_fails():
     """A failed self-check of the first attempt (forced here) must cost one more attempt with FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0,
     not the measurement: the forwarded line is the second attempt's, says so, and keeps the first attempt's verdict."""
-    r = _run(["--gpus", "4", *SMALL], {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_TEST_HOOKS": "1", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1", "FLEXAM_BENCH_LAYOUT_FORCE": "0"})
+    r = _run(["--gpus", "4", *SMALL], {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_TEST_HOOKS": "1", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1", "FLEXAM_BENCH_LAYOUT_FORCE": "1"})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -87,7 +87,7 @@ def _torchrun(world, args, env_extra, timeout=900):
 def test_ranks_started_by_torchrun_remeasure_on_the_conservative_exchange_when_the_check_fails():
     """Under the caller's own torch.distributed.run there is no parent to start a second attempt: a failed self-check (forced) makes the
     SAME processes switch to FLEXAM_SP_PIECES=1 FLEXAM_SP_OVERLAP=0, measure again and check again; the line keeps the first verdict."""
-    r = _torchrun(4, SMALL, {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_TEST_HOOKS": "1", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1", "FLEXAM_BENCH_LAYOUT_FORCE": "0"})
+    r = _torchrun(4, SMALL, {"FLEXAM_BENCH_ONE_DEVICE": "1", "FLEXAM_BENCH_BACKEND": "gloo", "FLEXAM_BENCH_TEST_HOOKS": "1", "FLEXAM_BENCH_FORCE_CHECK_FAIL": "1", "FLEXAM_BENCH_LAYOUT_FORCE": "1"})
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1

@@ -414,6 +414,12 @@ def test_configs4_fp8_three_layers_at_the_704x1280_latent(variant, monkeypatch):
     finally:
         m.enable_fp8_gemm(False)                           # the model is shared with the other cases
     if variant == "fp8":
+        _CACHE["three_layer_fwd_22880_fp8"] = out.float().cpu()
         stats(out, want, "three-layer 5B-width model, L = 22880 (704 x 1280), fp8 QKV / FFN", rel_max=3e-2, psnr_min=40.0)
     else:
+        f8 = _CACHE.get("three_layer_fwd_22880_fp8")
+        if f8 is not None:                                 # the quantised attention kernel really ran: another result than fp8 GEMMs alone
+            d = (out.float().cpu() - f8).pow(2).mean().sqrt() / f8.pow(2).mean().sqrt()
+            print(f"fp8 + MXFP8 self-attention vs fp8 alone: rel-rms {d:.3e}")
+            assert d > 1e-5
         stats(out, want, "three-layer 5B-width model, L = 22880 (704 x 1280), fp8 QKV / FFN + MXFP8 self-attention", rel_max=4e-2, psnr_min=38.0)

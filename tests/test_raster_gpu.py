@@ -168,7 +168,9 @@ def test_raster_argument_errors():
         H.raster_keys(pts, torch.ones(2, 4, dtype=torch.uint8, device=DEV), 8, 8, 2)
     with pytest.raises(RuntimeError):
         H.raster_resolve(H.raster_keys(pts, None, 8, 8, 2), torch.zeros(5, 4, dtype=torch.uint8, device=DEV))
-    keys5 = H.raster_keys(pts, None, 8, 8, 2)
+    spread = pts.clone()
+    spread[:, :, 0] = torch.arange(5, device=DEV, dtype=torch.float32)           # x = 0 .. 4, equal depths: pixel column 6 shows point 4 only
+    keys5 = H.raster_keys(spread, None, 8, 8, 2)
     with pytest.raises(RuntimeError, match="index 5 points"):                     # a colour table of another point count (round-5 advice)
         H.raster_resolve(keys5, torch.zeros(4, 3, dtype=torch.uint8, device=DEV))
     with pytest.raises(RuntimeError, match="index 5 points"):
@@ -178,7 +180,9 @@ def test_raster_argument_errors():
     u8, _ = H.raster_resolve(anon, torch.full((3, 3), 200, dtype=torch.uint8, device=DEV), want_u8=True, want_f32=False)
     drawn = (keys5 != -1)
     idx = (keys5 & 0xFFFFFFFF)
-    assert bool(drawn.any()) and torch.equal(u8[..., 0] == 200, drawn & (idx < 3)) and int(u8[drawn & (idx >= 3)].max(initial=0)) == 0
+    past = drawn & (idx >= 3)
+    assert bool(past.any()) and bool((drawn & (idx < 3)).any())
+    assert torch.equal(u8[..., 0] == 200, drawn & (idx < 3)) and int(u8[past].max()) == 0
     with pytest.raises(RuntimeError, match="y_min"):
         H.raster_keys(pts, None, 8, 8, 2, y_min=2)                    # the C ABI's own check (FLEXAM_E_SHAPE + message)
     with pytest.raises(RuntimeError, match="half"):

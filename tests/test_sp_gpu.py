@@ -83,7 +83,7 @@ def set_mode_env(mode):
         os.environ["FLEXAM_SP_OVERLAP"] = mode.split("-ov")[1][0]
     else:
         os.environ["FLEXAM_SP_OVERLAP"] = "0" if "-wait" in mode else "1"
-    os.environ["FLEXAM_SP_PIECES"] = "1" if "-p1" in mode else "2"
+    os.environ["FLEXAM_SP_PIECES"] = "1" if ("-p1" in mode or mode.startswith("ulysses")) else "2"     # (head-group pieces belong to the K|V gather)
     os.environ["FLEXAM_SP_FUSED_QKV"] = "0" if "-splitqkv" in mode else "1"       # r4 form: K|V projection, gather start, then the Q projection
     if "-sage" in mode:
         os.environ["VIDEOX_ATTENTION_TYPE"] = "SAGE_ATTENTION"

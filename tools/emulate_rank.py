@@ -19,8 +19,10 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 cfg = dict(WAN22_FUN_5B_FLEXAM)
 model = build_model(cfg, dev)
-name, mode, cfgp, pieces = layouts(world, model.num_heads)[which]
+name, mode, cfgp, pieces, overlap = layouts(world, model.num_heads)[which]
 os.environ["FLEXAM_SP_MODE"] = mode
+if overlap is not None:
+    os.environ["FLEXAM_SP_OVERLAP"] = str(overlap)
 sp = world // 2 if cfgp else world
 rank = int(os.environ.get("FLEXAM_EMULATE_WHICH", sp // 2 if sp > 2 else 0))
 set_emulated_layout(model, world, cfgp, rank)
@@ -39,5 +41,5 @@ t_enq = time.perf_counter() - t0
 torch.cuda.synchronize()
 sec = (time.perf_counter() - t0) / steps
 eng = model.engine()
-print(f"{name}: rank {rank} of sp{eng.sp_size} (cfg{eng.cfg_size}), {eng.cond['L'] // eng.sp_size} tokens x {1 if eng.cfg_size == 2 else 2} sample(s): "
+print(f"{name} [replayed launches: {bool(getattr(eng, 'replay_taken', False))}]: rank {rank} of sp{eng.sp_size} (cfg{eng.cfg_size}), {eng.cond['L'] // eng.sp_size} tokens x {1 if eng.cfg_size == 2 else 2} sample(s): "
       f"{sec * 1e3:.2f} ms per step, host enqueue {t_enq / steps * 1e3:.2f} ms")
