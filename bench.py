@@ -355,6 +355,11 @@ def main():
             from benchlib.emulate import HOST_NOTE
             result["emulated_ranks"] = {"world": n_emulate, "layouts": emulated, "host_enqueue_note": HOST_NOTE,
                                         "predicted_scaling_no_comm": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step"], 3) for r in emulated if "ms_per_step" in r},
+                                        "predicted_scaling_compute_only": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step_compute_only"], 3)
+                                                                           for r in emulated if "ms_per_step_compute_only" in r},
+                                        "compute_only_note": "the same rank step with collectives that move nothing (stream plumbing only): predicted_scaling_no_comm keeps "
+                                                             "the same-size device copies as a stand-in for the bytes a rank receives; where a gather is waited for, "
+                                                             "those copies sit in front of the attention call and are counted as if they were compute",
                                         "what": "ONE process ran one rank's share of an N-GPU step per layout at full size: the real engine on that rank's token chunk / "
                                                 "CFG row with every launch, piece, partial attention and merge of the multi-GPU path, collectives replaced by device "
                                                 "copies of the same sizes on a side stream (flexam_amd.dist.LoopbackGroup).  predicted_scaling_no_comm = this run's "

@@ -58,14 +58,14 @@ def layouts(world: int, num_heads: int):
     return out
 
 
-def set_emulated_layout(model, world: int, cfg_parallel: bool, rank: int):
+def set_emulated_layout(model, world: int, cfg_parallel: bool, rank: int, copies: bool = True):
     from flexam_amd.dist import LoopbackGroup
     if cfg_parallel:
         sp = world // 2
-        par = dict(sp_group=LoopbackGroup(sp, rank % sp) if sp > 1 else None, sp_rank=rank % sp, sp_size=sp, world_group=LoopbackGroup(world, rank),
-                   world_size=world, cfg_size=2, cfg_row=rank // sp)
+        par = dict(sp_group=LoopbackGroup(sp, rank % sp, copies) if sp > 1 else None, sp_rank=rank % sp, sp_size=sp,
+                   world_group=LoopbackGroup(world, rank, copies), world_size=world, cfg_size=2, cfg_row=rank // sp)
     else:
-        g = LoopbackGroup(world, rank)
+        g = LoopbackGroup(world, rank, copies)
         par = dict(sp_group=g, sp_rank=rank, sp_size=world, world_group=g, world_size=world)
     model._parallel = par
     model._engine = None                                   # rebuilt for the layout on its next use (reads the FLEXAM_SP_* switches)
@@ -96,6 +96,15 @@ def emulate(model, make_pipe, inp, cond, world: int, steps: int, warmup: int, to
                          "samples_per_rank": 1 if eng.cfg_size == 2 else 2, "pieces": getattr(eng, "sp_pieces", 1), "ms_per_step": m["sec"] * 1e3,
                          "host_enqueue_ms_per_step": m["host_sec"] * 1e3, "host_share_of_step": m["host_sec"] / m["sec"],
                          "replayed_launches": bool(getattr(eng, "replay_taken", False))})
+            del pipe
+            # the same rank step with the collectives moving NOTHING (stream plumbing only): what the stand-in copies themselves cost in
+            # the figure above -- a gather that is waited for sits in front of its attention call for as long as 107 MB of device copies
+            # take (~45 us per block), an exchange that is hidden does not
+            set_emulated_layout(model, world, cfgp, r, copies=False)
+            pipe = make_pipe()
+            pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+            m0 = measure_rank_step(lambda i: pipe.denoise_step(i % total_steps), torch.cuda.synchronize, min(steps, 6), min(warmup, 2))
+            rows[-1]["ms_per_step_compute_only"] = m0["sec"] * 1e3
             del pipe
     finally:
         for k, v in saved.items():

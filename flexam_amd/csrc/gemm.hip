@@ -24,6 +24,7 @@
 //  * workgroup -> tile map is XCD-aware: the 8 XCDs (private 4 MiB L2 each) get contiguous
 //    chunks of the tile list, walked in groups of 4 tile-rows so concurrently resident tiles
 //    share A row-panels and W column-panels in L2 (FLEXAM_GEMM_GM overrides the group height).
+#include <math.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -98,8 +99,16 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 // 80-column wave rows do not fit the 128-byte LDS turn-around).
 template <int EPI, typename OutT, int MT, bool TAIL = false, int WMW = 2, int NTW = 4>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const int64_t* __restrict__ a_koff) {
-  static_assert((WMW == 2 && NTW == 4) || (WMW == 4 && NTW == 5 && MT <= 4), "supported wave layouts: 2 x 4 x 4 n-tiles, 4 x 2 x 5 n-tiles");
-  constexpr bool STD = WMW == 2 && NTW == 4;   // the 256-wide shape with LDS-staged epilogues
+  static_assert((WMW == 2 && (NTW == 4 || NTW == 3)) || (WMW == 4 && NTW == 5 && MT <= 6),
+                "supported wave layouts: 2 x 4 waves x 4 or 3 n-tiles, 4 x 2 waves x 5 n-tiles");
+  // STD: the LDS-staged epilogues (a wave's row of 16 NTW bf16 outputs turned around through a 128-byte LDS row).  NTW = 4: the 256-wide
+  // tile of the DiT shapes.  NTW = 3 (r6): a 192-wide tile, (32 MT) x 192 -- with MT = 6 a 192 x 192 tile, 16 x 16 = 256 of which cover
+  // a rank-of-eight's 2912 x 3072 outputs in ONE full round of the CUs (94.8 % useful) where 160 x 256 tiles are 228 tiles at 89 % fill:
+  // 10 % less matrix work per CU on the N = 3072 launches of a rank's block (o-proj, cross-o, cross-q, FFN2).  Its wave rows are 48
+  // columns = 96 bytes = 6 of the 8 sixteen-byte slots of a staging row; lanes that would carry slots 6, 7 (bf16 store: lane % 8 >= 6;
+  // fp32 read-modify-write: lane % 16 >= 12) load a neighbour's address again and store nothing.
+  constexpr bool STD = WMW == 2 && (NTW == 4 || NTW == 3);
+  constexpr int CW = 16 * NTW;                 // columns per wave
   constexpr int WNW = 8 / WMW;              // waves along N
   constexpr int BN_ = WNW * NTW * 16;       // columns of this tile shape
   constexpr int RT = 16;                    // rows per row tile
@@ -111,6 +120,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   constexpr int PA = (BM_ + 63) / 64;       // 64-row staging pieces per thread for A
   constexpr int PW = (BN_ + 63) / 64;       // ... and for W
   constexpr int NP = PA + PW;               // LDS-DMA pieces per thread per K block
+  // LDS image of one K block: [A tile | W tile].  Tiles of up to 256 rows keep the 32 KiB + 32 KiB form; the 384 x 160 shape (r6: 4 x 2
+  // waves of 96 x 80 outputs, 30 MFMAs per 11 fragment reads instead of 20 per 9 on the 256 x 160 tile -- the VAE encoder's 160-channel
+  // 3x3x3 convolutions over millions of rows) holds 48 KiB of A and three 8 KiB pieces of W per buffer; it has no LDS-staged epilogue.
+  constexpr int A_BYTES = BM_ > 256 ? BM_ * 128 : TILE_BYTES;
+  constexpr int BUF_BYTES = BM_ > 256 ? A_BYTES + PW * 8192 : 2 * TILE_BYTES;
+  static_assert(BM_ <= 256 || !(WMW == 2), "tall tiles: the 160-wide shape only");
   constexpr int NF = NTW + MT;              // fragments per 32-deep K half
   // a_koff: optional [K/BK] element offsets added to every A row base per K block (implicit conv)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile], then [8 waves][STG_WAVE] of epilogue staging
@@ -160,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   auto stage_setup = [&](int m0, int n0) {
     const int ts = (wave << 6) | fresh_lane();          // thread id, rebuilt (see fresh_lane)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (PA > PW ? PA : PW); ++i) {
       const int row = i * 64 + (ts >> 3);
       const int chunk = (ts & 7) ^ ((row >> 1) & 7);
       if (i < PA) a_off[i] = (uint32_t)(((int64_t)min(row, p.M - 1 - m0) * p.lda + chunk * 8) * 2);   // edge tiles re-read their last row
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   auto dma = [&](int i, int64_t ka, int64_t kw, char* buf) {
     const char* sbase = i < PA ? a_tile + ka * 2 : w_tile + kw * 2;
     const uint32_t voff = i < PA ? a_off[i] : w_off[i - PA];
-    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * 8192 : TILE_BYTES + (i - PA) * 8192) + wave * 1024;
+    const uint32_t dst = (uint32_t)(uintptr_t)LDS_PTR(buf) + (i < PA ? i * 8192 : A_BYTES + (i - PA) * 8192) + wave * 1024;
     if (ABLATE(p, 4) || (ABLATE(p, 16) && i >= PA)) return;      // 16: no W-tile staging (half the LDS-DMA)
     // M0 (the LDS base of the DMA) is written and NOT restored: nothing else in this kernel uses it (gfx9+ LDS instructions do not;
     // tools/isa_loopwaits.py lists any other M0 reader of the listing), and the save / restore pair was 2 of the 6 scalar
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // fragment j (< NF = MT + NTW) of the set of K half hf: j < NTW -> W n-tile j, else A m-tile j - NTW, all 32 deep
   auto frag = [&](const char* buf, int hf, int j) -> bf16x8 {
     const int fo = frag_off[hf];
-    return j < NTW ? *(const bf16x8*)(buf + TILE_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
+    return j < NTW ? *(const bf16x8*)(buf + A_BYTES + wn * (16 * NTW * 128) + j * 2048 + fo)
                    : *(const bf16x8*)(buf + wm * (16 * MT * 128) + (j - NTW) * 2048 + fo);
   };
   // fragments 2g, 2g+1 of a set
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     if (nkl > 1) {
       const int64_t k1 = kcol_a(kb0 + 1);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(kb0 + 1) * BK, smem + 2 * TILE_BYTES);
+      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(kb0 + 1) * BK, smem + BUF_BYTES);
     }
   }
   int64_t kcol_next = kcol_a(kb0 + 2);    // A offset of the K block staged next, fetched one step ahead
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // compiler's own wait for that reload must land here and not in the loop, where a vmcnt(0) would drain the LDS-DMA pipeline
   // on every K block.
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < (PA > PW ? PA : PW); ++i) {
     if (i < PA) asm volatile("" : "+v"(a_off[i]));
     if (i < PW) asm volatile("" : "+v"(w_off[i]));
   }
@@ -339,8 +354,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
 
   auto block = [&](int kb, auto dma_c, auto rd_c, auto wait_c) {
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
-    char* cur = smem + (kb & 1) * (2 * TILE_BYTES);
-    char* nxt = smem + ((kb + 1) & 1) * (2 * TILE_BYTES);
+    char* cur = smem + (kb & 1) * BUF_BYTES;
+    char* nxt = smem + ((kb + 1) & 1) * BUF_BYTES;
     const int64_t kw = (int64_t)(kb0 + kb + 2) * BK;
 #pragma unroll
     for (int g = 0; g < MT; ++g) {                      // phase A
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     if (nnkl > 1) {
       const int64_t k1 = kcol_a(nkb0 + 1);
 #pragma unroll
-      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(nkb0 + 1) * BK, smem + 2 * TILE_BYTES);
+      for (int i = 0; i < NP; ++i) dma(i, k1, (int64_t)(nkb0 + 1) * BK, smem + BUF_BYTES);
     }
   }
 
@@ -446,7 +461,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     // the loads of 32 rows in flight together.  (LDS serves a wave's operations in order: no wait between the y writes and
     // the reads behind them.)
     if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
-      const int rr = le >> 4, cc = le & 15;            // row inside a group of 4, 16-byte piece of the 256-byte row
+      const int rr = le >> 4, cc_ = le & 15;           // row inside a group of 4, 16-byte piece of the wave's fp32 row (CW / 4 pieces)
+      const bool live = cc_ < CW / 4;                  // (192-wide tiles: pieces 12..15 do not exist; their lanes shadow piece 11 and store nothing)
+      const int cc = live ? cc_ : CW / 4 - 1;
       const int mw = m0 + wm * (16 * MT);
       const int nw = n0 + wn * (16 * NTW) + cc * 4;
       // X addresses = uniform 64-bit row base (scalar registers) + ONE 32-bit per-lane offset: eight 64-bit per-lane pointers
@@ -520,7 +537,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
               f32x4 x = xb[idx];
 #pragma unroll
               for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[idx][j] : bf2f(y[j]);
-              __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane));
+              if (NTW == 4 || live) __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane));
             }
           }
         };
@@ -551,7 +568,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     // instruction.  The wave turns its 16*MT x 64 outputs around in its LDS slice instead, one row tile at a time, and stores
     // whole 128-byte rows, 8 per instruction.
     if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
-      const int rd_row = le >> 3, rd_c = le & 7;
+      const int rd_row = le >> 3, rd_c_ = le & 7;
+      const bool live = rd_c_ < CW / 8;                // (192-wide tiles: 6 sixteen-byte pieces per wave row)
+      const int rd_c = live ? rd_c_ : CW / 8 - 1;
       bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
 #pragma unroll
       for (int t = 0; t < NRT; ++t) {
@@ -573,8 +592,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
           const bf16x8 o8 = *(const bf16x8*)(stg + row * 128 + ((rd_c ^ (row & 7)) << 4));
           // the GELU output (FFN1: 668 MB, read once by FFN2 from its start, when the Infinity Cache holds only its end) leaves non-temporally
           // as well (a further -0.2 ... -0.4 %); the plain outputs (QKV, cross-q) are re-read at once by the next launch and stay cached
-          if constexpr (EPI == EPI_GELU) __builtin_nontemporal_store(o8, (bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc));
-          else *(bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc) = o8;
+          if (NTW == 4 || live) {
+            if constexpr (EPI == EPI_GELU) __builtin_nontemporal_store(o8, (bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc));
+            else *(bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc) = o8;
+          }
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));   // see the gate-residual path
@@ -587,7 +608,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     // The X (and gate) loads of a whole row tile are issued together and one row tile ahead of the stores.  (Written as one load,
     // add, store per 16-byte unit, hipcc kept that order -- it cannot prove the units of different rows apart -- and put a
     // vmcnt(0) in front of every store: NRT * NV serial HBM round trips per tile, each also waiting for the store before it.)
-    constexpr int DEPTH = STD ? 1 : 2;                 // the 256-wide instances have no registers to spare next to 128 accumulators
+    constexpr int DEPTH = (STD || BM_ > 320) ? 1 : 2;  // the 256-wide instances have no registers to spare next to 128 accumulators, the 384 x 160 one next to 120
     auto rmw_rows = [&](auto gate_c) {
       constexpr bool GATE = decltype(gate_c)::value;
       f32x4 xq[DEPTH][NV], gq[DEPTH][NV];
@@ -771,7 +792,10 @@ template <int EPI, typename OutT, int MT, int WMW = 2, int NTW = 4>
 int launch_shape(GemmParams p, const GemmWorkspace& g_ws, const int64_t* a_koff, hipStream_t s) {
   auto kern = gemm_bf16_kernel<EPI, OutT, MT, false, WMW, NTW>;
   static bool attr_set[FLEXAM_MAX_DEVICES] = {};          // per device: the attribute belongs to the device's copy of the code object
-  const int smem = 4 * TILE_BYTES + 8 * 16 * 128 + 2 * 8 * 256 + 2 * 8 * 512;   // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots + two gate-row slots per wave
+  // two K-block buffers (128 KiB) + one row tile of bf16 outputs per wave + two bias slots + two gate-row slots per wave; the tall
+  // 160-wide shape: two buffers of [384 rows of A | 3 pieces of W] (144 KiB), no staging
+  const int smem = WMW * 16 * MT > 256 ? 2 * (WMW * 16 * MT * 128 + ((8 / WMW) * NTW * 16 + 63) / 64 * 8192)
+                                       : 4 * TILE_BYTES + 8 * 16 * 128 + 2 * 8 * 256 + 2 * 8 * 512;
   const int dev = flexam_current_device();
   if (!attr_set[dev]) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -870,7 +894,42 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
     const int mode = e ? atoi(e) : 1;
     const bool narrow = p.N <= 160;                      // one 160-wide tile column instead of a 256-wide one (VAE head convs: 12 / 96 channels)
     const bool mult160 = p.N % 160 == 0 && p.N % 256 != 0 && (p.N <= 480 || mode == 2);
-    if (mode && (narrow || mult160)) return launch_shape<EPI, OutT, 4, 4, 5>(p, g_ws, a_koff, s);
+    if (mode && (narrow || mult160)) {
+      // 384-row tiles where the rows fill many rounds of the CUs (the encoder's 160-channel convolutions: millions of rows): a third
+      // more MFMAs per fragment read and per staged byte; FLEXAM_GEMM_N160_TALL=0 keeps 256 rows (A/B)
+      static const int tall = [] { const char* t = getenv("FLEXAM_GEMM_N160_TALL"); return t ? atoi(t) : 1; }();
+      const long tiles_tall = (long)((p.M + 383) / 384) * ((p.N + 159) / 160);
+      // (the read-modify-write epilogue next to 120 accumulators spills: that instance runs 320-row tiles, 100 accumulators)
+      if (tall && tiles_tall >= 4L * num_cus()) return launch_shape<EPI, OutT, EPI == EPI_GATE_RESIDUAL ? 5 : 6, 4, 5>(p, g_ws, a_koff, s);
+      return launch_shape<EPI, OutT, 4, 4, 5>(p, g_ws, a_koff, s);
+    }
+  }
+  // 192 x 192 tiles (MT = 6, 3 n-tiles per wave) where their rounds of the CUs beat the best 256-wide plan: output widths that are
+  // multiples of 192 at row counts where 256-wide tiles quantise badly -- a rank-of-eight's 2912 x 3072 launches are exactly 16 x 16 =
+  // 256 tiles (one full round, 94.8 % useful) against 228 tiles of 160 x 256.  Relative cost of a 192 x 192 tile: 18 of the 256-wide
+  // MT = 6 tile's 24 MFMAs per K half and wave, the same 9 fragment reads, 6 of 7 staging pieces: (0.75 * 6 + 1.1) on pick_mt's scale.
+  // FLEXAM_GEMM_N192 = 0 keeps the 256-wide shapes (A/B), = 2 forces the 192-wide one wherever N % 192 == 0.
+  if (p.N % 192 == 0) {
+    const char* e = getenv("FLEXAM_GEMM_N192");
+    const int mode = e ? atoi(e) : 1;
+    bool take = mode == 2;
+    if (mode == 1) {
+      const int G = num_cus(), nk = p.K / BK;
+      double best256 = 1e30;
+      for (int mt = 8; mt >= 4; --mt) {
+        const int tiles = (int)((long)((p.M + 32 * mt - 1) / (32 * mt)) * p.tiles_n);
+        int S, rem;
+        double tail;
+        plan_split(g_ws, tiles, nk, S, rem, &tail);
+        best256 = fmin(best256, (tiles / G + tail) * (mt + 1.25));
+      }
+      const int tiles192 = (int)((long)((p.M + 191) / 192) * (p.N / 192));
+      int S, rem;
+      double tail;
+      plan_split(g_ws, tiles192, nk, S, rem, &tail);
+      take = (tiles192 / G + tail) * (0.75 * 6 + 1.1) < 0.95 * best256;
+    }
+    if (take) return launch_shape<EPI, OutT, 6, 2, 3>(p, g_ws, a_koff, s);
   }
   switch (pick_mt(g_ws, p.M, p.tiles_n, p.K / BK)) {
     case 7: return launch_mt<EPI, OutT, 7>(p, g_ws, a_koff, s);

@@ -70,10 +70,14 @@ class LoopbackGroup:
     a Work-like object, so a rank's launch sequence, buffer shapes, partial / merge calls and stream dependencies are the real ones
     while nothing leaves the GPU.  The "received" chunks are copies of the local one: timing and plumbing only, never results."""
 
-    def __init__(self, size: int, rank: int = 0):
+    def __init__(self, size: int, rank: int = 0, copies: bool = True):
         if not 0 <= rank < size:
             raise ValueError(f"LoopbackGroup: rank {rank} outside 0..{size - 1}")
         self.size, self.rank = int(size), int(rank)
+        # copies = False: a collective keeps its stream plumbing (side stream, event, Work) but moves nothing -- the rank's step with NO
+        # stand-in for the exchange at all (its "received" buffers keep whatever they held: timing only)
+        self.copies = bool(copies)
+        self._filled = set()                           # (copies = False) buffers that received their one-off fill
         self._stream = None
 
     def side_stream(self, device):
@@ -84,13 +88,19 @@ class LoopbackGroup:
     def run(self, fn, ref: torch.Tensor, async_op: bool):
         """`fn()` (the copies) after everything enqueued so far on the caller's stream; returns a Work (async) or None (joined)."""
         if ref.device.type != "cuda":                      # CPU tensors (unit tests of the plumbing): synchronous
-            fn()
+            if self.copies:
+                fn()
             return _LoopbackWork(None) if async_op else None
         cur = torch.cuda.current_stream(ref.device)
         side = self.side_stream(ref.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            fn()
+            # copies = False: every receive buffer is filled ONCE (the first collective that targets it), so that what the kernels read
+            # is data of the workload's kind -- uninitialised memory would be timed on the attention kernel's rescale path
+            key = (ref.data_ptr(), ref.numel())
+            if self.copies or key not in self._filled:
+                fn()
+                self._filled.add(key)
             done = torch.cuda.Event()
             done.record(side)
         work = _LoopbackWork(done)
@@ -233,7 +243,7 @@ def all_to_all_chunks(out: torch.Tensor, inp: torch.Tensor, group=None, async_op
     return None
 
 
-def all_to_all_blocks(outs, ins, group=None, async_op: bool = False):
+def all_to_all_blocks(outs, ins, group=None, async_op: bool = False, packed=None):
     """ins[j] (contiguous) goes to rank j, outs[i] (contiguous, anywhere in memory) receives rank i's block: the list form lets
     every received block land where the consumer wants it (no unpack pass).  RCCL: one grouped send/recv (dist.all_to_all);
     async_op = True returns its Work (wait() makes the caller's stream wait for the exchange), so the next sample's exchange
@@ -241,6 +251,9 @@ def all_to_all_blocks(outs, ins, group=None, async_op: bool = False):
     every rank's stacked blocks, finished before returning (None: nothing to wait for)."""
     if isinstance(group, LoopbackGroup):                                  # block i "arrives" as a copy of the block sent to rank i
         def copies():
+            if packed is not None:                                        # packed = (out, inp) with out[i] = outs[i], inp[i] = ins[i]: the same bytes, one copy
+                packed[0].copy_(packed[1])
+                return
             for o, t in zip(outs, ins):
                 o.copy_(t)
         return group.run(copies, outs[0], async_op)

@@ -772,11 +772,16 @@ class DiTEngine:
         # launch plan; `st` carries the Work handles from the step that issues to the step that waits
         st = {"there": [None] * B, "back": [None] * B}
 
-        def go_there(b, async_op):
-            st["there"][b] = all_to_all_blocks([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)], self.sp_group, async_op=async_op)
+        if "a2a_lists" not in ws:                      # the per-peer block views, made once (a replayed step must not rebuild 32 views per block)
+            ws["a2a_lists"] = [([recv[b, i] for i in range(sp)], [send[b, j] for j in range(sp)],
+                                [recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)]) for b in range(B)]
+        lists = ws["a2a_lists"]
+
+        def go_there(b, async_op):                     # packed = the same blocks as ONE tensor pair (a backend that copies can do it in one go)
+            st["there"][b] = all_to_all_blocks(lists[b][0], lists[b][1], self.sp_group, async_op=async_op, packed=(recv[b], send[b]))
 
         def go_back(b, async_op):
-            st["back"][b] = all_to_all_blocks([recv2[j, b] for j in range(sp)], [chunks[b, i] for i in range(sp)], self.sp_group, async_op=async_op)
+            st["back"][b] = all_to_all_blocks(lists[b][2], lists[b][3], self.sp_group, async_op=async_op, packed=(recv2[:, b], chunks[b]))
 
         def wait(which, bs):
             for b in bs:

@@ -240,6 +240,60 @@ def test_gemm_gate_residual_exact_at_ffn2_shape_with_tail_split_k():
         assert torch.equal(col, want_col), f"gate row {r}: {int((col != want_col).sum())} columns differ"
 
 
+@pytest.mark.parametrize("m", [2912, 5824])
+def test_block_gemms_exact_at_the_per_rank_row_counts(m):
+    """The five GEMM shapes of a block at the row counts ONE RANK sees at 8 / 4 GPUs (M = 2912 / 5824: 2 x 11648 / N rows; round-5 verdict
+    item 1) through the C ABI -- q|k|v (N = 9216, K = 3072), cross-attention q (3072, 3072), FFN1 + GELU (14336, 3072), o-projection and
+    FFN2 with the fp32 gated-residual epilogue (3072 x 3072 and 3072 x 14336) -- on integer operands: every output is an exact integer in
+    fp32.  At these sizes a launch is one to three rounds of the 256 CUs with another tile height than the full-size launch picks
+    (pick_mt: 224 / 160 rows) and, for FFN2, other tail-split plans: checked through row / column checksums over all tiles and
+    element-wise on 512 rows; the read-modify-write launches must repeat bit for bit."""
+    from flexam_amd import hip
+    g = torch.Generator().manual_seed(1000 + m)
+    rows = torch.cat([torch.arange(0, 128), torch.arange(m - 128, m), torch.randint(128, m - 128, (256,), generator=g)])
+    for name, n, k, gelu in (("q|k|v", 9216, 3072, False), ("cross-attention q", 3072, 3072, False), ("FFN1 + GELU", 14336, 3072, True)):
+        a = torch.randint(-2, 3, (m, k), generator=g, dtype=torch.int8).float()
+        w = torch.randint(-2, 3, (n, k), generator=g, dtype=torch.int8).float()
+        b = torch.randint(-8, 9, (n,), generator=g).float()
+        ad, wd, bd = a.to(BF).cuda(), w.to(BF).cuda(), b.cuda()
+        out = hip.gemm(ad, wd, bd, out_dtype=torch.float32)
+        _checksums_exact(out, a, w, (b,), f"{name} at M = {m}")
+        want = a[rows] @ w.t() + b
+        assert torch.equal(out[rows.cuda()].cpu(), want), name
+        if gelu:
+            o16 = hip.gemm(ad, wd, bd, epilogue=hip.EPI_GELU_TANH)[rows.cuda()].float().cpu()
+            ref = torch.nn.functional.gelu(want, approximate="tanh")
+            assert not ((o16 - ref).abs() > 2.0 * 2.0 ** -8 * ref.abs() + 1e-2).any()
+        else:                                                 # the bf16 store path of the same launch: integers below 2^8 survive it exactly
+            small = (want.abs() < 256)
+            o16 = hip.gemm(ad, wd, bd)[rows.cuda()].float().cpu()
+            assert torch.equal(o16[small], want[small])
+    for name, n, k in (("o-projection + gated residual", 3072, 3072), ("FFN2 + gated residual", 3072, 14336)):
+        keep = 4 if k == 3072 else 16                         # sparse +-1 rows keep |a.w^T + b| < 256: integers bf16 holds exactly
+        a = (torch.randint(-1, 2, (m, k), generator=g, dtype=torch.int8) * (torch.randint(0, keep, (m, k), generator=g, dtype=torch.int8) == 0)).float()
+        w = torch.randint(-1, 2, (n, k), generator=g, dtype=torch.int8).float()
+        b = torch.randint(-8, 9, (n,), generator=g).float()
+        gate = torch.randint(-2, 3, (4, n), generator=g).float()
+        grow = torch.randint(0, 4, (m,), generator=g, dtype=torch.int32)
+        x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+        ad, wd, bd = a.to(BF).cuda(), w.to(BF).cuda(), b.cuda()
+        xs = []
+        for _ in range(2):
+            x = x0.clone().cuda()
+            hip.gemm_gate_residual(ad, wd, bd, x, gate.cuda(), grow.cuda())
+            xs.append(x)
+        assert torch.equal(xs[0], xs[1]), name
+        y = a[rows] @ w.t() + b
+        assert float(y.abs().max()) < 256.0
+        assert torch.equal(xs[0][rows.cuda()].cpu(), x0[rows] + y * gate[grow[rows].long()]), name
+        delta = (xs[0] - x0.cuda()).double()
+        for r in range(4):
+            sel = (grow == r)
+            col = delta[sel.cuda()].sum(dim=0).cpu()
+            want_col = (a[sel].double().sum(dim=0) @ w.double().t() + b.double() * int(sel.sum())) * gate[r].double()
+            assert torch.equal(col, want_col), f"{name} at M = {m}, gate row {r}: {int((col != want_col).sum())} columns differ"
+
+
 # ----------------------------------------------------------------------------- depth and step accumulation
 def test_thirty_layers_fifty_steps_accumulation():
     """SURVEY section 7 hard part (ii): 30 layers x 50 Euler steps (the real depth and step count) with the fp32 residual

@@ -155,6 +155,50 @@ def test_gemm_160_wide_tile_shape_exact(H, m, n, k, monkeypatch):
     torch.testing.assert_close(H.gemm(ad, wd, bd, out_dtype=torch.float32).cpu(), want, rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("m,n,k", [(2912, 3072, 3072), (2912, 3072, 14336), (1000, 768, 192), (4097, 384, 5184), (200, 192, 27648), (5824, 3072, 3072)])
+def test_gemm_192_wide_tile_shape_exact(H, m, n, k, monkeypatch):
+    """The 192 x 192 tile (r6: 2 x 4 waves, 6 m-tiles x 3 n-tiles each; LDS-staged epilogues with 96-byte wave rows), forced wherever
+    N % 192 == 0 (FLEXAM_GEMM_N192=2; by itself the launcher takes it where it wins, e.g. a rank-of-eight's 2912 x 3072 launches = 16 x
+    16 tiles = one full round of 256 CUs): ragged row counts, interior and edge tiles, several units per workgroup, the tail split-K
+    (K = 27648 / 14336), all four epilogues incl. the per-row gate table -- integer data, exact, and identical to the 256-wide plans."""
+    monkeypatch.setenv("FLEXAM_GEMM_N192", "2")
+    g = torch.Generator().manual_seed(m + n + k)
+    lim = 2 if k < 8000 else 1
+    a = torch.randint(-lim, lim + 1, (m, k), generator=g).float()
+    if k >= 8000:                                                # sparse rows keep |y| < 256, so the bf16 rounding of y changes nothing
+        a = a * (torch.randint(0, 8, (m, k), generator=g) == 0).float()
+    w = torch.randint(-lim, lim + 1, (n, k), generator=g).float()
+    b = torch.randint(-8, 9, (n,), generator=g).float()
+    want = a @ w.t() + b
+    ad, wd, bd = bf(a).to(dev()), bf(w).to(dev()), b.to(dev())
+    gate = torch.randint(-2, 3, (3, n), generator=g).float()
+    rows = torch.randint(0, 3, (m,), generator=g, dtype=torch.int32)
+    x0 = torch.randint(-5, 6, (m, n), generator=g).float()
+    ref16 = torch.nn.functional.gelu(want, approximate="tanh")
+    res = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("FLEXAM_GEMM_N192", mode)
+        o32 = H.gemm(ad, wd, bd, out_dtype=torch.float32)
+        torch.testing.assert_close(o32.cpu(), want, rtol=0, atol=0)
+        o16 = H.gemm(ad, wd, bd)
+        torch.testing.assert_close(o16.float().cpu(), want.to(BF).float(), rtol=0, atol=0)
+        og = H.gemm(ad, wd, bd, epilogue=H.EPI_GELU_TANH)
+        assert_bf16_close(og, ref16, ulps=2.0, atol=1e-2, msg="gelu, 192-wide shape")
+        xs = []
+        for _ in range(2):
+            x = x0.clone().to(dev())
+            H.gemm_gate_residual(ad, wd, bd, x, gate.to(dev()), rows.to(dev()))
+            xs.append(x)
+        assert torch.equal(xs[0], xs[1])
+        torch.testing.assert_close(xs[0].cpu(), x0 + want.to(BF).float() * gate[rows.long()], rtol=0, atol=0)
+        xn = x0.clone().to(dev())
+        H.gemm_gate_residual(ad, wd, None, xn)                 # no bias, no gate
+        torch.testing.assert_close(xn.cpu(), x0 + (a @ w.t()).to(BF).float(), rtol=0, atol=0)
+        res[mode] = (o16, og, xs[0])
+    for u, v in zip(res["2"], res["0"]):
+        assert torch.equal(u, v)                                # the same bits as the 256-wide plans (GELU included: same fp32 sums)
+
+
 @pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
 def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
     """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on
