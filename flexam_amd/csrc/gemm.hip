@@ -106,7 +106,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   // a rank-of-eight's 2912 x 3072 outputs in ONE full round of the CUs (94.8 % useful) where 160 x 256 tiles are 228 tiles at 89 % fill:
   // 10 % less matrix work per CU on the N = 3072 launches of a rank's block (o-proj, cross-o, cross-q, FFN2).  Its wave rows are 48
   // columns = 96 bytes = 6 of the 8 sixteen-byte slots of a staging row; lanes that would carry slots 6, 7 (bf16 store: lane % 8 >= 6;
-  // fp32 read-modify-write: lane % 16 >= 12) load a neighbour's address again and store nothing.
+  // fp32 read-modify-write: lane % 16 >= 12) SHADOW the last piece: same addresses, same loads, the same value stored again by the same
+  // instruction.  (Predicating their stores instead put the epilogue's LDS reads behind branches, and hipcc then let the staging
+  // writes of the next row tile overtake the last reads of this one: rows 12-15 of every other row tile came out as the next tile's.)
   constexpr bool STD = WMW == 2 && (NTW == 4 || NTW == 3);
   constexpr int CW = 16 * NTW;                 // columns per wave
   constexpr int WNW = 8 / WMW;              // waves along N
@@ -462,8 +464,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     // the reads behind them.)
     if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
       const int rr = le >> 4, cc_ = le & 15;           // row inside a group of 4, 16-byte piece of the wave's fp32 row (CW / 4 pieces)
-      const bool live = cc_ < CW / 4;                  // (192-wide tiles: pieces 12..15 do not exist; their lanes shadow piece 11 and store nothing)
-      const int cc = live ? cc_ : CW / 4 - 1;
+      const int cc = cc_ < CW / 4 ? cc_ : CW / 4 - 1;   // (192-wide tiles: pieces 12..15 do not exist; their lanes shadow piece 11)
       const int mw = m0 + wm * (16 * MT);
       const int nw = n0 + wn * (16 * NTW) + cc * 4;
       // X addresses = uniform 64-bit row base (scalar registers) + ONE 32-bit per-lane offset: eight 64-bit per-lane pointers
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
               f32x4 x = xb[idx];
 #pragma unroll
               for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[idx][j] : bf2f(y[j]);
-              if (NTW == 4 || live) __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane));
+              __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane));      // (shadow lanes: the same 16 bytes again)
             }
           }
         };
@@ -569,8 +570,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
     // whole 128-byte rows, 8 per instruction.
     if (m0 + BM_ <= p.M && n0 + BN_ <= p.N) {
       const int rd_row = le >> 3, rd_c_ = le & 7;
-      const bool live = rd_c_ < CW / 8;                // (192-wide tiles: 6 sixteen-byte pieces per wave row)
-      const int rd_c = live ? rd_c_ : CW / 8 - 1;
+      const int rd_c = rd_c_ < CW / 8 ? rd_c_ : CW / 8 - 1;   // (192-wide tiles: 6 sixteen-byte pieces per wave row; lanes 6, 7 of a row shadow piece 5)
       bf16* crow = (bf16*)p.C + (int64_t)(m0 + wm * (16 * MT) + rd_row) * p.ldc + n0 + wn * (16 * NTW) + rd_c * 8;
 #pragma unroll
       for (int t = 0; t < NRT; ++t) {
@@ -592,10 +592,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
           const bf16x8 o8 = *(const bf16x8*)(stg + row * 128 + ((rd_c ^ (row & 7)) << 4));
           // the GELU output (FFN1: 668 MB, read once by FFN2 from its start, when the Infinity Cache holds only its end) leaves non-temporally
           // as well (a further -0.2 ... -0.4 %); the plain outputs (QKV, cross-q) are re-read at once by the next launch and stay cached
-          if (NTW == 4 || live) {
-            if constexpr (EPI == EPI_GELU) __builtin_nontemporal_store(o8, (bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc));
-            else *(bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc) = o8;
-          }
+          if constexpr (EPI == EPI_GELU) __builtin_nontemporal_store(o8, (bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc));
+          else *(bf16x8*)(crow + (int64_t)(t * RT + 8 * i) * p.ldc) = o8;
         }
       }
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));   // see the gate-residual path
