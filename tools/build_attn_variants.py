@@ -4,7 +4,7 @@ flexam_amd/build, so run `python -m flexam_amd.build` first)."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "flexam_amd", "csrc"); objdir = os.path.join(root, "flexam_amd", "build"); out = os.path.join(root, "tools", "probes")
-flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result", "-I" + csrc, "-I" + os.path.join(root, "include")]
+flags = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result", "-I" + csrc, "-I" + os.path.join(root, "include"), "-I" + out]      # tools/probes holds attn_body16.inc (the diagnostic 16x16x32 body)
 others = [os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o") and f != "attn.o"]
 procs = []
 for spec in sys.argv[1:]:
