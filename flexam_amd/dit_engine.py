@@ -642,6 +642,8 @@ class DiTEngine:
             plans = cd.setdefault("_plans", {})
             plan = plans.get(pkey)
             if plan is None:
+                for k in [k for k in plans if k[0] != self._ws_gen]:      # plans of dropped activation buffers would keep those buffers alive
+                    del plans[k]
                 with hip.record() as plan:
                     run_blocks()
                     run_head()
