@@ -62,8 +62,13 @@ struct AttnParams {
   // MXFP8 operands (attn_fp8.inc; q8 != nullptr selects that kernel): written by flexam_attn_fp8_pack
   const unsigned char* q8;   // [B][H][lq_pad][128] e4m3
   const unsigned* qs;        // [B][H][lq_pad] four E8M0 bytes per row
-  const unsigned char* kv8;  // [B][H][ceil(Lk / 64)] records of REC_BYTES
+  const unsigned char* kv8;  // [B][H][ceil(Lk / 64)] records of REC_BYTES -- or, in chunks of kv8_chunk_tiles key tiles, [chunk][B][H][kv8_chunk_tiles]
   int lq_pad;
+  // key tile g lives in chunk g / kv8_chunk_tiles (flexam_attn_fwd_fp8_chunked: the rank-major result of a sequence-parallel all-gather of
+  // every rank's records; one chunk = all tiles for the plain call); kv8_chunk_magic = ceil(2^32 / kv8_chunk_tiles) turns the division
+  // into one s_mul_hi_u32 (exact for g, tiles < 2^16)
+  int kv8_chunk_tiles;
+  unsigned kv8_chunk_magic;
 };
 
 // byte offset of 16-byte chunk `ch` (0..15) of key row `row` in a [64][128] bf16 tile, image (b)
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(AttnParams p) {
 int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k_bs, int64_t k_rs, const void* v, int64_t v_bs,
              int64_t v_rs, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int Lq, int Lk, int head_dim, float softmax_scale,
              int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream, int partial_slot0 = -1, float last_key_bias = 0.f,
-             const void* q8 = nullptr, const void* qs = nullptr, const void* kv8 = nullptr) {
+             const void* q8 = nullptr, const void* qs = nullptr, const void* kv8 = nullptr, int kv8_chunk_tiles = 0) {
   FX_REQUIRE(((q && k && v) || (q8 && qs && kv8)) && (o || partial_slot0 >= 0), FLEXAM_E_ARG, "attn_fwd: null pointer");
   FX_REQUIRE(head_dim == HD, FLEXAM_E_SHAPE, "attn_fwd: head_dim %d unsupported (128 only)", head_dim);
   FX_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, FLEXAM_E_SHAPE, "attn_fwd: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
@@ -757,6 +762,9 @@ int attn_run(const void* q, int64_t q_bs, int64_t q_rs, const void* k, int64_t k
   p.last_key_bias = last_key_bias;
   p.q8 = (const unsigned char*)q8; p.qs = (const unsigned*)qs; p.kv8 = (const unsigned char*)kv8;
   p.lq_pad = p.q_blocks * QBLK;
+  p.kv8_chunk_tiles = kv8_chunk_tiles > 0 ? kv8_chunk_tiles : tiles_all;
+  FX_REQUIRE(tiles_all < 65536, FLEXAM_E_SHAPE, "attn_fwd: %d key tiles (at most 65535)", tiles_all);
+  p.kv8_chunk_magic = p.kv8_chunk_tiles > 1 ? (unsigned)(((1ull << 32) + (unsigned)p.kv8_chunk_tiles - 1) / (unsigned)p.kv8_chunk_tiles) : 0u;
   FX_REQUIRE(q8 || (int64_t)Lk * k_rs * 2 < (1ll << 31) && (int64_t)Lk * v_rs * 2 < (1ll << 31), FLEXAM_E_SHAPE,
              "attn_fwd: one (batch, head) K/V panel must span < 2 GiB (32-bit tile offsets)");
   const int smem = q8 ? NSLOT * REC_BYTES : NSLOT * 2 * KV_TILE_BYTES;   // ring of 4 K tiles, then ring of 4 V tiles: 128 KiB (fp8: 4 records, 68 KiB)
@@ -900,6 +908,16 @@ extern "C" int flexam_attn_fwd_fp8(const void* q8, const void* qs, const void* k
   FX_REQUIRE(((uintptr_t)q8 | (uintptr_t)qs | (uintptr_t)kv8) % 16 == 0, FLEXAM_E_ARG, "attn_fwd_fp8: misaligned pointer");
   return attn_run(nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, o, o_bs, o_rs, B, H, L, L, head_dim, FLEXAM_ATTN_PRESCALED, kv_splits,
                   split_from_unit, ws_o, ws_ml, stream, -1, 0.f, q8, qs, kv8);
+}
+
+extern "C" int flexam_attn_fwd_fp8_chunked(const void* q8, const void* qs, const void* kv8, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
+                                           int Lq, int Lk, int chunk_tiles, int head_dim, int kv_splits, int split_from_unit, float* ws_o,
+                                           float* ws_ml, void* stream) {
+  FX_REQUIRE(q8 && qs && kv8, FLEXAM_E_ARG, "attn_fwd_fp8_chunked: null pointer");
+  FX_REQUIRE(((uintptr_t)q8 | (uintptr_t)qs | (uintptr_t)kv8) % 16 == 0, FLEXAM_E_ARG, "attn_fwd_fp8_chunked: misaligned pointer");
+  FX_REQUIRE(chunk_tiles > 0, FLEXAM_E_SHAPE, "attn_fwd_fp8_chunked: chunk_tiles = %d", chunk_tiles);
+  return attn_run(nullptr, 0, 0, nullptr, 0, 0, nullptr, 0, 0, o, o_bs, o_rs, B, H, Lq, Lk, head_dim, FLEXAM_ATTN_PRESCALED, kv_splits,
+                  split_from_unit, ws_o, ws_ml, stream, -1, 0.f, q8, qs, kv8, chunk_tiles);
 }
 
 #ifdef FLEXAM_ATTN_STAMPS

@@ -407,7 +407,13 @@ class DiTEngine:
         # A sequence that does not divide over the ranks is padded to the next multiple with zero tokens at its end, as the reference
         # does (FX.py:919-925); they are rows like any other in every token-local op, never keys of self-attention (the key ranges
         # below end at L), and the head gather drops them
-        Lp = -(-L // sp) * sp
+        # VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION under the K|V gather (one gather, waited for): the ranks exchange their MXFP8 key / value
+        # RECORDS (one per 64 keys) instead of bf16 rows, so every chunk is a whole number of 64-key tiles: the padding unit is 64 x ranks
+        sage_asked = os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION"
+        sage_gather = (sage_asked and self.fused and sp > 1 and getattr(self, "sp_mode", None) == "allgather" and not self.sp_overlap
+                       and self.sp_pieces == 1)
+        unit = sp * 64 if sage_gather else sp
+        Lp = -(-L // unit) * unit
         lc = Lp // sp
         tok0 = rank * lc
         if Lp > L and cd["cos"].shape[0] < Lp:             # RoPE rows of the pad tokens: the identity, like every token beyond the grid
@@ -488,19 +494,18 @@ class DiTEngine:
 
         nh, hdim = self.nh, self.hd
         # the reference reads the switch at every attention call (attention_utils.py:195); quantised self-attention on one rank only
-        sage_asked = os.environ.get("VIDEOX_ATTENTION_TYPE", "FLASH_ATTENTION") == "SAGE_ATTENTION"
         # one rank: the fused producer (RMSNorm + RoPE write the MXFP8 operands).  Sequence parallel with the all-to-all over heads: every
-        # rank ends up with ALL tokens of its heads in bf16, packs them and runs the MXFP8 kernel on them (r6).  The K|V all-gather keeps
-        # the bf16 kernel: its key tiles (64 keys, one record each) do not line up with the ranks' token chunks, so MXFP8 records cannot
-        # be gathered and re-packing ALL keys on every rank costs more than the kernel saves -- said once per process
-        sage = sage_asked and self.fused and (sp == 1 or (self.sp_mode == "ulysses" and Lp == L))
+        # rank ends up with ALL tokens of its heads in bf16, packs them and runs the MXFP8 kernel on them.  K|V all-gather in its default
+        # form (one gather, waited for): each rank quantises ITS keys / values and the MXFP8 records are what is gathered (sage_gather,
+        # above).  The overlapped gather forms (head-group pieces, partial softmaxes) keep the bf16 kernel -- said once per process
+        sage = sage_asked and self.fused and (sp == 1 or (self.sp_mode == "ulysses" and Lp == L) or sage_gather)
         self.sage_taken = bool(sage)                       # what this forward DID (bench.py labels its line from it, like share0_taken)
         if sage_asked and not sage and not DiTEngine._sage_warned:
             DiTEngine._sage_warned = True
             import warnings
             warnings.warn("flexam_amd: VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION is ignored " +
-                          "under sequence parallelism with the K|V all-gather (or a padded sequence): self-attention runs the bf16 kernel; "
-                          "FLEXAM_SP_MODE=ulysses keeps the MXFP8 kernel", RuntimeWarning, stacklevel=2)
+                          "under sequence parallelism with the OVERLAPPED K|V all-gather (FLEXAM_SP_OVERLAP=1 / head-group pieces) or an all-to-all "
+                          "over a padded sequence: self-attention runs the bf16 kernel", RuntimeWarning, stacklevel=2)
         fp8_oproj = self.fp8 and os.environ.get("FLEXAM_FP8_OPROJ", "0") == "1"
         q4 = qkv.view(B, lc, 3 * d)[:, :, 0:d].unflatten(2, (nh, hdim))
         k4 = qkv.view(B, lc, 3 * d)[:, :, d:2 * d].unflatten(2, (nh, hdim))
@@ -546,8 +551,12 @@ class DiTEngine:
                     #  columns quantise worse on 256 CUs than one of 36 (emulated rank of 8, profiles/r5*: 119 + 80 us against ~135), and the
                     #  gather starts ~15 us later, not ~80)
                     fused_qkv = self.sp_fused_qkv
-                    self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None) if fused_qkv else slice(d, None), qkv if fused_qkv else qkv[:, d:])
-                    self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0, q_done=fused_qkv)
+                    if sage:                               # (sage_gather: the MXFP8 records travel; always one q|k|v launch)
+                        self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None), qkv)
+                        self._allgather_attention_mx(qkv, p, ao4, q4, k4, v4, B, lc, tok0)
+                    else:
+                        self._proj(hbuf, fp8_here and (a8, sa), i, p, "wqkv", "bqkv", slice(None) if fused_qkv else slice(d, None), qkv if fused_qkv else qkv[:, d:])
+                        self._allgather_attention(qkv, hbuf, fp8_here and (a8, sa), i, p, ao4, q4, B, lc, tok0, q_done=fused_qkv)
                     hip.gemm_gate_residual(ao, p["wo"], p["bo"], xres, gate=T[:, 2], gate_row=row_index, rows_per_batch=rpb)
                 else:
                     a8sa = fp8_here and (a8[:mb], sa[:mb])
@@ -898,6 +907,31 @@ class DiTEngine:
             if tok0 + lc < Lr:
                 n += hip.attn_fwd_partial(qg, heads(kc[:, tok0 + lc:Lr]), heads(vc[:, tok0 + lc:Lr]), ws["kv_part"], n, s_after, prescaled=True)
             hip.attn_merge(og, ws["kv_part"], n, prescaled=True)
+
+    def _allgather_attention_mx(self, qkv, p, ao4, q4, k4, v4, B, lc, tok0):
+        """SAGE_ATTENTION under the K|V all-gather (r6; the reference's `sageattn` switch, attention_utils.py:195-203, with the exchange of
+        the missing FlexAM/dist, wan_transformer3d_FlexAM.py:801-815): this rank's q, k (RMSNorm + RoPE at the chunk's global offset) and
+        v become MXFP8 operands -- written by the RMSNorm + RoPE launch itself at the 5B width (flexam_rmsnorm_rope_mx; the V half by the
+        pack kernel), else normed in bf16 and packed --, ONE all-gather moves the key / value RECORDS ([B, H, lc / 64] x 18 KiB per rank:
+        288 bytes per key and head instead of 512 in bf16; the rank-major result is the chunk layout flexam_attn_fwd_fp8_chunked reads),
+        and one attention call of the local queries over all L real keys follows.  lc is a multiple of 64 (run() pads to 64 x ranks)."""
+        from .dist import all_gather_into_tensor
+        sp, nh, hd, d = self.sp_size, self.nh, self.hd, self.dim
+        cd = self.cond
+        ws = self._ws[(B, lc)]
+        bufs = self._attn8_buffers(B, lc)
+        if "kv8_all" not in ws:
+            ws["kv8_all"] = torch.empty(sp, *bufs[2].shape, device=self.device, dtype=torch.uint8)
+        kv8_all = ws["kv8_all"]
+        if nh == 24 and hd == 128 and os.environ.get("FLEXAM_SAGE_FUSED", "1") != "0":
+            hip.rmsnorm_rope_mx(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], bufs, cd["cos"], cd["sin"], lc, tok0, eps=self.eps)
+            hip.attn_fp8_pack(None, None, v4, bufs)
+        else:
+            hip.rmsnorm_rope(qkv[:, 0:d], p["nq"], qkv[:, d:2 * d], p["nk"], eps=self.eps, rope_cos=cd["cos"], rope_sin=cd["sin"],
+                             tokens_per_batch=lc, token_offset=tok0, head_dim=hd)
+            hip.attn_fp8_pack(q4, k4, v4, bufs)
+        hip.host_op(lambda: all_gather_into_tensor(kv8_all.view(sp * B, *bufs[2].shape[1:]), bufs[2], group=self.sp_group))
+        hip.attn_fwd_fp8_chunked(bufs[0], bufs[1], kv8_all, lc, cd["L"], out=ao4)
 
     def gather_tokens(self, head_local: torch.Tensor) -> torch.Tensor:
         """All-gather of the head output [B, Lc, 192] -> [B, L, 192] (the reference's one collective,

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "flexam_attn_fp8_pack": ([_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _P, _P, _I, _I, _I, _I, _P], c_int),
     "flexam_rmsnorm_rope_mx": ([_P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _I, _F, _P, _P, _L, _L, _I, _I, _P], c_int),
     "flexam_attn_fwd_fp8": ([_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
+    "flexam_attn_fwd_fp8_chunked": ([_P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], c_int),
     "flexam_ln_modulate": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P], c_int),
     "flexam_ln_modulate_fp8": ([_P, _L, _L, _I, _F, _P, _P, _L, _P, _L, _P, _P, _P, _L, _P, _P, _F, _F, _P], c_int),
     "flexam_gate_residual": ([_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _P], c_int),
@@ -625,6 +626,42 @@ def attn_fwd_fp8(bufs, L, out=None, kv_splits=None, split_from_unit=None):
         _, ws_o, ws_ml = _ws_slot(_ATTN_WS, slot, None)
     _check(lib().flexam_attn_fwd_fp8(_raw(q8), _raw(qs), _raw(kv8), _ptr(out, BF16), out.stride(0), out.stride(1), B, H, L, D,
                                      max(S, 1), from_unit if S > 1 else 0, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()), "flexam_attn_fwd_fp8")
+    return out
+
+
+def attn_fwd_fp8_chunked(q8, qs, kv8_chunks, lq, lk, out=None):
+    """Attention of `lq` local queries (q8 / qs of attn_fp8_buffers(B, H, lq)) over `lk` keys whose MXFP8 records come in CHUNKS:
+    kv8_chunks uint8 [n_chunks, B, H, chunk_tiles, ATTN8_REC_BYTES], chunk c holding the keys [c, c + 1) * chunk_tiles * 64 -- the
+    rank-major result of all-gathering every sequence-parallel rank's own records.  -> out [B, lq, H, 128] bf16."""
+    B, H, D = q8.shape[0], q8.shape[1], 128
+    lp = -(-lq // 256) * 256
+    if tuple(q8.shape) != (B, H, lp, D) or tuple(qs.shape) != (B, H, lp) or q8.dtype != U8 or qs.dtype != torch.int32 or not (q8.is_contiguous() and qs.is_contiguous()):
+        raise RuntimeError(f"attn_fwd_fp8_chunked: q8 / qs are not the query buffers of attn_fp8_buffers(B={B}, H={H}, L={lq})")
+    if (kv8_chunks.dim() != 5 or kv8_chunks.dtype != U8 or not kv8_chunks.is_contiguous() or tuple(kv8_chunks.shape[1:3]) != (B, H)
+            or kv8_chunks.shape[4] != ATTN8_REC_BYTES or kv8_chunks.device != q8.device):
+        raise RuntimeError(f"attn_fwd_fp8_chunked: records must be contiguous uint8 [chunks, B={B}, H={H}, chunk_tiles, {ATTN8_REC_BYTES}], got {tuple(kv8_chunks.shape)}")
+    n_chunks, chunk_tiles = kv8_chunks.shape[0], kv8_chunks.shape[3]
+    if not 0 < lk <= n_chunks * chunk_tiles * 64:
+        raise RuntimeError(f"attn_fwd_fp8_chunked: {lk} keys do not fit {n_chunks} chunks of {chunk_tiles} tiles")
+    if out is None:
+        out = torch.empty(B, lq, H, D, device=q8.device, dtype=BF16)
+    if out.stride(3) != 1 or out.stride(2) != D or tuple(out.shape) != (B, lq, H, D):
+        raise RuntimeError(f"attn_fwd_fp8_chunked: out must be [B={B}, L={lq}, H={H}, 128] with heads packed along the row, got {tuple(out.shape)}")
+    units = B * H * ((lq + 255) // 256)
+    S, from_unit = attn_split_plan(B * H, lq, lk, num_cus())
+    ws_o = ws_ml = None
+    if S > 1:
+        n = units - from_unit
+        st = _stream()
+        slot, key = (q8.device.index if q8.device.index is not None else torch.cuda.current_device(), st), (S, n)
+        if _ATTN_WS.get(slot, (None,))[0] != key:
+            _ATTN_WS.pop(slot, None)
+            _ws_slot(_ATTN_WS, slot, lambda: (key, torch.empty(S, n, 256, D, device=q8.device, dtype=F32),
+                                              torch.empty(S, n, 256, 2, device=q8.device, dtype=F32)))
+        _, ws_o, ws_ml = _ws_slot(_ATTN_WS, slot, None)
+    _check(lib().flexam_attn_fwd_fp8_chunked(_raw(q8), _raw(qs), _raw(kv8_chunks), _ptr(out, BF16), out.stride(0), out.stride(1), B, H, lq, lk,
+                                             chunk_tiles, D, max(S, 1), from_unit if S > 1 else 0, _ptr(ws_o, F32), _ptr(ws_ml, F32), _stream()),
+           "flexam_attn_fwd_fp8_chunked")
     return out
 
 

@@ -160,6 +160,14 @@ int flexam_rmsnorm_rope_mx(const void* q, int64_t ldq, const float* wq, const vo
                            int64_t tokens_per_batch, int64_t token_offset, int H, int head_dim, void* stream);
 int flexam_attn_fwd_fp8(const void* q8, const void* qs, const void* kv8, void* o, int64_t o_bs, int64_t o_rs, int B, int H, int L,
                         int head_dim, int kv_splits, int split_from_unit, float* ws_o, float* ws_ml, void* stream);
+/* The same kernel with Lq != Lk and the key records in CHUNKS of `chunk_tiles` 64-key tiles: kv8 = [n_chunks][B][H][chunk_tiles] records,
+ * n_chunks = ceil(ceil(Lk / 64) / chunk_tiles) -- the rank-major result of all-gathering every rank's own records under sequence
+ * parallelism (each rank's token chunk a multiple of 64 tokens: MXFP8 K|V travel instead of bf16 rows, 288 instead of 512 bytes per key
+ * and head; the missing exchange of FlexAM/dist, wan_transformer3d_FlexAM.py:801-815, for VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION).
+ * q8 / qs: [B][H][ceil(Lq / 256) * 256] rows as flexam_attn_fp8_pack writes them for L = Lq.  Keys >= Lk are masked. */
+int flexam_attn_fwd_fp8_chunked(const void* q8, const void* qs, const void* kv8, void* o, int64_t o_bs, int64_t o_rs, int B, int H,
+                                int Lq, int Lk, int chunk_tiles, int head_dim, int kv_splits, int split_from_unit, float* ws_o,
+                                float* ws_ml, void* stream);
 
 /* out_bf16[m,:] = LN(x_f32[m,:]; eps) [* ln_w + ln_b] [* scale[row(m),:] + shift[row(m),:]]
  * row(m) = row_index[m] if row_index else m / rows_per_batch; scale rows already hold (1+scale),
