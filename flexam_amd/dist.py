@@ -269,10 +269,11 @@ def all_to_all_blocks(outs, ins, group=None, async_op: bool = False, packed=None
     return None
 
 
-def shard_rows(full: torch.Tensor, batch: int, seq_len: int, rank: int, world: int) -> torch.Tensor:
+def shard_rows(full: torch.Tensor, batch: int, seq_len: int, rank: int, world: int, chunk: int = None) -> torch.Tensor:
     """Per-token vector [B*L] (e.g. the AdaLN row index) -> this rank's [B*Lc] slice of the padded sequence; pad tokens repeat the
-    last real token's entry (the reference pads `t` with its last element, wan_transformer3d_FlexAM.py:930-934)."""
-    s, e = chunk_bounds(seq_len, rank, world)
+    last real token's entry (the reference pads `t` with its last element, wan_transformer3d_FlexAM.py:930-934).  `chunk`: rows per
+    rank when the engine pads to more than a multiple of the ranks (MXFP8 key records: whole 64-key tiles per rank)."""
+    s, e = (rank * chunk, (rank + 1) * chunk) if chunk is not None else chunk_bounds(seq_len, rank, world)
     v = full.view(batch, seq_len)
     if e > seq_len:
         v = torch.cat([v, v[:, -1:].expand(batch, e - seq_len)], dim=1)

@@ -484,7 +484,7 @@ class DiTEngine:
             # builds a new one per call) -- what a recorded launch plan (below) needs
             if sp > 1:
                 from .dist import shard_rows
-                row_index = shard_rows(row_index, B, L, rank, sp)
+                row_index = shard_rows(row_index, B, L, rank, sp, chunk=lc)
             buf = ws.get("row_index_buf")
             if buf is None or buf.numel() != row_index.numel():
                 buf = ws["row_index_buf"] = torch.empty(row_index.numel(), device=dev, dtype=I32)

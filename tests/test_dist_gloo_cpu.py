@@ -118,6 +118,8 @@ def test_chunk_bounds_pad_like_the_reference():
     idx = torch.arange(2 * 7, dtype=torch.int32)                                     # B = 2, L = 7, three ranks: chunks of 3, the last 1 real + 2 pads
     assert shard_rows(idx, 2, 7, 0, 3).tolist() == [0, 1, 2, 7, 8, 9]
     assert shard_rows(idx, 2, 7, 2, 3).tolist() == [6, 6, 6, 13, 13, 13]             # pads repeat the last real token's entry (FX.py:930-934)
+    assert shard_rows(idx, 2, 7, 1, 3, chunk=4).tolist() == [4, 5, 6, 6, 11, 12, 13, 13]    # a wider padding unit (MXFP8 key records: whole tiles per rank)
+    assert shard_rows(idx, 2, 7, 2, 3, chunk=4).tolist() == [6, 6, 6, 6, 13, 13, 13, 13]    # a rank that holds pads only
 
 
 def _async_gather(rank, world):

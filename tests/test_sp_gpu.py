@@ -315,4 +315,4 @@ def test_sage_attention_under_the_kv_gather_moves_mxfp8_records(world, cfg_paral
     single, _ = single_process(wide)
     rel, rel_l, rel_b = rel_rms(out0, single8), rel_rms(lat0, lat8), rel_rms(out0, single)
     print(f"{world} ranks, K|V gather of MXFP8 records ({'24 heads' if wide else 'tiny'}): vs the single-rank MXFP8 result rel-rms {rel:.2e} (DiT), {rel_l:.2e} (sampler); vs bf16 {rel_b:.2e}")
-    assert rel < 2e-3 and rel_l < 1e-2 and 1e-4 < rel_b < 6e-2
+    assert rel < 4e-3 and rel_l < 2e-2 and 1e-4 < rel_b < 6e-2
