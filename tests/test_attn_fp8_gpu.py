@@ -191,3 +191,37 @@ def test_fused_rmsnorm_rope_writes_the_same_operands_as_the_two_step_path(H):
     r1, r2 = float((o1 - ref).norm() / ref.norm()), float((o2 - ref).norm() / ref.norm())
     print("fused", r1, "two-step", r2)
     assert r1 <= 1.15 * r2 + 5e-3
+
+
+@pytest.mark.parametrize("B,Hh,chunk,n_chunks,lk", [(1, 2, 256, 4, 1024), (2, 3, 128, 3, 300), (1, 1, 64, 5, 257), (1, 24, 2944, 4, 11648)])
+def test_chunked_key_records_equal_the_contiguous_ones(H, B, Hh, chunk, n_chunks, lk):
+    """flexam_attn_fwd_fp8_chunked (r6): the key / value records of a sequence cut into `n_chunks` chunks of `chunk` tokens (a multiple
+    of 64), each packed on its own -- what every sequence-parallel rank does with its tokens -- and stacked rank-major, against ONE pack
+    of the whole sequence: the records are the same bytes, so (1) all queries over the chunked records = the plain call's bits, and (2)
+    the queries of ONE chunk (Lq != Lk, a rank's local rows) agree with the same rows of the plain call to the fp32 merge's rounding.
+    `lk` real keys: the last chunks hold pads (rows of zeros here), masked by the key count; the last case is a rank of four at the
+    bench's 11648 tokens (chunks of 46 tiles)."""
+    lp = chunk * n_chunks
+    q, k, v = _inputs(B, Hh, lp, 7 + lk)
+    for t in (q, k, v):
+        t[:, lk:] = 0                                          # pad tokens behind the real ones
+    plain = H.attn_fwd_fp8(H.attn_fp8_pack(q[:, :lk].contiguous(), k[:, :lk].contiguous(), v[:, :lk].contiguous()), lk)
+    per = [H.attn_fp8_pack(q[:, c * chunk:(c + 1) * chunk].contiguous(), k[:, c * chunk:(c + 1) * chunk].contiguous(),
+                           v[:, c * chunk:(c + 1) * chunk].contiguous()) for c in range(n_chunks)]
+    kv8 = torch.stack([p[2] for p in per]).contiguous()        # [chunks, B, H, chunk / 64, record]: the all-gather's rank-major result
+    assert kv8.shape[3] == chunk // 64
+    for c in range(n_chunks):
+        if c * chunk >= lk:
+            continue                                           # a rank that holds pads only computes rows nobody reads
+        got = H.attn_fwd_fp8_chunked(per[c][0], per[c][1], kv8, chunk, lk)
+        n = min(chunk, lk - c * chunk)
+        want = plain[:, c * chunk:c * chunk + n]
+        err = (got[:, :n].float() - want.float()).abs().max().item()
+        assert err <= 2.0 ** -7 * want.float().abs().max().item() + 1e-6, (c, err)      # a bf16 ulp of the largest output: other split plans, same records
+    if lk == lp and lk % 256 == 0:                             # no pads, whole q blocks: the full query set over chunked records, bit for bit
+        qfull = H.attn_fp8_pack(q, k, v)
+        assert torch.equal(H.attn_fwd_fp8_chunked(qfull[0], qfull[1], kv8, lk, lk), plain)
+    with pytest.raises(RuntimeError):
+        H.attn_fwd_fp8_chunked(per[0][0], per[0][1], kv8, chunk, lp + 1)             # more keys than the chunks hold
+    with pytest.raises(RuntimeError):
+        H.attn_fwd_fp8_chunked(per[0][0], per[0][1], kv8[:, :, :, :, :-1], chunk, lk)  # not record-sized
