@@ -14,10 +14,11 @@ synthetic seeded conditioning.  One *step* = one iteration of the reference loop
 (pipeline_wan2_2_fun_control_FlexAM.py:844-949): two DiT sample-forwards + CFG + Euler + masked blend.
 N > 1: one process per GPU (strong scaling of ONE clip).  Default layout: the two CFG rows are split
 first (independent until the guidance combine: no per-block traffic), then the token sequence into N/2 contiguous chunks whose
-post-norm K|V are all-gathered per block over RCCL/xGMI while the rank attends to its local chunk ("allgather", the collective
-BASELINE.json's north_star names).  FLEXAM_SP_MODE=ulysses selects the all-to-all-over-heads exchange instead (then N >= 4 runs
-N-way token chunks with the CFG pair batched), FLEXAM_SP_OVERLAP=0 the all-gather without local-chunk-first attention,
-FLEXAM_CFG_PARALLEL=0/1 overrides the CFG split; `config.parallelism` names what ran.
+post-norm K|V are all-gathered per block over RCCL/xGMI ("allgather", the collective BASELINE.json's north_star names; since r6 ONE
+gather per block, waited for, then ONE attention call -- FLEXAM_SP_OVERLAP=1 selects the local-chunk-first form that attends to the
+local chunk under the gather).  FLEXAM_SP_MODE=ulysses selects the all-to-all-over-heads exchange instead (then N >= 4 runs N-way
+token chunks with the CFG pair batched), FLEXAM_CFG_PARALLEL=0/1 overrides the CFG split; for N >= 4 with nothing pinned the layout
+probe times two steps of every candidate on the node and runs the fastest; `config.parallelism` names what ran.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the self-attention flash kernel, timed
 live with events on the launch stream) and `cpu_baseline` (the fp32 oracle on the host cores, one of the

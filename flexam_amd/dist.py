@@ -7,9 +7,10 @@ full 3-D so chunks need not be frame aligned, RoPE rows are looked up by the *gl
 weights replicated, every op token-local except self-attention, which needs all keys/values.  Two
 exchange schemes per block (DiTEngine.sp_mode):
   * "allgather" (default; the collective BASELINE.json's north_star names): all-gather of the post-norm, post-RoPE K|V
-    ([L/N, 2C] bf16 per CFG row and rank), started as soon as K|V exist; underneath it the rank projects Q and attends
-    to its LOCAL K/V chunk (flexam_attn_fwd_partial), then to the gathered chunks, and merges the partial softmaxes
-    (flexam_attn_merge) -- (N-1) x 2 C elements per token arrive;
+    ([L/N, 2C] bf16 per CFG row and rank) -- (N-1) x 2 C elements per token arrive.  Default form (r6): ONE gather per block, waited
+    for, ONE attention call of the local queries over all keys; with VIDEOX_ATTENTION_TYPE=SAGE_ATTENTION the MXFP8 key / value records
+    are what travels.  FLEXAM_SP_OVERLAP=1: the gather in head-group pieces started as soon as K|V exist, the rank attending to its
+    LOCAL chunk underneath (flexam_attn_fwd_partial), then to the gathered chunks, partial softmaxes merged (flexam_attn_merge);
   * "ulysses" (FLEXAM_SP_MODE=ulysses; the heads must divide over the ranks): all-to-all of q|k|v so that every rank holds
     ALL tokens of H/N heads, attention, all-to-all of the output back to token chunks -- (N-1)/N of 4 C elements per
     token leave a rank, each peer link carries 1/N of it.  q|k|v are written in the send layout by the RMSNorm+RoPE kernel
