@@ -843,7 +843,9 @@ class DiTEngine:
         """K|V of this rank's tokens are in qkv[:, C:] (projected, not yet normed).  The RMSNorm+RoPE launch writes K (normed,
         rotated) and V into the send buffer, cut into `sp_pieces` groups of heads: [G, B, lc, 2*C/G].  One all-gather per group
         and CFG row assembles [G, B, L, 2*C/G] in token order (the rank-major concatenation IS the token order: no re-layout
-        pass), all of them issued at once.  Underneath: Q projection, Q norm/RoPE, then the heads of group 0 attend to the LOCAL
+        pass), all of them issued at once.  DEFAULT (r6: FLEXAM_SP_OVERLAP=0, one piece): the gather is waited for and ONE ordinary
+        attention call of the local queries over all L real keys follows -- the fastest form on compute.  FLEXAM_SP_OVERLAP=1
+        (r2-r5's default, a layout-probe candidate): underneath the gather: Q projection, Q norm/RoPE, then the heads of group 0 attend to the LOCAL
         chunk (partial softmax, straight from the send buffer), to the chunks before / after it once piece 0 has landed, one
         merge; the heads of group g > 0 run one ordinary attention call on their gathered piece, which travelled while group
         g - 1 computed.  A peer chunk cannot arrive faster than its one xGMI link delivers it, and the chunks of one gather all
