@@ -358,6 +358,9 @@ def main():
                                         "predicted_scaling_no_comm": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step"], 3) for r in emulated if "ms_per_step" in r},
                                         "predicted_scaling_compute_only": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step_compute_only"], 3)
                                                                            for r in emulated if "ms_per_step_compute_only" in r},
+                                        "predicted_scaling_at_link_GBps": {r["layout"]: {k: round(elapsed / args.steps * 1e3 / v, 3) for k, v in r["ms_per_step_at_link_GBps"].items()}
+                                                                           for r in emulated if "ms_per_step_at_link_GBps" in r},
+                                        "link_time_note": __import__("benchlib.emulate", fromlist=["LINK_NOTE"]).LINK_NOTE,
                                         "compute_only_note": "the same rank step with collectives that move nothing (stream plumbing only): predicted_scaling_no_comm keeps "
                                                              "the same-size device copies as a stand-in for the bytes a rank receives; where a gather is waited for, "
                                                              "those copies sit in front of the attention call and are counted as if they were compute",

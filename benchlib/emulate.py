@@ -58,20 +58,31 @@ def layouts(world: int, num_heads: int):
     return out
 
 
-def set_emulated_layout(model, world: int, cfg_parallel: bool, rank: int, copies: bool = True):
+def set_emulated_layout(model, world: int, cfg_parallel: bool, rank: int, copies: bool = True, link_gbps: float = None):
     from flexam_amd.dist import LoopbackGroup
+    mk = lambda size, r: LoopbackGroup(size, r, copies, link_gbps)
     if cfg_parallel:
         sp = world // 2
-        par = dict(sp_group=LoopbackGroup(sp, rank % sp, copies) if sp > 1 else None, sp_rank=rank % sp, sp_size=sp,
-                   world_group=LoopbackGroup(world, rank, copies), world_size=world, cfg_size=2, cfg_row=rank // sp)
+        par = dict(sp_group=mk(sp, rank % sp) if sp > 1 else None, sp_rank=rank % sp, sp_size=sp, world_group=mk(world, rank),
+                   world_size=world, cfg_size=2, cfg_row=rank // sp)
     else:
-        g = LoopbackGroup(world, rank, copies)
+        g = mk(world, rank)
         par = dict(sp_group=g, sp_rank=rank, sp_size=world, world_group=g, world_size=world)
     model._parallel = par
     model._engine = None                                   # rebuilt for the layout on its next use (reads the FLEXAM_SP_* switches)
 
 
-def emulate(model, make_pipe, inp, cond, world: int, steps: int, warmup: int, total_steps: int, rank=None):
+# ASSUMED rates of one direction of one xGMI link for the `with_link_time` legs (GB/s).  MI355X: 7 links per GPU, 153.6 GB/s each
+# counting both directions = 76.8 GB/s per direction at the wire; collectives typically deliver 60-75 % of it.  Two points bracket that.
+LINK_RATES_GBPS = (50.0, 75.0)
+LINK_NOTE = ("the same rank step with every collective ALSO holding its side stream for (bytes one link carries) / (an ASSUMED rate per link and "
+             "direction) + 10 us: the xGMI mesh is point-to-point, so an all-gather's time is ONE peer chunk over one link and an all-to-all's "
+             "ONE block, all links in parallel (flexam_amd.dist.LoopbackGroup, flexam_delay_us: a wave waiting on the 100 MHz counter).  "
+             "What hides under compute and what does not is the engine's real stream order.  A MODEL of the links, not a measurement: no "
+             "multi-GPU box has been available to this build")
+
+
+def emulate(model, make_pipe, inp, cond, world: int, steps: int, warmup: int, total_steps: int, rank=None, link_rates=LINK_RATES_GBPS):
     """Times one emulated rank per layout.  `rank`: which rank's share (default: the middle chunk of the first CFG half -- remote
     chunks on both sides of its own, the most partial-attention calls).  Leaves the model without a parallel layout."""
     saved = {k: os.environ.get(k) for k in ("FLEXAM_SP_MODE", "FLEXAM_SP_PIECES", "FLEXAM_SP_OVERLAP")}
@@ -106,6 +117,15 @@ def emulate(model, make_pipe, inp, cond, world: int, steps: int, warmup: int, to
             m0 = measure_rank_step(lambda i: pipe.denoise_step(i % total_steps), torch.cuda.synchronize, min(steps, 6), min(warmup, 2))
             rows[-1]["ms_per_step_compute_only"] = m0["sec"] * 1e3
             del pipe
+            if link_rates:
+                rows[-1]["ms_per_step_at_link_GBps"] = {}
+                for rate in link_rates:
+                    set_emulated_layout(model, world, cfgp, r, link_gbps=rate)
+                    pipe = make_pipe()
+                    pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
+                    ml = measure_rank_step(lambda i: pipe.denoise_step(i % total_steps), torch.cuda.synchronize, min(steps, 6), min(warmup, 2))
+                    rows[-1]["ms_per_step_at_link_GBps"][f"{rate:g}"] = ml["sec"] * 1e3
+                    del pipe
     finally:
         for k, v in saved.items():
             if v is None:

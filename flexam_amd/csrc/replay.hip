@@ -47,3 +47,22 @@ extern "C" int flexam_replay(const flexam_cmd* cmds, int64_t n, int64_t* failed_
   if (failed_at) *failed_at = -1;
   return FLEXAM_OK;
 }
+
+// ---- flexam_delay_us: one wave that waits `us` microseconds of the constant 100 MHz counter (s_memrealtime: independent of the shader
+// clock, which moves with the power cap) and does nothing else.  The emulation of a multi-GPU rank on one GPU (flexam_amd.dist.LoopbackGroup,
+// bench.py --emulate-rank) puts it on the side stream where a collective's transfer time would sit: link time = bytes per link / an ASSUMED
+// link rate.  Not used by the product path.
+namespace {
+__global__ __launch_bounds__(64) void delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
+extern "C" int flexam_delay_us(float us, void* stream) {
+  FX_REQUIRE(us >= 0.f && us <= 1e6f, FLEXAM_E_ARG, "delay_us: %g us (0 .. 1e6)", (double)us);
+  const unsigned long long ticks = (unsigned long long)((double)us * 100.0);
+  if (ticks == 0) return FLEXAM_OK;
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ticks);
+  return flexam_check_launch("flexam_delay_us");
+}

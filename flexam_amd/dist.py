@@ -71,13 +71,18 @@ class LoopbackGroup:
     a Work-like object, so a rank's launch sequence, buffer shapes, partial / merge calls and stream dependencies are the real ones
     while nothing leaves the GPU.  The "received" chunks are copies of the local one: timing and plumbing only, never results."""
 
-    def __init__(self, size: int, rank: int = 0, copies: bool = True):
+    def __init__(self, size: int, rank: int = 0, copies: bool = True, link_gbps: float = None, latency_us: float = 10.0):
         if not 0 <= rank < size:
             raise ValueError(f"LoopbackGroup: rank {rank} outside 0..{size - 1}")
         self.size, self.rank = int(size), int(rank)
         # copies = False: a collective keeps its stream plumbing (side stream, event, Work) but moves nothing -- the rank's step with NO
         # stand-in for the exchange at all (its "received" buffers keep whatever they held: timing only)
         self.copies = bool(copies)
+        # link_gbps: an ASSUMED rate of one direction of one xGMI link (GB/s).  Every collective then also holds its side stream for
+        # bytes-per-link / rate + latency_us (flexam_delay_us): the mesh is point-to-point, every peer's chunk / block travels on its own
+        # link, all links in parallel -- so the time of an all-gather is ONE chunk's bytes over one link, of an all-to-all ONE block's.
+        self.link_gbps = None if not link_gbps else float(link_gbps)
+        self.latency_us = float(latency_us)
         self._filled = set()                           # (copies = False) buffers that received their one-off fill
         self._stream = None
 
@@ -86,8 +91,9 @@ class LoopbackGroup:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
 
-    def run(self, fn, ref: torch.Tensor, async_op: bool):
-        """`fn()` (the copies) after everything enqueued so far on the caller's stream; returns a Work (async) or None (joined)."""
+    def run(self, fn, ref: torch.Tensor, async_op: bool, link_bytes: int = 0):
+        """`fn()` (the copies) after everything enqueued so far on the caller's stream; returns a Work (async) or None (joined).
+        link_bytes: what ONE link carries for this collective (its transfer time under `link_gbps`)."""
         if ref.device.type != "cuda":                      # CPU tensors (unit tests of the plumbing): synchronous
             if self.copies:
                 fn()
@@ -102,6 +108,9 @@ class LoopbackGroup:
             if self.copies or key not in self._filled:
                 fn()
                 self._filled.add(key)
+            if self.link_gbps and self.size > 1:
+                from . import hip
+                hip.delay_us(link_bytes / (self.link_gbps * 1e3) + self.latency_us)
             done = torch.cuda.Event()
             done.record(side)
         work = _LoopbackWork(done)
@@ -139,7 +148,8 @@ def all_gather_into_tensor(out: torch.Tensor, inp: torch.Tensor, group=None, asy
     receives a copy of `inp` (one launch, the bytes a real gather writes)."""
     if isinstance(group, LoopbackGroup):
         src = inp.contiguous()
-        return group.run(lambda: out.view(group.size, *src.shape).copy_(src.unsqueeze(0).expand(group.size, *src.shape)), out, async_op)
+        return group.run(lambda: out.view(group.size, *src.shape).copy_(src.unsqueeze(0).expand(group.size, *src.shape)), out, async_op,
+                         link_bytes=src.numel() * src.element_size())        # every peer's chunk on its own link, all in parallel
     return dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
 
 
@@ -233,7 +243,7 @@ def all_to_all_chunks(out: torch.Tensor, inp: torch.Tensor, group=None, async_op
     all_to_all_single (pairwise sends over the xGMI mesh).  Other backends (the gloo test runs) may lack all-to-all on device
     tensors: the same result is assembled from an all-gather of every rank's send buffer."""
     if isinstance(group, LoopbackGroup):
-        return group.run(lambda: out.copy_(inp), out, async_op)
+        return group.run(lambda: out.copy_(inp), out, async_op, link_bytes=inp[0].numel() * inp.element_size())
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "nccl":
         return dist.all_to_all_single(out, inp, group=group, async_op=async_op)
@@ -257,7 +267,7 @@ def all_to_all_blocks(outs, ins, group=None, async_op: bool = False, packed=None
                 return
             for o, t in zip(outs, ins):
                 o.copy_(t)
-        return group.run(copies, outs[0], async_op)
+        return group.run(copies, outs[0], async_op, link_bytes=ins[0].numel() * ins[0].element_size())    # one block per peer link (and direction)
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "nccl":
         return dist.all_to_all(list(outs), list(ins), group=group, async_op=async_op)

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "flexam_vae_patchify_cl": ([_P, _I, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_space_to_depth_cl": ([_P, _I, _L, _I, _I, _I, _I, _P, _I, _I, _P], c_int),
     "flexam_avgdown_add_cl": ([_P, _L, _I, _I, _I, _I, _P, _L, _I, _I, _I, _I, _P], c_int),
+    "flexam_delay_us": ([_F, _P], c_int),
     "flexam_fn_id": ([c_char_p], c_int),
     "flexam_fn_count": ([], c_int),
     "flexam_fn_name": ([_I], c_char_p),
@@ -233,11 +234,25 @@ class record:
 
 def host_op(fn):
     """Runs `fn()` now; while a plan is recorded it also closes the open C segment and becomes a host step of the plan (run again, in
-    this place, by every Plan.run()).  For what is not a call into the library: collectives, Work.wait(), torch copies."""
-    if _rec is not None:
-        _rec.flush()
-        _rec.plan.items.append(("py", fn, None))
-    return fn()
+    this place, by every Plan.run()).  For what is not a call into the library: collectives, Work.wait(), torch copies.  A host step is
+    opaque: library calls it makes itself (an emulated collective's delay kernel on its side stream) are part of the step, not of a C
+    segment -- recording is suspended while it runs."""
+    global _rec
+    if _rec is None:
+        return fn()
+    rec = _rec
+    rec.flush()
+    rec.plan.items.append(("py", fn, None))
+    _rec = None
+    try:
+        return fn()
+    finally:
+        _rec = rec
+
+
+def delay_us(us: float):
+    """Emulation aid: the current stream waits `us` microseconds (flexam_delay_us)."""
+    _check(lib().flexam_delay_us(float(us), _stream()), "flexam_delay_us")
 
 
 def recording() -> bool:

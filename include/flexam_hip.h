@@ -374,6 +374,11 @@ int flexam_raster_resolve(const unsigned long long* keys, const unsigned char* c
  * declaration order: pointers -> p, float -> f (as double), integers -> i.  flexam_replay calls them in order on `stream`; every call
  * checks its own arguments as usual; it stops at the first failure (its code returned, its message in flexam_last_error(),
  * *failed_at = index; -1 = none).  The list is HOST memory of the caller, read during the call only. */
+/* Emulation aid (not on the product path): one wave that waits `us` microseconds of the constant 100 MHz counter on `stream`.  The
+ * one-GPU emulation of a multi-GPU rank (bench.py --emulate-rank, flexam_amd.dist.LoopbackGroup) puts it where a collective's transfer
+ * time would sit -- bytes per xGMI link / an ASSUMED link rate -- on the side stream RCCL's kernels would occupy. */
+int flexam_delay_us(float us, void* stream);
+
 #define FLEXAM_REPLAY_MAX_ARGS 26
 typedef union { int64_t i; double f; void* p; } flexam_arg;
 typedef struct { int32_t fn; int32_t nargs; flexam_arg a[FLEXAM_REPLAY_MAX_ARGS]; } flexam_cmd;

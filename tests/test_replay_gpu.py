@@ -167,3 +167,38 @@ def test_emulated_rank_replays_with_collectives_as_host_steps():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_delay_kernel_and_the_link_model_of_the_loopback_group():
+    """flexam_delay_us holds a stream for the asked time on the constant 100 MHz counter (the emulated ranks' stand-in for transfer time),
+    and a LoopbackGroup with an assumed link rate holds its side stream for bytes-per-link / rate + latency: an all-gather's time is ONE
+    chunk over one link (every peer's chunk on its own link), an all-to-all's ONE block; it is a host step of a recorded plan, not part
+    of a C segment."""
+    from flexam_amd import hip
+    from flexam_amd.dist import LoopbackGroup, all_gather_into_tensor, all_to_all_blocks
+    for us in (200.0, 1000.0):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        hip.delay_us(50.0)
+        torch.cuda.synchronize()
+        s.record(); hip.delay_us(us); e.record()
+        torch.cuda.synchronize()
+        got = s.elapsed_time(e) * 1e3
+        assert us <= got <= us * 1.15 + 30.0, (us, got)
+    g = LoopbackGroup(4, 1, link_gbps=50.0, latency_us=10.0)
+    chunk = torch.zeros(5 * 1000 * 1000, dtype=torch.uint8, device=DEV)          # 5 MB per peer link -> 100 us at 50 GB/s
+    out = torch.empty(4 * chunk.numel(), dtype=torch.uint8, device=DEV)
+    all_gather_into_tensor(out, chunk, group=g)                                   # warm (stream creation)
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    w = all_gather_into_tensor(out, chunk, group=g, async_op=True)
+    w.wait()
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1)
+    assert 0.105 <= ms <= 0.25, ms                                                # 100 us of "link" + 10 us latency + the copies themselves
+    blocks_in = [torch.zeros(1000 * 1000, dtype=torch.uint8, device=DEV) for _ in range(4)]      # 1 MB per link: 20 us + 10
+    blocks_out = [torch.empty_like(b) for b in blocks_in]
+    with hip.record() as plan:
+        hip.host_op(lambda: all_to_all_blocks(blocks_out, blocks_in, group=g))
+    assert [k for k, _, _ in plan.items] == ["py"] and plan.launches == 0          # the delay kernel inside the host step was not recorded

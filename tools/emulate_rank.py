@@ -25,7 +25,8 @@ if overlap is not None:
     os.environ["FLEXAM_SP_OVERLAP"] = str(overlap)
 sp = world // 2 if cfgp else world
 rank = int(os.environ.get("FLEXAM_EMULATE_WHICH", sp // 2 if sp > 2 else 0))
-set_emulated_layout(model, world, cfgp, rank)
+link = float(os.environ["FLEXAM_EMULATE_LINK_GBPS"]) if os.environ.get("FLEXAM_EMULATE_LINK_GBPS") else None      # assumed GB/s per link and direction
+set_emulated_layout(model, world, cfgp, rank, link_gbps=link)
 i = synthetic_inputs(97, 512, 896, cfg["text_dim"], "motion")
 cond = LatentConditioning(control_latents=i["control"], additional_control=i["additional"], masked_video_latents=i["masked"], ref_latents=i["ref"],
                           mask_latents=i["mask_latents"], mask=i["mask"], mask_pixels=i["mask_pixels"])
@@ -41,5 +42,5 @@ t_enq = time.perf_counter() - t0
 torch.cuda.synchronize()
 sec = (time.perf_counter() - t0) / steps
 eng = model.engine()
-print(f"{name} [replayed launches: {bool(getattr(eng, 'replay_taken', False))}]: rank {rank} of sp{eng.sp_size} (cfg{eng.cfg_size}), {eng.cond['L'] // eng.sp_size} tokens x {1 if eng.cfg_size == 2 else 2} sample(s): "
+print((f"[links modelled at {link:g} GB/s per direction] " if link else "") + f"{name} [replayed launches: {bool(getattr(eng, 'replay_taken', False))}]: rank {rank} of sp{eng.sp_size} (cfg{eng.cfg_size}), {eng.cond['L'] // eng.sp_size} tokens x {1 if eng.cfg_size == 2 else 2} sample(s): "
       f"{sec * 1e3:.2f} ms per step, host enqueue {t_enq / steps * 1e3:.2f} ms")
