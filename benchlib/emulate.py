@@ -123,7 +123,7 @@ def emulate(model, make_pipe, inp, cond, world: int, steps: int, warmup: int, to
                     set_emulated_layout(model, world, cfgp, r, link_gbps=rate)
                     pipe = make_pipe()
                     pipe.prepare(inp["latents"], cond, inp["ctx_c"], inp["ctx_u"], density=0.1, guidance_scale=6.0, num_inference_steps=total_steps)
-                    ml = measure_rank_step(lambda i: pipe.denoise_step(i % total_steps), torch.cuda.synchronize, min(steps, 6), min(warmup, 2))
+                    ml = measure_rank_step(lambda i: pipe.denoise_step(i % total_steps), torch.cuda.synchronize, min(steps, 8), min(warmup, 2))
                     rows[-1]["ms_per_step_at_link_GBps"][f"{rate:g}"] = ml["sec"] * 1e3
                     del pipe
     finally:
