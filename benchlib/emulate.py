@@ -55,6 +55,8 @@ def layouts(world: int, num_heads: int):
         out.append((f"cfg1 x sp{world}, K|V all-gather", "allgather", False, None, None))
     if world >= 4 and world % 2 == 0:
         out.append((f"cfg2 x sp{world // 2}, K|V all-gather with local-chunk-first attention under it (FLEXAM_SP_OVERLAP=1)", "allgather", True, None, "1"))
+    if world >= 4 and num_heads % world == 0:
+        out.append((f"cfg1 x sp{world}, all-to-all over heads, attention per sample (FLEXAM_SP_OVERLAP=2)", "ulysses", False, None, "2"))
     return out
 
 

@@ -163,7 +163,7 @@ def test_one_gpu_line_carries_an_emulated_rank_of_four():
     assert res["n_gpus"] == 1 and "invalid" not in res and em["world"] == 4
     names = [row["layout"] for row in em["layouts"]]
     assert names[0].startswith("cfg2 x sp2, K|V all-gather") and names[1].startswith("cfg1 x sp4, all-to-all over heads")
-    assert names[2].startswith("cfg2 x sp2, all-to-all over heads") and "FLEXAM_SP_OVERLAP=1" in names[3] and len(names) == 4
+    assert names[2].startswith("cfg2 x sp2, all-to-all over heads") and "FLEXAM_SP_OVERLAP=1" in names[3] and "FLEXAM_SP_OVERLAP=2" in names[4] and len(names) == 5
     assert all(row["host_share_of_step"] > 0 and row["ms_per_step_compute_only"] > 0 for row in em["layouts"])
     assert set(em["predicted_scaling_compute_only"]) == set(names) and "idle" in em["host_enqueue_note"]
     assert any(row["replayed_launches"] for row in em["layouts"])            # launch plans: the timed steps re-issue the recorded launches
