@@ -31,7 +31,9 @@ int flexam_current_device() {
   return dev < FLEXAM_MAX_DEVICES ? dev : FLEXAM_MAX_DEVICES - 1;
 }
 
-int flexam_num_cus() {
+static int g_cu_budget[FLEXAM_MAX_DEVICES] = {};         // flexam_set_cu_budget: 0 = all of the device's CUs
+
+static int hardware_cus() {
   static int cus[FLEXAM_MAX_DEVICES] = {};               // filled on first use per device (benign race: same value)
   const int dev = flexam_current_device();
   if (cus[dev] == 0) {
@@ -41,6 +43,22 @@ int flexam_num_cus() {
     cus[dev] = n;
   }
   return cus[dev];
+}
+
+int flexam_num_cus() {
+  const int n = hardware_cus(), b = g_cu_budget[flexam_current_device()];
+  return b > 0 && b < n ? b : n;
+}
+
+// The CUs the library plans its persistent grids for (one workgroup per CU, all of its LDS and registers).  A kernel that owns EVERY CU
+// leaves nothing for a collective's kernels to run on beside it: a workgroup of RCCL (or the emulation's delay wave) then waits for the
+// launch to end, or -- when it got there first -- one of our 256 workgroups waits for IT.  Under an exchange that is meant to travel
+// beside compute a few CUs are therefore left out of the plan (8 = one per XCD: -3 % of the matrix rate).
+extern "C" int flexam_set_cu_budget(int cus) {
+  const int n = hardware_cus();
+  FX_REQUIRE(cus == 0 || (cus >= 8 && cus <= n && cus % 8 == 0), FLEXAM_E_ARG, "set_cu_budget: %d (0 = all, or a multiple of 8 in 8 .. %d)", cus, n);
+  g_cu_budget[flexam_current_device()] = cus;
+  return FLEXAM_OK;
 }
 
 extern "C" int flexam_device_cus(void) { return flexam_num_cus(); }

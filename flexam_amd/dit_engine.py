@@ -187,6 +187,12 @@ class DiTEngine:
             raise ValueError(f"FLEXAM_SP_PIECES={pieces}: must divide the {self.nh} heads")
         self.sp_pieces = pieces if sp_size > 1 else 1
         self.sp_fused_qkv = os.environ.get("FLEXAM_SP_FUSED_QKV", "1") != "0"
+        # FLEXAM_CU_BUDGET=<n>: plan the persistent grids for n CUs (a multiple of 8) while this layout runs collectives beside compute --
+        # a kernel that owns every CU leaves a collective's own kernels nowhere to run until it ends.  Not set by default: on one GPU
+        # the emulation's stand-in (a single delay wave) finds room beside the GEMMs, and 8 CUs cost 3 % of a rank's step
+        # (profiles/r6s_*); what RCCL's kernels need on a real node is the first thing to measure there.
+        if os.environ.get("FLEXAM_CU_BUDGET"):
+            hip.set_cu_budget(int(os.environ["FLEXAM_CU_BUDGET"]) if sp_size > 1 else 0)
         self.world_group = world_group if cfg_size > 1 else sp_group
         self.world_size = world_size if world_size is not None else sp_size
         self.cfg_size, self.cfg_row = cfg_size, cfg_row
@@ -645,7 +651,7 @@ class DiTEngine:
         if use_plan:
             pkey = (self._ws_gen, B, lc, only_row, bool(share0), bool(sage), self.fp8, fp8_oproj, R, rows_per_batch,
                     row_index.data_ptr() if row_index is not None else 0, tabs["blk"].data_ptr(), cd["cos"].data_ptr(),
-                    torch.cuda.current_stream().cuda_stream, os.environ.get("FLEXAM_SAGE_FUSED", "1"), os.environ.get("FLEXAM_FP8_FFN_APRIORI", "1"),
+                    torch.cuda.current_stream().cuda_stream, hip.num_cus(), os.environ.get("FLEXAM_SAGE_FUSED", "1"), os.environ.get("FLEXAM_FP8_FFN_APRIORI", "1"),
                     sp, rank, getattr(self, "sp_mode", None), getattr(self, "sp_pieces", 1), getattr(self, "sp_overlap_level", 0),
                     getattr(self, "sp_fused_qkv", True), id(self.sp_group))
             plans = cd.setdefault("_plans", {})

@@ -23,6 +23,7 @@ _SIGNATURES = {
     "flexam_last_error": ([], c_char_p),
     "flexam_device_check": ([], c_int),
     "flexam_device_cus": ([], c_int),
+    "flexam_set_cu_budget": ([_I], c_int),
     "flexam_gemm_bf16": ([_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _I, _P, _P, _L, _P], c_int),
     "flexam_gemm_bf16_gate_residual": ([_P, _L, _P, _L, _P, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P, _P, _L, _P], c_int),
     "flexam_quantize_rows_fp8": ([_P, _L, _P, _L, _P, _L, _I, _P], c_int),
@@ -300,6 +301,11 @@ BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 
 def device_check():
     _check(lib().flexam_device_check(), "flexam_device_check")
+
+
+def set_cu_budget(cus: int = 0):
+    """Plan the library's persistent grids for `cus` CUs of the current device (0 = all); see flexam_set_cu_budget."""
+    _check(lib().flexam_set_cu_budget(int(cus)), "flexam_set_cu_budget")
 
 
 def num_cus() -> int:

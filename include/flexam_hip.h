@@ -44,6 +44,11 @@ int flexam_device_check(void);        /* FLEXAM_E_ARCH unless the current device
  * of 8: one persistent workgroup per CU, blockIdx & 7 = XCD; 256 on MI355X).  Callers that plan work units themselves -- the
  * key split of flexam_attn_fwd_splitkv -- use the same figure. */
 int flexam_device_cus(void);
+/* Plan the persistent grids of the current device for `cus` compute units (a multiple of 8: blockIdx & 7 stays the XCD; 0 = all of them,
+ * the default) -- flexam_device_cus() answers with the budget from then on.  For callers that run collectives BESIDE these kernels: a
+ * one-workgroup-per-CU kernel on every CU leaves a collective's own kernels nowhere to run until it ends (flexam_amd/dit_engine.py sets 8
+ * CUs aside under the overlapped sequence-parallel exchanges).  Process-global per device, not stream-ordered: set it between launches. */
+int flexam_set_cu_budget(int cus);
 
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]); A, W bf16 row-major with K contiguous (nn.Linear
  * weight layout), fp32 accumulate on MFMA; C bf16 (out_f32 = 0) or fp32 (out_f32 = 1).

@@ -199,6 +199,30 @@ def test_gemm_192_wide_tile_shape_exact(H, m, n, k, monkeypatch):
         assert torch.equal(u, v)                                # the same bits as the 256-wide plans (GELU included: same fp32 sums)
 
 
+def test_cu_budget_plans_the_persistent_grids_for_fewer_cus(H):
+    """flexam_set_cu_budget (r6): the library plans its one-workgroup-per-CU grids for a multiple of 8 CUs below the device's count (room
+    for a collective's kernels beside compute); flexam_device_cus answers with the budget, results do not change, 0 restores all CUs."""
+    full = H.num_cus()
+    g = torch.Generator().manual_seed(8)
+    m, n, k = 5000, 3072, 512
+    a = torch.randint(-2, 3, (m, k), generator=g).float()
+    w = torch.randint(-2, 3, (n, k), generator=g).float()
+    want = a @ w.t()
+    q, kk, v = (torch.randn(1, 3000, 4, 128, generator=g).to(BF).to(dev()) for _ in range(3))
+    try:
+        base = H.attn_fwd(q, kk, v)
+        H.set_cu_budget(full - 8)
+        assert H.num_cus() == full - 8
+        torch.testing.assert_close(H.gemm(bf(a).to(dev()), bf(w).to(dev()), out_dtype=torch.float32).cpu(), want, rtol=0, atol=0)
+        assert_bf16_close(H.attn_fwd(q, kk, v), base.float().cpu(), ulps=2.0, atol=1e-3, msg="attention under a CU budget")      # (another tail split plan)
+        for bad in (4, full + 8, full - 3):
+            with pytest.raises(RuntimeError):
+                H.set_cu_budget(bad)
+    finally:
+        H.set_cu_budget(0)
+    assert H.num_cus() == full
+
+
 @pytest.mark.parametrize("mt", [4, 5, 6, 7, 8])
 def test_gemm_every_tile_height_exact(H, mt, monkeypatch):
     """The launch heuristic picks a tile height (32*MT rows) per shape; force each one and check exact integer results on

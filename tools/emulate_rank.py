@@ -17,6 +17,9 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 warm = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
+if os.environ.get("FLEXAM_CU_BUDGET"):                  # plan the persistent grids for fewer CUs (the rest stay free for the collectives' kernels)
+    from flexam_amd import hip
+    hip.set_cu_budget(int(os.environ["FLEXAM_CU_BUDGET"]))
 cfg = dict(WAN22_FUN_5B_FLEXAM)
 model = build_model(cfg, dev)
 name, mode, cfgp, pieces, overlap = layouts(world, model.num_heads)[which]
