@@ -24,6 +24,7 @@ ap.add_argument("--w", type=int, default=28)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--host-oracle", choices=["seeded", "all", "none"], default="seeded")
 ap.add_argument("--scales", type=float, nargs="*", default=[1.0, 6.0])
+ap.add_argument("--fp8", action="store_true", help="also run the fp8 QKV / FFN variant (BASELINE configs[4]) and fp8 + MXFP8 attention")
 args = ap.parse_args()
 
 torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -77,6 +78,18 @@ for S in args.scales:
         out8 = m(**dcase).float().cpu()
     finally:
         os.environ.pop("VIDEOX_ATTENTION_TYPE")
+    out_f8 = out_f8s = None
+    if args.fp8:
+        m.enable_fp8_gemm(True)
+        try:
+            out_f8 = m(**dcase).float().cpu()
+            os.environ["VIDEOX_ATTENTION_TYPE"] = "SAGE_ATTENTION"
+            try:
+                out_f8s = m(**dcase).float().cpu()
+            finally:
+                os.environ.pop("VIDEOX_ATTENTION_TYPE")
+        finally:
+            m.enable_fp8_gemm(False)
     t0 = time.time()
     want = oracle_on_gpu(False)
     t1 = time.time()
@@ -90,4 +103,6 @@ for S in args.scales:
               f"psnr {C.psnr(want, host):.1f} dB; HIP bf16 vs the HOST-run oracle rel-rms {rel(out, host):.3e} psnr {C.psnr(out, host):.1f} dB", flush=True)
     print(f"  {nl} layers, L = {L}, batch {args.batch}, logit std {S:g}: HIP bf16 vs fp32 oracle rel-rms {rel(out, want):.3e} psnr {C.psnr(out, want):.1f} dB | "
           f"bf16-emulated oracle vs fp32 oracle rel-rms {rel(emu, want):.3e} psnr {C.psnr(emu, want):.1f} dB | "
-          f"HIP with MXFP8 self-attention rel-rms {rel(out8, want):.3e} psnr {C.psnr(out8, want):.1f} dB", flush=True)
+          f"HIP with MXFP8 self-attention rel-rms {rel(out8, want):.3e} psnr {C.psnr(out8, want):.1f} dB"
+          + (f" | fp8 QKV / FFN rel-rms {rel(out_f8, want):.3e} psnr {C.psnr(out_f8, want):.1f} dB | fp8 + MXFP8 attention rel-rms {rel(out_f8s, want):.3e} "
+             f"psnr {C.psnr(out_f8s, want):.1f} dB" if out_f8 is not None else ""), flush=True)
