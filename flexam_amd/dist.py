@@ -86,10 +86,18 @@ class LoopbackGroup:
         self._filled = set()                           # (copies = False) buffers that received their one-off fill
         self._stream = None
 
+    _side_streams = {}                                 # one side stream per device for ALL loopback groups of the process
+
     def side_stream(self, device):
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=device)
-        return self._stream
+        """The stream the stand-ins run on -- the place RCCL's own stream has in a real run.  ONE per device and process (ROCm maps
+        streams onto a few hardware queues; a fresh stream per group landed on the compute stream's queue every few groups and the
+        "collective" then serialised with compute: two timing regimes 10 ms per step apart, profiles/r6u_*), high priority like RCCL's."""
+        key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+        st = LoopbackGroup._side_streams.get(key)
+        if st is None:
+            st = LoopbackGroup._side_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+        self._stream = st
+        return st
 
     def run(self, fn, ref: torch.Tensor, async_op: bool, link_bytes: int = 0):
         """`fn()` (the copies) after everything enqueued so far on the caller's stream; returns a Work (async) or None (joined).
