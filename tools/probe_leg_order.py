@@ -1,3 +1,6 @@
+"""Dev probe (r6u): the emulated overlapped K|V gather of a rank of 8 (cfg2 x sp4, FLEXAM_SP_OVERLAP=1) in ONE process, legs with the links modelled at
+the given rates in the given order (`none` = no link model) -- found that a fresh side stream per loopback group aliased the compute stream's hardware
+queue every few groups (two timing regimes).  usage: probe_leg_order.py none 50 75 75 50 75   [FLEXAM_CU_BUDGET=248 to leave 8 CUs free]"""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 os.chdir("/root/repo")
