@@ -25,7 +25,6 @@
 //    chunks of the tile list, walked in groups of 4 tile-rows so concurrently resident tiles
 //    share A row-panels and W column-panels in L2 (FLEXAM_GEMM_GM overrides the group height).
 #include <math.h>
-#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -59,7 +58,6 @@ struct GemmParams {
   // (gemm_splitk_finish_kernel) adds the slices up in slice order and runs the epilogue
   int units, split_full, split_s;
   float* ws;
-  int stagger_groups, stagger_ticks;   // EXPERIMENT: workgroup group g = (blockIdx / 8) % groups starts g * ticks (100 MHz) late
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -140,13 +138,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   asm volatile("" : "+s"(wave));
   const int wm = wave / WNW, wn = wave % WNW;
-  if (!TAIL && p.stagger_ticks) {
-    const int grp = ((int)blockIdx.x >> 3) % p.stagger_groups;
-    if (grp) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)(grp * p.stagger_ticks)) __builtin_amdgcn_s_sleep(4);
-    }
-  }
 
   // ---- persistent workgroups over an XCD-aware, grouped tile order: workgroup w lives on XCD w & 7 (round-robin
   // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
@@ -889,11 +880,6 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
     const char* g = getenv("FLEXAM_GEMM_GM");
     p.gm = g ? atoi(g) : (EPI == EPI_GATE_RESIDUAL && a_koff == nullptr && p.K >= 8192 ? 1 : 4);
     if (p.gm < 1) p.gm = 4;
-  }
-  {
-    const char* e = getenv("FLEXAM_GEMM_STAGGER");      // EXPERIMENT "groups:microseconds"
-    int g = 0; float us = 0.f;
-    if (e && sscanf(e, "%d:%f", &g, &us) == 2 && g > 1 && us > 0.f) { p.stagger_groups = g; p.stagger_ticks = (int)(us * 100.f); }
   }
 #ifdef FLEXAM_GEMM_ABLATE
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
