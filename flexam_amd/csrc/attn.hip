@@ -159,8 +159,8 @@ __device__ __forceinline__ float pair_sum(float x) {
 // (A 4-wave x 64-row variant -- each K/V fragment feeding two MFMAs -- was tried in r1: hipcc cannot keep
 //  Q in the accumulator file and spills 150+ VGPRs; see DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
-#if (defined(FLEXAM_ATTN_STAMPS) || defined(A32_NOMAX_ABLATE) || defined(A32_VALU) || defined(FLEXAM_ATTN_BODY16)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
-#error "FLEXAM_ATTN_STAMPS / A32_NOMAX_ABLATE / A32_VALU / FLEXAM_ATTN_BODY16 are switches of diagnostic builds (timing ablations give WRONG results): add -DFLEXAM_DIAGNOSTIC_BUILD (tools/build_attn_variants.py does)"
+#if (defined(FLEXAM_ATTN_STAMPS) || defined(A32_NOMAX_ABLATE) || defined(A32_VALU) || defined(FLEXAM_ATTN_BODY16) || defined(A32_RESCALE_THR)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
+#error "FLEXAM_ATTN_STAMPS / A32_NOMAX_ABLATE / A32_VALU / FLEXAM_ATTN_BODY16 / A32_RESCALE_THR are switches of diagnostic builds (timing ablations give WRONG results): add -DFLEXAM_DIAGNOSTIC_BUILD (tools/build_attn_variants.py does)"
 #endif
 #ifndef A32_DEFER
 #define A32_DEFER 0      // scores of a half tile whose exp2 / sum / pack wait for part A of the next step (see stepA); 0 = none
@@ -188,7 +188,16 @@ constexpr int NSLOT = 4;
 constexpr int V_RING = NSLOT * KV_TILE_BYTES;   // LDS: [4 K slots][4 V slots]
 template <int V>
 using IC = std::integral_constant<int, V>;
+// Deferred-rescale threshold in exp2 units.  A trade, measured in r6 (profiles/r6zb_*): every deferral leaves the row's dominant key at a
+// P that is not exactly 1, i.e. with a bf16 rounding error the exact-maximum form does not have -- attention error against fp64 on
+// peaked rows (logit std 6, L = 11648) 1.51e-3 rms at 2^0, 1.77e-3 at 2^8, 2.10e-3 at 2^24 -- while the rescale branch costs
+// +1.2 % of a denoise step at 2^4 and -0.5 / -0.9 / -1.3 ... -2.1 % at 2^12 / 2^16 / 2^24 on such rows (nothing on N(0, 1) logits).
+// 8 stays: parity before speed.  -DA32_RESCALE_THR=n builds the other points (diagnostic builds).
+#ifdef A32_RESCALE_THR
+constexpr float RESCALE_THR_LOG2 = (float)A32_RESCALE_THR;
+#else
 constexpr float RESCALE_THR_LOG2 = 8.0f;
+#endif
 
 // KIND: 0 = self-attention, 1 = short-context (text) attention: distinct profiler symbols.
 // PRE: q was multiplied by softmax_scale * log2(e) by its producer, BEFORE its one rounding to bf16 (in the DiT: folded into the

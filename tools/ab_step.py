@@ -1,7 +1,7 @@
 """Dev tool: IN-STEP same-process A/B.  Builds bench.py's pipeline once (97x512x896, 30 layers, CFG pair) and alternates groups of
 denoise steps between arms; an arm is VAR=value (an environment switch the library reads per call) or lib=NAME
 (tools/probes/libflexam_var_NAME.so, `tree` = the in-tree library; the kernels are stateless, so the library can be swapped between
-steps).  usage: ab_step.py ARM ARM ... [--steps=3] [--rounds=5] [--fp8=1]; prints the median ms per step of every arm."""
+steps).  usage: ab_step.py ARM ARM ... [--steps=3] [--rounds=5] [--fp8=1] [--logit=6]; prints the median ms per step of every arm."""
 import os, sys, time, statistics
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -18,6 +18,8 @@ steps, rounds = opt.get("steps", 3), opt.get("rounds", 5)
 dev = torch.device("cuda:0"); torch.cuda.set_device(0)
 cfg = dict(WAN22_FUN_5B_FLEXAM)
 model = bench.build_model(cfg, dev)
+if opt.get("logit", 0):
+    bench.set_logit_scale(model, float(opt["logit"]))          # --logit=6: peaked softmax rows (bench.py --logit-scale), for every arm
 if opt.get("fp8", 0):
     model.enable_fp8_gemm(True)                 # --fp8=1: the QKV / FFN GEMMs on the fp8 pipe (BASELINE configs[4] variant) for every arm
 pipe = Wan2_2FunControlPipeline_FlexAM(transformer=model)
