@@ -25,7 +25,7 @@ def timeit(fn, n=10):
     return (time.perf_counter() - t0) / n
 
 
-M = 23296
+M = int(os.environ.get("FLEXAM_AB_M", "23296"))          # 2912 = one rank of eight
 x = torch.randn(M, 3072, device=dev)
 gate = torch.randn(4, 3072, device=dev)
 rows = torch.randint(0, 4, (M,), dtype=torch.int32, device=dev)
