@@ -109,3 +109,25 @@ def test_emulated_rank_host_time_does_not_move_with_the_step_count():
         assert 0.0018 < m["host_sec"] < 0.0045, (steps, m)   # ~2 ms of host work per step, not the ~10 ms of a back-pressured loop
         assert 0.009 < m["sec"] < 0.013, (steps, m)
     assert abs(res[2]["host_sec"] - res[20]["host_sec"]) < 0.0015
+
+
+def test_probe_candidates_and_emulated_layouts_are_consistent_decompositions():
+    """The layout probe of a multi-GPU run and the emulated ranks of the single-GPU line describe the same exchanges: the first candidate is
+    the library's default (one K|V gather per block, waited for), every all-to-all form has heads divisible by its sequence-parallel ranks,
+    names are unique, and a width whose heads do not divide offers the gathers only."""
+    from benchlib.emulate import layouts
+    from benchlib.probe import candidates
+    for world in (4, 8):
+        cands = candidates(world, 24)
+        assert cands[0][1:] == ("allgather", True, "0", "1") and "default" in cands[0][0]
+        assert len({c[0] for c in cands}) == len(cands)
+        for name, mode, cfgp, overlap, pieces in cands:
+            sp = world // 2 if cfgp else world
+            assert f"sp{sp}" in name and f"cfg{2 if cfgp else 1}" in name
+            assert mode in ("allgather", "ulysses") and (mode != "ulysses" or 24 % sp == 0)
+        rows = layouts(world, 24)
+        assert len(rows) == 5 and rows[0][1:3] == ("allgather", True) and len({r[0] for r in rows}) == 5
+        assert {(m, c) for _, m, c, _, _ in rows} == {(m, c) for _, m, c, _, _ in cands}
+    assert [c[1] for c in candidates(8, 20)] == ["allgather"] * 3 + ["ulysses"]          # 20 heads: only cfg2 x sp4 divides
+    assert all(c[1] == "allgather" for c in candidates(8, 6))                             # 6 heads: neither 8 nor 4 ranks divide
+    assert [r[1:3] for r in layouts(2, 24)] == [("allgather", True), ("allgather", False)]
