@@ -166,7 +166,7 @@ ATTN_TRAFFIC_FILE = "profiles/head_attn_traffic.json"
 
 # compile-time switches of DIAGNOSTIC builds (tools/build_attn_variants.py, -DFLEXAM_DIAGNOSTIC_BUILD): never defined in the product
 # library, so the text they guard is not part of what the counter record was measured on
-ATTN_DIAGNOSTIC_MACROS = ("FLEXAM_ATTN_STAMPS", "A32_NOMAX_ABLATE", "A32_VALU", "FLEXAM_ATTN_BODY16", "A32_RESCALE_THR", "FLEXAM_DIAGNOSTIC_BUILD")
+ATTN_DIAGNOSTIC_MACROS = ("FLEXAM_ATTN_STAMPS", "A32_NOMAX_ABLATE", "A32_VALU", "FLEXAM_ATTN_BODY16", "A32_RESCALE_THR", "A32_HALF_FRAG_ABLATE", "FLEXAM_DIAGNOSTIC_BUILD")
 
 
 def product_text(src: str, undefined=ATTN_DIAGNOSTIC_MACROS) -> str:

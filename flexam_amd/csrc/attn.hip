@@ -159,8 +159,8 @@ __device__ __forceinline__ float pair_sum(float x) {
 // (A 4-wave x 64-row variant -- each K/V fragment feeding two MFMAs -- was tried in r1: hipcc cannot keep
 //  Q in the accumulator file and spills 150+ VGPRs; see DESIGN.md.)
 // ------------------------------------------------------------------------------------------------
-#if (defined(FLEXAM_ATTN_STAMPS) || defined(A32_NOMAX_ABLATE) || defined(A32_VALU) || defined(FLEXAM_ATTN_BODY16) || defined(A32_RESCALE_THR)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
-#error "FLEXAM_ATTN_STAMPS / A32_NOMAX_ABLATE / A32_VALU / FLEXAM_ATTN_BODY16 / A32_RESCALE_THR are switches of diagnostic builds (timing ablations give WRONG results): add -DFLEXAM_DIAGNOSTIC_BUILD (tools/build_attn_variants.py does)"
+#if (defined(FLEXAM_ATTN_STAMPS) || defined(A32_NOMAX_ABLATE) || defined(A32_VALU) || defined(FLEXAM_ATTN_BODY16) || defined(A32_RESCALE_THR) || defined(A32_HALF_FRAG_ABLATE)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
+#error "FLEXAM_ATTN_STAMPS / A32_NOMAX_ABLATE / A32_VALU / FLEXAM_ATTN_BODY16 / A32_RESCALE_THR / A32_HALF_FRAG_ABLATE are switches of diagnostic builds (timing ablations give WRONG results): add -DFLEXAM_DIAGNOSTIC_BUILD (tools/build_attn_variants.py does)"
 #endif
 #ifndef A32_DEFER
 #define A32_DEFER 0      // scores of a half tile whose exp2 / sum / pack wait for part A of the next step (see stepA); 0 = none
@@ -359,8 +359,13 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     constexpr int ghalf = decltype(ghalf_c)::value, ds0 = decltype(ds0_c)::value;
     constexpr int slot = (ghalf >> 1) & (NSLOT - 1);
     constexpr int imm = slot * KV_TILE_BYTES + (ghalf & 1) * 8192;
+#ifdef A32_HALF_FRAG_ABLATE     // TIMING ABLATION (WRONG results): half the K / V fragment reads per MFMA, everything else as it is -- the ceiling of what
+#pragma unroll                  // a tiling with 64 query rows per wave (each fragment feeding two MFMAs) could win at THIS occupancy
+    for (int i = 0; i < 2; ++i) kf[i] = kf[2 + i] = *(const bf16x8*)(kaddr[ds0 + i] + imm);
+#else
 #pragma unroll
     for (int i = 0; i < 4; ++i) kf[i] = *(const bf16x8*)(kaddr[ds0 + i] + imm);
+#endif
   };
   // ... and their 4 MFMAs of the S^T chain
   auto qk_mma = [&](auto ds0_c, const bf16x8 (&kf)[4], f32x16& sacc) {
@@ -419,7 +424,11 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
     for (int ss = 0; ss < 2; ++ss) {
       bf16x8 vf[4];
 #pragma unroll
+#ifdef A32_HALF_FRAG_ABLATE
+      for (int dt = 0; dt < 2; ++dt) {
+#else
       for (int dt = 0; dt < 4; ++dt) {                                                   // 8 transposed reads first ...
+#endif
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[0][dt] + imm + ss * 4096));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vaddr[1][dt] + imm + ss * 4096));
         const bf16x4 lo_b = __builtin_bit_cast(bf16x4, lo), hi_b = __builtin_bit_cast(bf16x4, hi);
@@ -429,6 +438,9 @@ __global__ __launch_bounds__(NT, 2) void attn_fwd_kernel(AttnParams p) {
           vf[dt][4 + e] = hi_b[e];
         }
       }
+#ifdef A32_HALF_FRAG_ABLATE
+      vf[2] = vf[0]; vf[3] = vf[1];
+#endif
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)                                                     // ... then 4 MFMAs
         o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt], pf_prev[ss], o_acc[dt], 0, 0, 0);

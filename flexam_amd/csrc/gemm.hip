@@ -64,8 +64,8 @@ struct GemmParams {
 template <int V>
 using IC = std::integral_constant<int, V>;
 
-#if defined(FLEXAM_GEMM_ABLATE) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
-#error "FLEXAM_GEMM_ABLATE builds give WRONG results (timing ablations): add -DFLEXAM_DIAGNOSTIC_BUILD"
+#if (defined(FLEXAM_GEMM_ABLATE) || defined(FLEXAM_GEMM_HALF_FRAG)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
+#error "FLEXAM_GEMM_ABLATE / FLEXAM_GEMM_HALF_FRAG builds give WRONG results (timing ablations): add -DFLEXAM_DIAGNOSTIC_BUILD"
 #endif
 #ifdef FLEXAM_GEMM_ABLATE
 #define ABLATE(p, bit) ((p).debug & (bit))
@@ -353,6 +353,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   frag_setup();
 #pragma unroll
   for (int g = 0; g < (NF + PER - 1) / PER; ++g) ld2(smem, 0, g, f0);
+#ifdef FLEXAM_GEMM_HALF_FRAG
+#pragma unroll
+  for (int j = 0; j < NF; ++j) f1[j] = f0[j];
+#endif
 
   auto block = [&](int kb, auto dma_c, auto rd_c, auto wait_c) {
     constexpr bool DMA = decltype(dma_c)::value, RD = decltype(rd_c)::value;
@@ -364,7 +368,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
       __builtin_amdgcn_sched_barrier(0);
       mfma_group(g, f0);
       __builtin_amdgcn_sched_barrier(0);                // MFMAs first: the wait for F0 must not cover reads issued after it
-      if (!ABLATE(p, 8)) ld2(cur, 1, g, f1);            // 8: no phase-A fragment reads (half the ds_reads)
+#ifndef FLEXAM_GEMM_HALF_FRAG                           // (compile-time form of ablation 8, without its run-time tests in the loop: the ceiling of
+      if (!ABLATE(p, 8)) ld2(cur, 1, g, f1);            //  what fewer fragment reads per MFMA -- 128 x 128 wave tiles: a third fewer -- could win)  8: no phase-A fragment reads (half the ds_reads)
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     wait_barrier(wait_c);
