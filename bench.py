@@ -268,6 +268,13 @@ def main():
         torch.cuda.empty_cache()
         vae_sec, enc_stream_sec, enc_image_sec, vae_finite, vae = time_vae(device, args.frames, args.height, args.width)
         enc_sec = 7 * enc_stream_sec + enc_image_sec     # control, depth, 4 cos levels, masked video + the reference image
+        band_sec = None
+        if n_emulate and n_emulate > 1:
+            try:                                         # one rank's row band of the N-rank parallel decode (for the predicted sec/clip below)
+                from benchlib.vae_clip import time_decode_band
+                band_sec = time_decode_band(vae, device, args.frames, args.height, args.width, n_emulate)
+            except Exception as e:                       # noqa: BLE001
+                band_sec = None
         finite = finite and vae_finite
         try:                                             # the step before the encode: tracks -> conditioning videos
             from benchlib.vae_clip import time_raster
@@ -354,12 +361,24 @@ def main():
                                              "roofline.launch_ms with the default line of the same box"}
         if emulated is not None:
             from benchlib.emulate import HOST_NOTE
+            clip_pred = None
+            if vae_sec is not None and band_sec is not None:
+                # the clip on N ranks before any link time: the 8 conditioning streams encoded round-robin (dist.shard_streams: ceil(8 / N) per rank),
+                # prepare, 50 rank steps of the layout, this rank's row band of the decode (bands all-gathered: not included)
+                jobs = [enc_stream_sec] * 7 + [enc_image_sec]                     # stream j on rank j % N: the slowest rank's share
+                streams = max(sum(jobs[r::n_emulate]) for r in range(n_emulate))
+                clip_pred = {"vae_encode_sec": streams, "vae_decode_band_sec": band_sec, "prepare_sec": prepare_sec,
+                             "per_layout": {r["layout"]: round(streams + prepare_sec + total_steps * r["ms_per_step"] * 1e-3 + band_sec, 3) for r in emulated if "ms_per_step" in r},
+                             "single_gpu_sec_per_clip": enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec,
+                             "note": "sum of one rank's parts (7 videos + the reference image over the ranks, 50 rank steps, one row band of the decode) measured on "
+                                     "this GPU; no collective is timed: a ceiling, NOT a multi-GPU measurement"}
             result["emulated_ranks"] = {"world": n_emulate, "layouts": emulated, "host_enqueue_note": HOST_NOTE,
                                         "predicted_scaling_no_comm": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step"], 3) for r in emulated if "ms_per_step" in r},
                                         "predicted_scaling_compute_only": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step_compute_only"], 3)
                                                                            for r in emulated if "ms_per_step_compute_only" in r},
                                         "predicted_scaling_at_link_GBps": {r["layout"]: {k: round(elapsed / args.steps * 1e3 / v, 3) for k, v in r["ms_per_step_at_link_GBps"].items()}
                                                                            for r in emulated if "ms_per_step_at_link_GBps" in r},
+                                        "predicted_sec_per_clip_no_comm": clip_pred,
                                         "link_time_note": __import__("benchlib.emulate", fromlist=["LINK_NOTE"]).LINK_NOTE,
                                         "compute_only_note": "the same rank step with collectives that move nothing (stream plumbing only): predicted_scaling_no_comm keeps "
                                                              "the same-size device copies as a stand-in for the bytes a rank receives; where a gather is waited for, "

@@ -40,6 +40,21 @@ def time_vae(device, frames, height, width):
     return sec, enc[0], enc[1], finite, vae
 
 
+def time_decode_band(vae, device, frames, height, width, world, which=None):
+    """One rank's share of the row-band parallel decode (AutoencoderKLWan3_8.enable_parallel_decode: every rank decodes 1/N of the output
+    rows exactly, one all-gather of the bands assembles the clip): the band of rank `which` (default: a middle one, halos on both sides)
+    of a `world`-rank decode, timed on this GPU; the all-gather of the bands is not included.  -> seconds."""
+    eng = vae.engine()
+    z = torch.randn(48, (frames - 1) // 4 + 1, height // 16, width // 16, device=device)
+    r = world // 2 if which is None else which
+    eng.decode(z, stripe=(r, world))                 # warm-up (this band's buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.decode(z, stripe=(r, world))
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
 def time_clip(model, vae, inp, frames, height, width, steps, device):
     """ONE clip end to end through the drop-in call the reference's demo makes (PIPE.py:505-965 via pipelines.py:1174-1190):
     pixel-space conditioning streams -> VAE encode of the 8 streams -> `steps` denoise steps -> VAE decode -> frames on the

@@ -86,29 +86,34 @@ def test_emulated_rank_host_time_does_not_move_with_the_step_count():
     two-step region it does not -- and the reported host time is the same for 2 and 20 steps."""
     import time
     from benchlib.emulate import measure_rank_step
+    HOST, DEV, QUEUE = 0.005, 0.025, 0.0375              # (the docstring's 2 / 10 / 15 ms, scaled: sleep() jitter on a loaded host is ~1 ms)
 
     class Device:
         def __init__(self):
             self.free_at = time.perf_counter()            # when the device has finished everything enqueued so far
         def step(self, i):
-            t = time.perf_counter()
-            time.sleep(0.002)                             # the host's own work for one step
+            time.sleep(HOST)                              # the host's own work for one step
             start = max(self.free_at, time.perf_counter())
-            self.free_at = start + 0.010
+            self.free_at = start + DEV
             backlog = self.free_at - time.perf_counter()
-            if backlog > 0.015:                           # queue full: the enqueue call blocks until there is room
-                time.sleep(backlog - 0.015)
+            if backlog > QUEUE:                           # queue full: the enqueue call blocks until there is room
+                time.sleep(backlog - QUEUE)
         def sync(self):
             time.sleep(max(0.0, self.free_at - time.perf_counter()))
 
-    res = {}
-    for steps in (2, 20):
-        d = Device()
-        res[steps] = measure_rank_step(d.step, d.sync, steps, 1)
-    for steps, m in res.items():
-        assert 0.0018 < m["host_sec"] < 0.0045, (steps, m)   # ~2 ms of host work per step, not the ~10 ms of a back-pressured loop
-        assert 0.009 < m["sec"] < 0.013, (steps, m)
-    assert abs(res[2]["host_sec"] - res[20]["host_sec"]) < 0.0015
+    def attempt():
+        res = {}
+        for steps in (2, 20):
+            d = Device()
+            res[steps] = measure_rank_step(d.step, d.sync, steps, 1)
+        for steps, m in res.items():
+            assert 0.9 * HOST < m["host_sec"] < 0.5 * DEV, (steps, m)   # the host's own work per step, not the device time of a back-pressured loop
+            assert 0.9 * DEV < m["sec"] < 1.6 * DEV, (steps, m)
+        assert abs(res[2]["host_sec"] - res[20]["host_sec"]) < 0.25 * DEV, res
+    try:
+        attempt()
+    except AssertionError:                                # one more try: a scheduling hiccup of this (shared) host is not what is being tested
+        attempt()
 
 
 def test_probe_candidates_and_emulated_layouts_are_consistent_decompositions():
