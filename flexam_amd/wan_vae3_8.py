@@ -558,8 +558,8 @@ class _DecoderEngine(_EngineBase):
 
     def _chunk(self, src_rows, h, w, first, video, f0, stripe=None, t=1):
         """Decoder3d.forward on `t` latent frames (VAE.py:677-728; the first chunk is always the single first frame); writes 1 or 4 t
-        frames into `video`.  stripe = (cut, a, b): stages < cut run on full frames, then rows [a, b) of the activation entering stage
-        `cut` are kept and everything after works on that row band (`video` is then the band's buffer)."""
+        frames into `video`.  stripe = {stage: (a, b)}: rows [a, b) (relative to the rows it holds at that point) of the activation ENTERING
+        that stage are kept and everything after works on that row band (`video` is then the band's buffer); see stripe_plan."""
         c1 = self.conv1
         hip.vae_prep_cl(src_rows, c1.ci, t, h, w, c1.image(h, w), mode=0, t0=c1.hist)
         x = c1.run(t, h, w, out_dtype=F32)
@@ -567,8 +567,8 @@ class _DecoderEngine(_EngineBase):
         x = self._attention(self.attn, x, t, h, w)
         x = self._res(self.mid[2], x, t, h, w)
         for si, st in enumerate(self.stages):
-            if stripe is not None and si == stripe[0]:
-                _, a, b = stripe
+            if stripe is not None and si in stripe:
+                a, b = stripe[si]
                 band = torch.zeros(t, b - a + 2, w + 2, x.shape[1], device=self.device, dtype=F32)
                 band[:, 1:-1] = x.view(t, h + 2, w + 2, -1)[:, a + 1:b + 1]
                 x, h = band.view(-1, x.shape[1]), b - a
@@ -613,30 +613,41 @@ class _DecoderEngine(_EngineBase):
         return t
 
     def stripe_plan(self, h: int, rank: int, world: int):
-        """Row band of the high-resolution stages for `rank` of `world`.  The low-resolution part of
-        the decoder (conv1, the middle block with its global attention, stages 0-1: about a quarter of the FLOPs) is
-        computed on full frames by every rank; from stage 2 on each rank keeps H/world rows plus a halo equal to the
-        receptive field of the remaining 3x3 convolutions, so the band's interior is EXACT (no seams, no exchange).
-        Returns (cut, a, b, keep_lo, keep_hi, scale): band rows [a, b) at the cut resolution, of which
-        [keep_lo, keep_hi) (in output pixel rows, relative to the band's output) are this rank's."""
-        cut = 2
+        """Row bands of the parallel decode for `rank` of `world`: which rows of the activation ENTERING each stage this rank
+        keeps so that its 1/world of the output rows comes out EXACT with no exchange.  Walking back from the output, the rows a stage
+        must deliver grow by the receptive field of what follows: 1 row for the head conv, 1 (at the upsampled resolution) for a resample
+        conv, 2 per residual block (two 3x3(x3) convs); a 2x upsample halves the range.  conv1 and the middle block (global attention)
+        always run on full frames.  r6: the band is re-cropped at EVERY stage where that removes >= 1/8 of the rows held (r1-r5 cropped
+        once, entering stage 2, and ran stages 0-1 on full frames: 0.47 of a whole decode per rank at 8 ranks; now ~0.3).
+        Returns (crops, keep_lo, keep_hi): crops = {stage: (a, b)} relative to the rows held when entering that stage; the band's video
+        has its own rows at [keep_lo, keep_hi)."""
         n_st = len(self.stages)
-        if n_st <= cut:
-            raise RuntimeError("parallel decode needs at least 3 decoder stages")
-        hc = h * 2 ** sum(1 for st in self.stages[:cut] if st["up"])
-        if hc % world:
-            raise ValueError(f"{hc} rows at the striping resolution do not divide over {world} ranks")
-        halo, res = 0.0, 1.0                                   # rows of context, in units of the cut resolution
-        for st in self.stages[cut:]:
-            halo += 2 * len(st["res"]) / res                   # two 3x3(x3) convs per residual block
+        H = [h]
+        for st in self.stages:
+            H.append(H[-1] * (2 if st["up"] else 1))
+        h_out = 2 * H[-1]                                      # unpatchify doubles the rows once more
+        if h_out % world:
+            raise ValueError(f"{h_out} output rows do not divide over {world} ranks")
+        r0, r1 = rank * h_out // world, (rank + 1) * h_out // world
+        lo, hi = r0 // 2 - 1, -(-r1 // 2) + 1                  # rows of the head conv's input that its 3x3 window touches
+        need = [None] * n_st
+        for si in range(n_st - 1, -1, -1):
+            st = self.stages[si]
+            lo, hi = max(0, lo), min(H[si + 1], hi)
+            if st["up"]:                                       # resample conv: 3x3 at the upsampled resolution = rows (y - 1) // 2 .. (y + 1) // 2 of the low one
+                lo, hi = (lo - 1) // 2, -(-(hi + 1) // 2)
+            lo, hi = lo - 2 * len(st["res"]), hi + 2 * len(st["res"])
+            lo, hi = max(0, lo), min(H[si], hi)
+            need[si] = (lo, hi)
+        crops, cur = {}, (0, H[0])
+        for si, st in enumerate(self.stages):
+            a, b = need[si]
+            if (cur[1] - cur[0]) - (b - a) >= max(1, (cur[1] - cur[0]) // 8):
+                crops[si] = (a - cur[0], b - cur[0])
+                cur = (a, b)
             if st["up"]:
-                res *= 2
-                halo += 1 / res                                # the resample conv runs after the 2x upsample
-        halo = int(math.ceil(halo + 1 / res))                  # + the head conv
-        r0, r1 = rank * hc // world, (rank + 1) * hc // world
-        a, b = max(0, r0 - halo), min(hc, r1 + halo)
-        scale = int(res) * 2                                   # remaining upsamples x unpatchify
-        return cut, a, b, (r0 - a) * scale, (r1 - a) * scale, scale
+                cur = (2 * cur[0], 2 * cur[1])
+        return crops, r0 - 2 * cur[0], r1 - 2 * cur[0]
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, stripe=None) -> torch.Tensor:
@@ -656,9 +667,14 @@ class _DecoderEngine(_EngineBase):
             video = torch.empty(3, frames, h * scale * 2, w * scale * 2, device=self.device, dtype=F32)
             self._walk(x0, rows, tz, h, w, video, None)
             return video
-        cut, a, b, lo, hi, sc = self.stripe_plan(h, *stripe)
-        band = torch.empty(3, frames, (b - a) * sc, w * scale * 2, device=self.device, dtype=F32)
-        self._walk(x0, rows, tz, h, w, band, (cut, a, b))
+        crops, lo, hi = self.stripe_plan(h, *stripe)
+        held = h                                               # rows the band holds at the output resolution
+        for si, st in enumerate(self.stages):
+            if si in crops:
+                held = crops[si][1] - crops[si][0]
+            held *= 2 if st["up"] else 1
+        band = torch.empty(3, frames, 2 * held, w * scale * 2, device=self.device, dtype=F32)
+        self._walk(x0, rows, tz, h, w, band, crops)
         return band[:, :, lo:hi].contiguous()
 
     def _walk(self, x0, rows, tz, h, w, video, stripe):

@@ -97,19 +97,26 @@ def test_vae_encode_five_chunks_other_shape_repeatable_and_logvar():
     assert torch.isfinite(post.sample(generator=torch.Generator("cuda").manual_seed(0))).all()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_vae_row_band_decode_is_exact(world):
-    """Parallel decode: each rank decodes a band of output rows with a receptive-field halo; the
-    bands of all ranks, computed here one after another on one GPU, must tile the full decode BIT-EXACTLY."""
+@pytest.mark.parametrize("world,h", [(2, 8), (4, 8), (8, 8), (8, 32), (4, 20)])
+def test_vae_row_band_decode_is_exact(world, h):
+    """Parallel decode: each rank decodes a band of output rows with a receptive-field halo, re-cropped at every stage
+    (r6); the bands of all ranks, computed here one after another on one GPU, must tile the full decode BIT-EXACTLY.  h = 32 is the
+    97 x 512 x 896 clip's latent height: the crop pattern of every rank of eight at the real size (stage-0 crops at the edges, bands
+    of 32 / 36 / 46 rows in the middle)."""
     vae, sd = build(seed=55)
-    z = C.vae_case(seed=56, frames=3, h=8, w=4)
+    z = C.vae_case(seed=56, frames=3, h=h, w=4)
     full = vae.decode(z.cuda()).sample[0]
     eng = vae.engine()
     bands = [eng.decode(z[0].cuda(), stripe=(r, world)) for r in range(world)]
-    assert all(bd.shape == (3, 9, 128 // world, 64) for bd in bands)
+    assert all(bd.shape == (3, 9, 16 * h // world, 64) for bd in bands)
     torch.testing.assert_close(torch.cat(bands, dim=2), full, rtol=0, atol=0)
-    cut, a, b, lo, hi, sc = eng.stripe_plan(8, 1, world)
-    assert (cut, sc) == (2, 4) and b - a < 32 or world == 2          # bands are narrower than the frame once world > 2
+    plans = [eng.stripe_plan(h, r, world) for r in range(world)]
+    for crops, lo, hi in plans:
+        assert hi - lo == 16 * h // world and all(0 <= a < b for a, b in crops.values())
+    if world > 2:                                                    # the last stage works on less than the frame's 8 h rows
+        assert all(max(crops) == 3 and crops[3][1] - crops[3][0] < 8 * h for crops, _, _ in plans)
+    if h == 32:
+        assert plans[4][0] == {1: (20, 52), 2: (14, 50), 3: (13, 59)} and 0 in plans[0][0] and 0 in plans[7][0]
 
 
 @pytest.mark.parametrize("frames", [9, 12])
