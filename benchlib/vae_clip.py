@@ -41,12 +41,26 @@ def time_vae(device, frames, height, width):
 
 
 def time_decode_band(vae, device, frames, height, width, world, which=None):
-    """One rank's share of the row-band parallel decode (AutoencoderKLWan3_8.enable_parallel_decode: every rank decodes 1/N of the output
-    rows exactly, one all-gather of the bands assembles the clip): the band of rank `which` (default: a middle one, halos on both sides)
-    of a `world`-rank decode, timed on this GPU; the all-gather of the bands is not included.  -> seconds."""
+    """One rank's share of the tiled parallel decode (AutoencoderKLWan3_8.enable_parallel_decode: every rank decodes 1/N of the output
+    pixels exactly -- a tile of the grid _DecoderEngine.band_grid picks --, one all-gather assembles the clip): the SLOWEST tile of a
+    `world`-rank decode by the plan's own area model unless `which` names a rank, timed on this GPU; the all-gather is not included."""
     eng = vae.engine()
     z = torch.randn(48, (frames - 1) // 4 + 1, height // 16, width // 16, device=device)
-    r = world // 2 if which is None else which
+    if which is None:
+        cost = eng._stage_cost()
+
+        def work(rank):
+            crops, _, _ = eng.stripe_plan(z.shape[2], z.shape[3], rank, world)
+            hh, ww, c = z.shape[2], z.shape[3], 0.0
+            for si, st in enumerate(eng.stages):
+                if si in crops:
+                    hh, ww = crops[si][1] - crops[si][0], crops[si][3] - crops[si][2]
+                c += cost[si] * hh * ww
+                if st["up"]:
+                    hh, ww = 2 * hh, 2 * ww
+            return c
+        which = max(range(world), key=work)
+    r = which
     eng.decode(z, stripe=(r, world))                 # warm-up (this band's buffers)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -544,6 +544,7 @@ class _DecoderEngine(_EngineBase):
             self.head_conv = conv("decoder.head.2", tmul[-1])
         self.mean = torch.tensor(vae.latent_mean, device=dev, dtype=F32)
         self.std = torch.tensor(vae.latent_std, device=dev, dtype=F32)
+        self._grid_cache = {}
         del self.sd
 
     def _all_convs(self):
@@ -558,8 +559,9 @@ class _DecoderEngine(_EngineBase):
 
     def _chunk(self, src_rows, h, w, first, video, f0, stripe=None, t=1):
         """Decoder3d.forward on `t` latent frames (VAE.py:677-728; the first chunk is always the single first frame); writes 1 or 4 t
-        frames into `video`.  stripe = {stage: (a, b)}: rows [a, b) (relative to the rows it holds at that point) of the activation ENTERING
-        that stage are kept and everything after works on that row band (`video` is then the band's buffer); see stripe_plan."""
+        frames into `video`.  stripe = {stage: (a, b, ca, cb)}: rows [a, b) x columns [ca, cb) (relative to what it holds at that point) of
+        the activation ENTERING that stage are kept and everything after works on that tile (`video` is then the tile's buffer); see
+        stripe_plan."""
         c1 = self.conv1
         hip.vae_prep_cl(src_rows, c1.ci, t, h, w, c1.image(h, w), mode=0, t0=c1.hist)
         x = c1.run(t, h, w, out_dtype=F32)
@@ -568,10 +570,10 @@ class _DecoderEngine(_EngineBase):
         x = self._res(self.mid[2], x, t, h, w)
         for si, st in enumerate(self.stages):
             if stripe is not None and si in stripe:
-                a, b = stripe[si]
-                band = torch.zeros(t, b - a + 2, w + 2, x.shape[1], device=self.device, dtype=F32)
-                band[:, 1:-1] = x.view(t, h + 2, w + 2, -1)[:, a + 1:b + 1]
-                x, h = band.view(-1, x.shape[1]), b - a
+                a, b, ca, cb = stripe[si]
+                band = torch.zeros(t, b - a + 2, cb - ca + 2, x.shape[1], device=self.device, dtype=F32)
+                band[:, 1:-1, 1:-1] = x.view(t, h + 2, w + 2, -1)[:, a + 1:b + 1, ca + 1:cb + 1]
+                x, h, w = band.view(-1, x.shape[1]), b - a, cb - ca
             x_in, cin = x, x.shape[1]
             # the residual blocks update their input in place unless the first one has a shortcut convolution (a new tensor): only then
             # does x_in survive without a copy for the DupUp3D shortcut below
@@ -612,47 +614,111 @@ class _DecoderEngine(_EngineBase):
         hip.vae_unpatchify_clamp(y, t, h, w, video, f0)
         return t
 
-    def stripe_plan(self, h: int, rank: int, world: int):
-        """Row bands of the parallel decode for `rank` of `world`: which rows of the activation ENTERING each stage this rank
-        keeps so that its 1/world of the output rows comes out EXACT with no exchange.  Walking back from the output, the rows a stage
-        must deliver grow by the receptive field of what follows: 1 row for the head conv, 1 (at the upsampled resolution) for a resample
-        conv, 2 per residual block (two 3x3(x3) convs); a 2x upsample halves the range.  conv1 and the middle block (global attention)
-        always run on full frames.  r6: the band is re-cropped at EVERY stage where that removes >= 1/8 of the rows held (r1-r5 cropped
-        once, entering stage 2, and ran stages 0-1 on full frames: 0.47 of a whole decode per rank at 8 ranks; now ~0.3).
-        Returns (crops, keep_lo, keep_hi): crops = {stage: (a, b)} relative to the rows held when entering that stage; the band's video
-        has its own rows at [keep_lo, keep_hi)."""
+    def _axis_need(self, n: int, part: int, parts: int):
+        """One axis of stripe_plan: [lo, hi) of the activation ENTERING each stage that part `part` of `parts` needs for its share of the
+        2 n 2^ups output rows (or columns) to come out exact, and that share [r0, r1) itself."""
         n_st = len(self.stages)
-        H = [h]
+        N = [n]
         for st in self.stages:
-            H.append(H[-1] * (2 if st["up"] else 1))
-        h_out = 2 * H[-1]                                      # unpatchify doubles the rows once more
-        if h_out % world:
-            raise ValueError(f"{h_out} output rows do not divide over {world} ranks")
-        r0, r1 = rank * h_out // world, (rank + 1) * h_out // world
-        lo, hi = r0 // 2 - 1, -(-r1 // 2) + 1                  # rows of the head conv's input that its 3x3 window touches
+            N.append(N[-1] * (2 if st["up"] else 1))
+        n_out = 2 * N[-1]                                      # unpatchify doubles once more
+        if n_out % parts:
+            raise ValueError(f"{n_out} output rows / columns do not divide over {parts} parts")
+        r0, r1 = part * n_out // parts, (part + 1) * n_out // parts
+        lo, hi = r0 // 2 - 1, -(-r1 // 2) + 1                  # what the head conv's 3x3 window touches
         need = [None] * n_st
         for si in range(n_st - 1, -1, -1):
             st = self.stages[si]
-            lo, hi = max(0, lo), min(H[si + 1], hi)
-            if st["up"]:                                       # resample conv: 3x3 at the upsampled resolution = rows (y - 1) // 2 .. (y + 1) // 2 of the low one
+            lo, hi = max(0, lo), min(N[si + 1], hi)
+            if st["up"]:                                       # resample conv: 3x3 at the upsampled resolution = (y - 1) // 2 .. (y + 1) // 2 of the low one
                 lo, hi = (lo - 1) // 2, -(-(hi + 1) // 2)
             lo, hi = lo - 2 * len(st["res"]), hi + 2 * len(st["res"])
-            lo, hi = max(0, lo), min(H[si], hi)
-            need[si] = (lo, hi)
-        crops, cur = {}, (0, H[0])
-        for si, st in enumerate(self.stages):
-            a, b = need[si]
-            if (cur[1] - cur[0]) - (b - a) >= max(1, (cur[1] - cur[0]) // 8):
-                crops[si] = (a - cur[0], b - cur[0])
-                cur = (a, b)
+            need[si] = (max(0, lo), min(N[si], hi))
+        return need, N, r0, r1
+
+    def _stage_cost(self):
+        """Relative matrix work of a stage per pixel of ITS resolution and latent frame (weights of its convolutions x the frames the
+        temporal upsamples before it have made): what band_grid weighs the stages with."""
+        out, frames = [], 1
+        for st in self.stages:
+            n = sum(r[c].weight.numel() for r in st["res"] for c in ("c1", "c2")) + sum(r["short"].weight.numel() for r in st["res"] if r["short"] is not None)
             if st["up"]:
-                cur = (2 * cur[0], 2 * cur[1])
-        return crops, r0 - 2 * cur[0], r1 - 2 * cur[0]
+                rs = st["resample"]
+                n += sum(wt.numel() for wt in rs.weights) if hasattr(rs, "weights") else 4 * rs.weight.numel()
+                if st.get("time_conv") is not None:
+                    n += st["time_conv"].weight.numel()
+            out.append(n * frames)
+            if st["up"] and st["temporal"]:
+                frames *= 2
+        return out
+
+    def band_grid(self, h: int, w: int, world: int):
+        """(rows, columns) of the tile grid the parallel decode cuts the output into: the factorisation of `world` whose SLOWEST tile does
+        the least matrix work (area of what it holds in every stage x that stage's work per pixel).  A 97 x 512 x 896 clip on 8 ranks:
+        2 x 4 (0.72 of the work of 8 row bands: a tile's halo is a fixed number of rows / columns, so squarer tiles carry less of it)."""
+        key = (h, w, world)
+        if key in self._grid_cache:
+            return self._grid_cache[key]
+        cost = self._stage_cost()
+        best, best_c = None, None
+        for gr in range(world, 0, -1):                         # row bands first: another grid must beat them by 2 %
+            if world % gr:
+                continue
+            gc = world // gr
+            try:
+                worst = 0.0
+                for ri in range(gr):
+                    nr, _, _, _ = self._axis_need(h, ri, gr)
+                    for ci in range(gc):
+                        nc, _, _, _ = self._axis_need(w, ci, gc)
+                        c = 0.0
+                        for si, st in enumerate(self.stages):
+                            c += cost[si] * (nr[si][1] - nr[si][0]) * (nc[si][1] - nc[si][0])
+                        worst = max(worst, c)
+            except ValueError:
+                continue
+            if best is None or worst < best_c * 0.98:
+                best, best_c = (gr, gc), worst
+        if best is None:
+            raise ValueError(f"a [{16 * h}, {16 * w}] frame does not divide into {world} equal tiles")
+        self._grid_cache[key] = best
+        return best
+
+    def stripe_plan(self, h: int, w: int, rank: int, world: int):
+        """Tiles of the parallel decode for `rank` of `world`: which rows x columns of the activation ENTERING each stage this
+        rank keeps so that its tile of the output comes out EXACT with no exchange.  Walking back from the output, what a stage must
+        deliver grows by the receptive field of what follows: 1 for the head conv, 1 (at the upsampled resolution) for a resample conv,
+        2 per residual block (two 3x3(x3) convs); a 2x upsample halves the range (_axis_need, the same walk for both axes).  conv1 and
+        the middle block (global attention) always run on full frames.  r6: the tile is re-cropped at EVERY stage where that removes
+        >= 1/8 of what is held (r1-r5 cropped once, entering stage 2, row bands only: 0.47 of a whole decode per rank at 8 ranks; per-stage
+        row bands 0.35; the 2 x 4 grid band_grid picks for the 512 x 896 clip ~0.26).
+        Returns (crops, (lo, hi, clo, chi), (gr, gc)): crops = {stage: (a, b, ca, cb)} relative to what is held when entering that stage;
+        the tile's video has its own pixels at [lo, hi) x [clo, chi); rank = row * gc + column of the grid."""
+        gr, gc = self.band_grid(h, w, world)
+        ri, ci = divmod(rank, gc)
+        nr, _, r0, r1 = self._axis_need(h, ri, gr)
+        nc, _, c0, c1 = self._axis_need(w, ci, gc)
+        crops, cur, ccur = {}, (0, h), (0, w)
+        for si, st in enumerate(self.stages):
+            (a, b), (ca, cb) = nr[si], nc[si]
+            held, kept = (cur[1] - cur[0]) * (ccur[1] - ccur[0]), (b - a) * (cb - ca)
+            if held - kept >= max(1, held // 8):
+                crops[si] = (a - cur[0], b - cur[0], ca - ccur[0], cb - ccur[0])
+                cur, ccur = (a, b), (ca, cb)
+            if st["up"]:
+                cur, ccur = (2 * cur[0], 2 * cur[1]), (2 * ccur[0], 2 * ccur[1])
+        return crops, (r0 - 2 * cur[0], r1 - 2 * cur[0], c0 - 2 * ccur[0], c1 - 2 * ccur[0]), (gr, gc)
+
+    @staticmethod
+    def assemble_tiles(tiles, grid):
+        """Tiles [3, F, rows, cols] of all ranks (rank = row * gc + column) -> the frame."""
+        gr, gc = grid
+        return torch.cat([torch.cat(list(tiles[r * gc:(r + 1) * gc]), dim=3) for r in range(gr)], dim=2)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, stripe=None) -> torch.Tensor:
         """z [zc, T, H, W] -> video [3, 1 + 4(T-1), 16H, 16W] fp32 in [-1, 1].
-        stripe = (rank, world): only this rank's band of output rows, [3, F, 16H/world, 16W]."""
+        stripe = (rank, world): only this rank's tile of the output, [3, F, 16H/gr, 16W/gc] with (gr, gc) = band_grid(H, W, world)."""
         zc, tz, h, w = z.shape
         for c in self._all_convs():
             c.reset()
@@ -667,15 +733,15 @@ class _DecoderEngine(_EngineBase):
             video = torch.empty(3, frames, h * scale * 2, w * scale * 2, device=self.device, dtype=F32)
             self._walk(x0, rows, tz, h, w, video, None)
             return video
-        crops, lo, hi = self.stripe_plan(h, *stripe)
-        held = h                                               # rows the band holds at the output resolution
+        crops, (lo, hi, clo, chi), _ = self.stripe_plan(h, w, *stripe)
+        held, cheld = h, w                                     # rows / columns the tile holds at the output resolution
         for si, st in enumerate(self.stages):
             if si in crops:
-                held = crops[si][1] - crops[si][0]
-            held *= 2 if st["up"] else 1
-        band = torch.empty(3, frames, 2 * held, w * scale * 2, device=self.device, dtype=F32)
+                held, cheld = crops[si][1] - crops[si][0], crops[si][3] - crops[si][2]
+            held, cheld = held * (2 if st["up"] else 1), cheld * (2 if st["up"] else 1)
+        band = torch.empty(3, frames, 2 * held, 2 * cheld, device=self.device, dtype=F32)
         self._walk(x0, rows, tz, h, w, band, crops)
-        return band[:, :, lo:hi].contiguous()
+        return band[:, :, lo:hi, clo:chi].contiguous()
 
     def _walk(self, x0, rows, tz, h, w, video, stripe):
         """The chunk walk over the latent frames: frame 0 alone, then `self.chunk` frames at a time."""
@@ -860,9 +926,9 @@ class AutoencoderKLWan3_8(nn.Module):
         return self._engine
 
     def enable_parallel_decode(self, group=None):
-        """Row-band decode over the ranks of `group` (replaces the reference's missing `parallel_magvit_vae`,
-        FlexAM/models/__init__.py:36-38): every rank decodes 1/N of the output rows (exactly, see
-        _DecoderEngine.stripe_plan) and one all-gather assembles the clip."""
+        """Tiled decode over the ranks of `group` (replaces the reference's missing `parallel_magvit_vae`,
+        FlexAM/models/__init__.py:36-38): every rank decodes 1/N of the output pixels -- a tile of a rows x columns grid -- exactly
+        (see _DecoderEngine.stripe_plan) and one all-gather assembles the clip."""
         self._parallel_group, self._parallel = group, True
 
     def disable_parallel_decode(self):
@@ -876,7 +942,8 @@ class AutoencoderKLWan3_8(nn.Module):
         band = eng.decode(u, stripe=(dist.get_rank(self._parallel_group), world))
         bands = [torch.empty_like(band) for _ in range(world)]
         dist.all_gather(bands, band, group=self._parallel_group)
-        return torch.cat(bands, dim=2)
+        grid = eng.band_grid(u.shape[-2], u.shape[-1], world) if hasattr(eng, "band_grid") else (world, 1)
+        return _DecoderEngine.assemble_tiles(bands, grid)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):

@@ -182,6 +182,27 @@ def test_parallel_vae_decode_assembles_row_bands():
     assert all(run_world(_parallel_decode_gather, 2))
 
 
+def _parallel_decode_gather_tiles(rank, world):
+    from flexam_amd.wan_vae3_8 import AutoencoderKLWan3_8
+    full = torch.arange(3 * 5 * 8 * 6, dtype=torch.float32).view(3, 5, 8, 6)
+
+    class FakeEngine:                                     # a 2 x 2 grid: rank = row * 2 + column (what _DecoderEngine.band_grid / decode hand out)
+        def band_grid(self, h, w, n):
+            return (2, 2)
+        def decode(self, u, stripe=None):
+            r, n = stripe
+            ri, ci = divmod(r, 2)
+            return full[:, :, ri * 4:(ri + 1) * 4, ci * 3:(ci + 1) * 3].contiguous()
+    vae = AutoencoderKLWan3_8(c_dim=16, dec_dim=16)
+    vae.enable_parallel_decode()
+    out = vae._decode_one(FakeEngine(), torch.zeros(1, 1, 4, 3))
+    return bool(torch.equal(out, full))
+
+
+def test_parallel_vae_decode_assembles_a_tile_grid():
+    assert all(run_world(_parallel_decode_gather_tiles, 4))
+
+
 def _a2a_blocks_and_layouts(rank, world):
     """The all-to-all exchange of the head-parallel mode, with the send / receive layouts the engine uses:
     send [B, sp, lc, 3G] (block (b, j) -> rank j), receive [B, sp, lc, 3G] = [B, L, 3G] in token order, output chunks back to

@@ -2,6 +2,8 @@
 module output, small widths, 3 latent frames: first chunk, "Rep" hand-over, cached chunk) and against
 the fp32 oracle on another shape (4 chunks).  Tolerance: bf16 conv operands, fp32 accumulate and fp32
 residual stream -> PSNR >= 40 dB on the clamped [-1, 1] video (peak 2), rel-RMS <= 2e-2."""
+import math
+
 import pytest
 import torch
 
@@ -97,26 +99,65 @@ def test_vae_encode_five_chunks_other_shape_repeatable_and_logvar():
     assert torch.isfinite(post.sample(generator=torch.Generator("cuda").manual_seed(0))).all()
 
 
-@pytest.mark.parametrize("world,h", [(2, 8), (4, 8), (8, 8), (8, 32), (4, 20)])
-def test_vae_row_band_decode_is_exact(world, h):
-    """Parallel decode: each rank decodes a band of output rows with a receptive-field halo, re-cropped at every stage
-    (r6); the bands of all ranks, computed here one after another on one GPU, must tile the full decode BIT-EXACTLY.  h = 32 is the
-    97 x 512 x 896 clip's latent height: the crop pattern of every rank of eight at the real size (stage-0 crops at the edges, bands
-    of 32 / 36 / 46 rows in the middle)."""
+def test_vae_tiled_decode_is_exact_at_half_the_clip_size():
+    """The 2 x 4 grid of the clip itself on a [16, 28] latent.  At this size the tiles' GEMMs and the full frames' get different tail
+    split-K plans -- another fp32 summation order, the only difference between them: in a child process with FLEXAM_GEMM_SPLITK=0 (the
+    switch is read once per process) the tiles are bit-identical to the full decode; with the default plans they agree to > 50 dB."""
+    import os, subprocess, sys
+    env = dict(os.environ, FLEXAM_GEMM_SPLITK="0")
+    code = ("import sys; sys.path.insert(0, %r); import test_vae_gpu as T; T.test_vae_tiled_decode_is_exact(8, 16, 28); print('exact')"
+            % os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "exact" in r.stdout, r.stderr[-2000:]
     vae, sd = build(seed=55)
-    z = C.vae_case(seed=56, frames=3, h=h, w=4)
+    z = C.vae_case(seed=56, frames=3, h=16, w=28)
     full = vae.decode(z.cuda()).sample[0]
     eng = vae.engine()
-    bands = [eng.decode(z[0].cuda(), stripe=(r, world)) for r in range(world)]
-    assert all(bd.shape == (3, 9, 16 * h // world, 64) for bd in bands)
-    torch.testing.assert_close(torch.cat(bands, dim=2), full, rtol=0, atol=0)
-    plans = [eng.stripe_plan(h, r, world) for r in range(world)]
-    for crops, lo, hi in plans:
-        assert hi - lo == 16 * h // world and all(0 <= a < b for a, b in crops.values())
-    if world > 2:                                                    # the last stage works on less than the frame's 8 h rows
-        assert all(max(crops) == 3 and crops[3][1] - crops[3][0] < 8 * h for crops, _, _ in plans)
-    if h == 32:
-        assert plans[4][0] == {1: (20, 52), 2: (14, 50), 3: (13, 59)} and 0 in plans[0][0] and 0 in plans[7][0]
+    got = eng.assemble_tiles([eng.decode(z[0].cuda(), stripe=(r_, 8)) for r_ in range(8)], eng.band_grid(16, 28, 8))
+    mse = float((got - full).double().pow(2).mean())
+    assert mse == 0 or 10 * math.log10(4.0 / mse) > 50.0
+
+
+@pytest.mark.parametrize("world,h,w", [(2, 8, 4), (4, 8, 4), (8, 8, 4), (8, 32, 4), (4, 20, 4), (4, 8, 14), (6, 12, 6)])
+def test_vae_tiled_decode_is_exact(world, h, w):
+    """Parallel decode: each rank decodes one tile of a rows x columns grid with a receptive-field halo, re-cropped at every
+    stage (r6); the tiles of all ranks, computed here one after another on one GPU, must tile the full decode BIT-EXACTLY.  Narrow latents
+    (w = 4) get row bands -- h = 32 is the 97 x 512 x 896 clip's latent height: the row pattern of every rank of eight at the real size --,
+    wide ones a 2-D grid (16 x 28 is the clip's latent at half size: 2 x 4 tiles on 8 ranks, like the clip itself)."""
+    vae, sd = build(seed=55)
+    z = C.vae_case(seed=56, frames=3, h=h, w=w)
+    full = vae.decode(z.cuda()).sample[0]
+    eng = vae.engine()
+    gr, gc = eng.band_grid(h, w, world)
+    assert gr * gc == world
+    tiles = [eng.decode(z[0].cuda(), stripe=(r, world)) for r in range(world)]
+    assert all(tl.shape == (3, 9, 16 * h // gr, 16 * w // gc) for tl in tiles)
+    torch.testing.assert_close(eng.assemble_tiles(tiles, (gr, gc)), full, rtol=0, atol=0)
+    plans = [eng.stripe_plan(h, w, r, world) for r in range(world)]
+    for crops, (lo, hi, clo, chi), grid in plans:
+        assert grid == (gr, gc) and hi - lo == 16 * h // gr and chi - clo == 16 * w // gc
+        assert all(0 <= a < b and 0 <= ca < cb for a, b, ca, cb in crops.values())
+    if w == 4:
+        assert gc == 1                                               # nothing to win from cutting 64 columns
+        if world > 2:                                                # the last stage works on less than the frame's 8 h rows
+            assert all(max(crops) == 3 and crops[3][1] - crops[3][0] < 8 * h for crops, _, _ in plans)
+        if h == 32:
+            assert {k: v[:2] for k, v in plans[4][0].items()} == {1: (20, 52), 2: (14, 50), 3: (13, 59)} and 0 in plans[0][0] and 0 in plans[7][0]
+    if (world, h, w) == (8, 16, 28):
+        assert (gr, gc) == (2, 4)
+
+
+def test_vae_tile_grid_of_the_clip():
+    """The grid the 97 x 512 x 896 clip gets (latent 32 x 56): 2 x 4 tiles on 8 ranks, 2 x 2 on 4, two row bands on 2 (host logic of the real
+    decoder widths; no decode)."""
+    from flexam_amd import AutoencoderKLWan3_8
+    with torch.device("cuda"):
+        vae = AutoencoderKLWan3_8(spatial_compression_ratio=16).to(torch.bfloat16)
+    eng = vae.engine()
+    assert eng.band_grid(32, 56, 8) == (2, 4) and eng.band_grid(32, 56, 4) == (2, 2) and eng.band_grid(32, 56, 2)[0] * eng.band_grid(32, 56, 2)[1] == 2
+    crops, (lo, hi, clo, chi), grid = eng.stripe_plan(32, 56, 5, 8)            # second row of tiles, second column
+    assert (hi - lo, chi - clo) == (256, 224) and max(crops) == 3
 
 
 @pytest.mark.parametrize("frames", [9, 12])
