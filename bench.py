@@ -270,7 +270,7 @@ def main():
         enc_sec = 7 * enc_stream_sec + enc_image_sec     # control, depth, 4 cos levels, masked video + the reference image
         band_sec = None
         if n_emulate and n_emulate > 1:
-            try:                                         # one rank's row band of the N-rank parallel decode (for the predicted sec/clip below)
+            try:                                         # the slowest rank's tile of the N-rank parallel decode (for the predicted sec/clip below)
                 from benchlib.vae_clip import time_decode_band
                 band_sec = time_decode_band(vae, device, args.frames, args.height, args.width, n_emulate)
             except Exception as e:                       # noqa: BLE001
@@ -364,13 +364,13 @@ def main():
             clip_pred = None
             if vae_sec is not None and band_sec is not None:
                 # the clip on N ranks before any link time: the 8 conditioning streams encoded round-robin (dist.shard_streams: ceil(8 / N) per rank),
-                # prepare, 50 rank steps of the layout, this rank's row band of the decode (bands all-gathered: not included)
+                # prepare, 50 rank steps of the layout, the slowest rank's tile of the decode (tiles all-gathered: not included)
                 jobs = [enc_stream_sec] * 7 + [enc_image_sec]                     # stream j on rank j % N: the slowest rank's share
                 streams = max(sum(jobs[r::n_emulate]) for r in range(n_emulate))
-                clip_pred = {"vae_encode_sec": streams, "vae_decode_band_sec": band_sec, "prepare_sec": prepare_sec,
+                clip_pred = {"vae_encode_sec": streams, "vae_decode_tile_sec": band_sec, "prepare_sec": prepare_sec,
                              "per_layout": {r["layout"]: round(streams + prepare_sec + total_steps * r["ms_per_step"] * 1e-3 + band_sec, 3) for r in emulated if "ms_per_step" in r},
                              "single_gpu_sec_per_clip": enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec,
-                             "note": "sum of one rank's parts (7 videos + the reference image over the ranks, 50 rank steps, one row band of the decode) measured on "
+                             "note": "sum of one rank's parts (7 videos + the reference image over the ranks, 50 rank steps, the slowest tile of the tiled decode) measured on "
                                      "this GPU; no collective is timed: a ceiling, NOT a multi-GPU measurement"}
             result["emulated_ranks"] = {"world": n_emulate, "layouts": emulated, "host_enqueue_note": HOST_NOTE,
                                         "predicted_scaling_no_comm": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step"], 3) for r in emulated if "ms_per_step" in r},

@@ -168,10 +168,10 @@ def test_one_gpu_line_carries_an_emulated_rank_of_four():
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     em = res["emulated_ranks"]
     assert res["n_gpus"] == 1 and "invalid" not in res and em["world"] == 4
-    # with the VAE timed: the clip one rank would see -- its share of the 8 conditioning streams, 50 rank steps, its row band of the decode
+    # with the VAE timed: the clip one rank would see -- its share of the 8 conditioning streams, 50 rank steps, its tile of the decode
     cp = em["predicted_sec_per_clip_no_comm"]
     # (no size relation asserted: at this debug size every part is launch-bound)
-    assert cp["vae_decode_band_sec"] > 0 and cp["vae_encode_sec"] > 0 and set(cp["per_layout"]) == {row["layout"] for row in em["layouts"]}
+    assert cp["vae_decode_tile_sec"] > 0 and cp["vae_encode_sec"] > 0 and set(cp["per_layout"]) == {row["layout"] for row in em["layouts"]}
     assert all(v > 0 for v in cp["per_layout"].values()) and cp["single_gpu_sec_per_clip"] > 0
     names = [row["layout"] for row in em["layouts"]]
     assert names[0].startswith("cfg2 x sp2, K|V all-gather") and names[1].startswith("cfg1 x sp4, all-to-all over heads")
