@@ -369,9 +369,12 @@ def main():
                 streams = max(sum(jobs[r::n_emulate]) for r in range(n_emulate))
                 clip_pred = {"vae_encode_sec": streams, "vae_decode_tile_sec": band_sec, "prepare_sec": prepare_sec,
                              "per_layout": {r["layout"]: round(streams + prepare_sec + total_steps * r["ms_per_step"] * 1e-3 + band_sec, 3) for r in emulated if "ms_per_step" in r},
+                             "per_layout_at_link_GBps": {r["layout"]: {k: round(streams + prepare_sec + total_steps * v * 1e-3 + band_sec, 3) for k, v in r["ms_per_step_at_link_GBps"].items()}
+                                                         for r in emulated if "ms_per_step_at_link_GBps" in r},
                              "single_gpu_sec_per_clip": enc_sec + prepare_sec + total_steps / steps_per_sec + vae_sec,
                              "note": "sum of one rank's parts (7 videos + the reference image over the ranks, 50 rank steps, the slowest tile of the tiled decode) measured on "
-                                     "this GPU; no collective is timed: a ceiling, NOT a multi-GPU measurement"}
+                                     "this GPU; no collective is timed: a ceiling, NOT a multi-GPU measurement.  per_layout_at_link_GBps: the same sum with the rank steps "
+                                     "of the link MODEL (link_time_note); the latent broadcasts and the all-gather of the tiles (67 MB per link) are not in it"}
             result["emulated_ranks"] = {"world": n_emulate, "layouts": emulated, "host_enqueue_note": HOST_NOTE,
                                         "predicted_scaling_no_comm": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step"], 3) for r in emulated if "ms_per_step" in r},
                                         "predicted_scaling_compute_only": {r["layout"]: round(elapsed / args.steps * 1e3 / r["ms_per_step_compute_only"], 3)
