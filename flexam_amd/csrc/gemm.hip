@@ -58,6 +58,7 @@ struct GemmParams {
   // (gemm_splitk_finish_kernel) adds the slices up in slice order and runs the epilogue
   int units, split_full, split_s;
   float* ws;
+  int x_nt;                // gate-residual epilogue: X leaves / arrives with non-temporal hints (launch() decides: only when X is larger than the Infinity Cache can keep)
   int debug;               // only in -DFLEXAM_GEMM_ABLATE builds (timing ablations, WRONG results): 1 no vmcnt wait, 2 no barrier, 4 no LDS-DMA, 8 half the ds_reads, 16 half the LDS-DMA
 };
 
@@ -491,8 +492,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
         }
       // GATE: 0 no gate, 1 gate row from the per-row table, 2 gate row = m / rows_per_batch (one straight-line body each:
       // a uniform branch per load would keep the loads from being issued together)
-      auto rmw = [&](auto gate_c) {
+      auto rmw = [&](auto gate_c, auto nt_c) {
         constexpr int GATE = decltype(gate_c)::value;
+        constexpr bool NT = decltype(nt_c)::value;
         constexpr int TPB = 32 / RT;                   // row tiles per batch of 32 rows (8 load / store instructions)
         constexpr int NB = (NRT + TPB - 1) / TPB;      // batches per wave tile
         // TWO batches in flight: the X (and gate) loads of batch b + 1 are issued before batch b is consumed, so a wave pays
@@ -507,7 +509,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
             if (i >= nit) continue;
             // X is 286 MB of fp32 at the DiT shapes -- larger than the Infinity Cache -- and every element is touched once per launch:
             // non-temporal loads and stores keep it from evicting the operands that ARE re-read (-0.8 ... -0.9 % of a step, profiles/r4as_*)
-            xb[i] = __builtin_nontemporal_load((const f32x4*)(xtile + (int64_t)(t0 * RT + 4 * i) * p.ldx * 4 + xlane));
+            const f32x4* xp_ = (const f32x4*)(xtile + (int64_t)(t0 * RT + 4 * i) * p.ldx * 4 + xlane);
+            xb[i] = NT ? __builtin_nontemporal_load(xp_) : *xp_;
           }
         };
         // gate rows of the wave tile: in LDS since this unit's K block 0 (grow_dma)
@@ -544,7 +547,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
               f32x4 x = xb[idx];
 #pragma unroll
               for (int j = 0; j < 4; ++j) x[j] += GATE != 0 ? bf2f(y[j]) * gv[idx][j] : bf2f(y[j]);
-              __builtin_nontemporal_store(x, (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane));      // (shadow lanes: the same 16 bytes again)
+              f32x4* xs_ = (f32x4*)(xtile + (int64_t)(t0 * RT + 4 * idx) * p.ldx * 4 + xlane);      // (shadow lanes: the same 16 bytes again)
+              if constexpr (NT) __builtin_nontemporal_store(x, xs_);
+              else *xs_ = x;
             }
           }
         };
@@ -560,9 +565,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
           if (b + 1 < NB) load_g(b + 1);
         }
       };
-      if (!p.gate) rmw(IC<0>{});
-      else if (p.gate_row) rmw(IC<1>{});
-      else rmw(IC<2>{});
+      using NT1 = std::integral_constant<bool, true>;
+      using NT0 = std::integral_constant<bool, false>;
+      if (p.x_nt) {
+        if (!p.gate) rmw(IC<0>{}, NT1{});
+        else if (p.gate_row) rmw(IC<1>{}, NT1{});
+        else rmw(IC<2>{}, NT1{});
+      } else {
+        if (!p.gate) rmw(IC<0>{}, NT0{});
+        else if (p.gate_row) rmw(IC<1>{}, NT0{});
+        else rmw(IC<2>{}, NT0{});
+      }
       // every load of this epilogue has been consumed; saying so with an instruction the compiler's wait bookkeeping sees keeps
       // it from putting a vmcnt(0) of its own in front of the next unit's first register reuse (behind the stores)
       __builtin_amdgcn_s_waitcnt(0x0F70 | (PEND & 15) | ((PEND >> 4) << 14));
@@ -886,6 +899,13 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
     const char* g = getenv("FLEXAM_GEMM_GM");
     p.gm = g ? atoi(g) : (EPI == EPI_GATE_RESIDUAL && a_koff == nullptr && p.K >= 8192 ? 1 : 4);
     if (p.gm < 1) p.gm = 4;
+  }
+  if constexpr (EPI == EPI_GATE_RESIDUAL) {
+    // X (fp32 residual stream) with non-temporal hints only when it cannot stay in the 256 MB Infinity Cache anyway (the single-GPU CFG pair:
+    // 286 MB, -0.8 % of a step with the hints, r4as); a sequence-parallel rank's 36-72 MB is touched six times per block and should stay cached.
+    // FLEXAM_GEMM_X_NT=0 / 1 forces (A/B).
+    const char* e = getenv("FLEXAM_GEMM_X_NT");
+    p.x_nt = e ? atoi(e) : ((int64_t)p.M * p.N * 4 > (int64_t)160 << 20);
   }
 #ifdef FLEXAM_GEMM_ABLATE
   const char* dbg = getenv("FLEXAM_GEMM_DEBUG");
