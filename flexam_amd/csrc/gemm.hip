@@ -65,8 +65,8 @@ struct GemmParams {
 template <int V>
 using IC = std::integral_constant<int, V>;
 
-#if (defined(FLEXAM_GEMM_ABLATE) || defined(FLEXAM_GEMM_HALF_FRAG)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
-#error "FLEXAM_GEMM_ABLATE / FLEXAM_GEMM_HALF_FRAG builds give WRONG results (timing ablations): add -DFLEXAM_DIAGNOSTIC_BUILD"
+#if (defined(FLEXAM_GEMM_ABLATE) || defined(FLEXAM_GEMM_HALF_FRAG) || defined(FLEXAM_GEMM_STAMPS)) && !defined(FLEXAM_DIAGNOSTIC_BUILD)
+#error "FLEXAM_GEMM_ABLATE / FLEXAM_GEMM_HALF_FRAG (WRONG results: timing ablations) and FLEXAM_GEMM_STAMPS (in-kernel clock stamps) are switches of diagnostic builds: add -DFLEXAM_DIAGNOSTIC_BUILD"
 #endif
 #ifdef FLEXAM_GEMM_ABLATE
 #define ABLATE(p, bit) ((p).debug & (bit))
@@ -74,6 +74,12 @@ using IC = std::integral_constant<int, V>;
 #define ABLATE(p, bit) 0
 #endif
 
+#ifdef FLEXAM_GEMM_STAMPS      // diagnostic builds only: the anatomy of a launch -- per workgroup the 100 MHz counter at kernel entry, when the first K block of its
+__device__ unsigned long long g_gemm_stamps[4 * 1024];      // first unit has landed, at the end of its last K loop and at exit; read by nobody on the device
+#define GEMM_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 1024) g_gemm_stamps[4 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define GEMM_STAMP(i)
+#endif
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RESIDUAL = 2 };
 
 // MT = 16-row m-tiles per wave: the workgroup tile is (32*MT) x 256 outputs, 8 waves = 2(M) x 4(N), two per SIMD.
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   asm volatile("" : "+s"(wave));
   const int wm = wave / WNW, wn = wave % WNW;
+  if constexpr (!TAIL) { GEMM_STAMP(0); }
 
   // ---- persistent workgroups over an XCD-aware, grouped tile order: workgroup w lives on XCD w & 7 (round-robin
   // dispatch); that XCD owns a contiguous chunk of the tile list and its gridDim/8 workgroups walk the chunk with
@@ -343,6 +350,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   else if (!pend && nkl > 1) wait_barrier(IC<NP>{});     // only K block 1 is younger than K block 0
   else wait_barrier(IC<0>{});                            // (one or two K blocks: drain everything)
   pend = false;
+  if constexpr (!TAIL) { if (it == 0) { GEMM_STAMP(1); } }
   // The staging offsets are read by asm statements inside the K loop.  Should one of them ever come back from a spill slot, the
   // compiler's own wait for that reload must land here and not in the loop, where a vmcnt(0) would drain the LDS-DMA pipeline
   // on every K block.
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   for (; kb + 2 < nkl; ++kb) block(kb, T_{}, T_{}, IC<0>{});
   if (kb + 1 < nkl) { block(kb, F_{}, T_{}, IC<0>{}); ++kb; }
   block(kb, F_{}, F_{}, IC<0>{});
+  if constexpr (!TAIL) { GEMM_STAMP(2); }
 
   // ---- the next unit's first two K blocks go on their way before this tile's epilogue: both buffers are idle from here on
   // (every wave passed the last barrier with its fragments in registers) and the epilogue has its own slice of LDS
@@ -719,6 +728,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): edge tiles / fp32 outputs issue an unknown number of stores, drained here (pend stays false)
   }   // !TAIL
   }   // tile loop
+  if constexpr (!TAIL) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // (stamps only: the epilogue's stores have left)
+    GEMM_STAMP(3);
+  }
 }
 
 // Second half of the tail split-K: one workgroup per (tail tile, row tile t).  Thread `te` owns the same 16-byte elements the
@@ -965,6 +978,13 @@ int launch(const GemmParams& p_, void* ws, int64_t ws_bytes, const int64_t* a_ko
 }
 
 }  // namespace
+
+#ifdef FLEXAM_GEMM_STAMPS
+// diagnostic builds only (not declared in flexam_hip.h): the per-workgroup stamps of the last whole-tile GEMM launch
+extern "C" int flexam_debug_gemm_stamps(unsigned long long* out, int n_workgroups) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), (size_t)n_workgroups * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int flexam_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C,
                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, int out_f32,
