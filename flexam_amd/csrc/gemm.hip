@@ -728,10 +728,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(GemmParams p, const i
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): edge tiles / fp32 outputs issue an unknown number of stores, drained here (pend stays false)
   }   // !TAIL
   }   // tile loop
+#ifdef FLEXAM_GEMM_STAMPS
   if constexpr (!TAIL) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // (stamps only: the epilogue's stores have left)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // the epilogue's stores have left
     GEMM_STAMP(3);
   }
+#endif
 }
 
 // Second half of the tail split-K: one workgroup per (tail tile, row tile t).  Thread `te` owns the same 16-byte elements the
